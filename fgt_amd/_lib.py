@@ -1,0 +1,84 @@
+"""ctypes binding of libfgt_hip.so (see include/fgt_hip.h).  There is NO fallback: a missing or unloadable
+library raises at first use, and every non-zero return code raises RuntimeError with the library's message."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfgt_hip.so")
+
+ACT = {"none": 0, None: 0, "lrelu": 1, "relu": 2, "sigmoid": 3, "tanh": 4}
+EPI = {"none": 0, None: 0, "mul": 1, "add": 2, "gru": 3}
+TILE = {"auto": 0, None: 0, "128x128": 1, "128x64": 2, "64x64": 3, "128x32": 4, "256x128": 5}
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C0", "ld0", "off0", "C1", "ld1", "off1", "Cout", "groups",
+                                       "kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw", "upsample", "pad_mode",
+                                       "in_relu", "Ho", "Wo", "ldo", "ooff", "out_nchw", "act")] + \
+               [("slope", C.c_float)] + \
+               [(n, C.c_int) for n in ("epi", "act2", "ld_aux1", "ld_aux2")] + \
+               [("out_scale", C.c_float)] + \
+               [(n, C.c_int) for n in ("Kpad", "Npad", "tile")]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("mode", "b", "t", "h", "w", "nh", "nw", "heads", "group", "ws", "n_global",
+                                       "ldq", "qoff", "ldk", "koff", "ldv", "voff", "ldg_k", "ldg_v", "ldo")]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_long
+_F = C.c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "fgt_last_error": [],
+    "fgt_abi_version": [],
+    "fgt_conv2d": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "fgt_layernorm": [_P, _I, _I, _P, _I, _I, _L, _F, _P, _P, _P, _I, _P, _P, _P, _I, _P],
+    "fgt_attention": [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P],
+    "fgt_dw_pool": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
+    "fgt_dw3x3_residual": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "fgt_fold": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P],
+    "fgt_nchw_to_nhwc": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _F, _P],
+    "fgt_nhwc_to_nchw": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "fgt_pad_tokens": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "fgt_warp": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "fgt_fb_consistency": [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P],
+    "fgt_avgpool2": [_P, _L, _I, _I, _P, _P],
+    "fgt_corr_lookup": [C.POINTER(_P), _I, _I, _I, _I, _I, _P, _P, _I, _P],
+    "fgt_convex_upsample": [_P, _I, _P, _I, _I, _I, _I, _P, _P],
+    "fgt_instnorm_stats": [_P, _I, _I, _I, _I, _P, _P],
+    "fgt_instnorm_apply": [_P, _I, _I, _I, _I, _P, _F, _I, _P, _I, _I, _P, _I, _P],
+    "fgt_axpby": [_P, _I, _F, _P, _I, _F, _L, _I, _I, _P, _I, _P],
+    "fgt_compose_blend": [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P],
+    "fgt_prof_enable": [_I],
+    "fgt_prof_collect": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)],
+}
+_RESTYPES = {"fgt_last_error": C.c_char_p, "fgt_prof_enable": None}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first (python -m fgt_amd.build). "
+                "fgt_amd has no CPU/PyTorch fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if the .so does not export a declared symbol
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().fgt_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,237 @@
+// Streaming-softmax attention for FGT's two attention flavours, head dim 128, fp32 matrix cores.
+//
+// A wavefront owns 32 queries.  Both contractions are issued "swapped" so the query index stays in
+// the lane (lane & 31) from QK^T through the softmax to PV and no cross-lane transpose is needed:
+//   S^T[key][q] = sum_d K[key][d] Q[q][d]      A = K tile (LDS), B = Q (registers)   -> C: col = q, rows = keys
+//   O^T[d][q]  += sum_key V[key][d] P[q][key]  A = V tile (LDS), B = P (the S^T accumulator registers themselves)
+// The k index of v_mfma_f32_32x32x2_f32 is lane>>5 (h).  For QK^T step s contracts d = 64*h + s, so each
+// lane needs a contiguous 64-float run of its Q/K row (float4 LDS reads).  For PV step e contracts the key
+// the lane already holds in accumulator register e: key(e, h) = (e&3) + 8*(e>>2) + 4*h.
+// Row max / sum need one exchange with lane^32.  O^T keeps q in the lane, so the online-softmax rescale is
+// a per-lane scalar multiply.
+//
+// The zone / window / head gathers of the reference (attention_base.py:61-69, attention_flow.py:76-108)
+// are folded into the row addressing: Q, K, V are read in place from the projection GEMM outputs.
+#include "common.h"
+
+namespace {
+
+struct AttnP {
+    fgt_attn_desc d;
+    const float *Q, *K, *V, *KG, *VG;
+    float* O;
+    int n_q, n_k, zh, zw, gh, gw, n_loc;
+    float scale_log2e;
+};
+
+constexpr int HD = 128;    // head dim
+constexpr int KT = 32;     // keys per tile
+constexpr int KLD = HD + 4;  // K tile row stride (floats): float4-aligned, conflict-free b128 reads
+
+struct Prob { int frame0, zi, zj, hd; };
+
+// pixel index (row of a [bt, nh, nw] map) of local token n of the problem
+__device__ __forceinline__ int local_pix(const AttnP& p, const Prob& pr, int n) {
+    const fgt_attn_desc& d = p.d;
+    if (d.mode == 0) {
+        const int zsz = p.zh * p.zw;
+        const int tt = n / zsz, rem = n - tt * zsz;
+        const int i = rem / p.zw, j = rem - i * p.zw;
+        return ((pr.frame0 + tt) * d.nh + pr.zi * p.zh + i) * d.nw + pr.zj * p.zw + j;
+    } else {
+        const int a = n / d.ws, b = n - a * d.ws;
+        return (pr.frame0 * d.nh + pr.zi * d.ws + a) * d.nw + pr.zj * d.ws + b;
+    }
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 2) attn_kernel(const AttnP p) {
+    constexpr int NT = NW * 64;
+    constexpr int LD_IT = KT * (HD / 4) / NT;  // float4 per thread per tensor per tile
+    __shared__ __attribute__((aligned(16))) float Ks[KT * KLD];
+    __shared__ __attribute__((aligned(16))) float Vs[KT * HD];
+
+    const fgt_attn_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    Prob pr;
+    {
+        int y = blockIdx.y;
+        pr.hd = y % d.heads; y /= d.heads;
+        if (d.mode == 0) {
+            pr.zj = y % d.group; y /= d.group;
+            pr.zi = y % d.group; y /= d.group;
+            pr.frame0 = y * d.t;
+        } else {
+            pr.zj = y % p.gw; y /= p.gw;
+            pr.zi = y % p.gh; y /= p.gh;
+            pr.frame0 = y;
+        }
+    }
+    const int choff = pr.hd * HD;
+
+    // ---- Q rows into registers: q[s] = Q[row][64*lh + s]
+    const int qi = blockIdx.x * (NW * 32) + wave * 32 + l31;
+    const int qpix = local_pix(p, pr, min(qi, p.n_q - 1));
+    float q[64];
+    {
+        const float* qp = p.Q + (long)qpix * d.ldq + d.qoff + choff + 64 * lh;
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const float4 v = *reinterpret_cast<const float4*>(qp + 4 * s4);
+            q[4 * s4 + 0] = v.x; q[4 * s4 + 1] = v.y; q[4 * s4 + 2] = v.z; q[4 * s4 + 3] = v.w;
+        }
+    }
+
+    f32x16 o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int k0 = 0; k0 < p.n_k; k0 += KT) {
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int it = 0; it < LD_IT; ++it) {
+            const int idx = tid + it * NT;
+            const int row = idx >> 5, c4 = idx & 31;
+            const int key = min(k0 + row, p.n_k - 1);
+            const float *kp, *vp;
+            if (key < p.n_loc) {
+                const long pix = local_pix(p, pr, key);
+                kp = p.K + pix * d.ldk + d.koff + choff;
+                vp = p.V + pix * d.ldv + d.voff + choff;
+            } else {
+                const long gr = (long)pr.frame0 * d.n_global + (key - p.n_loc);
+                kp = p.KG + gr * d.ldg_k + choff;
+                vp = p.VG + gr * d.ldg_v + choff;
+            }
+            const float4 kv = *reinterpret_cast<const float4*>(kp + c4 * 4);
+            const float4 vv = *reinterpret_cast<const float4*>(vp + c4 * 4);
+            *reinterpret_cast<float4*>(Ks + row * KLD + c4 * 4) = kv;
+            *reinterpret_cast<float4*>(Vs + row * HD + c4 * 4) = vv;
+        }
+        __syncthreads();
+
+        // ---- S^T tile = K . Q^T
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        const float* krow = Ks + l31 * KLD + 64 * lh;
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const float4 kf = *reinterpret_cast<const float4*>(krow + 4 * s4);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, q[4 * s4 + 0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, q[4 * s4 + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, q[4 * s4 + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, q[4 * s4 + 3], s, 0, 0, 0);
+        }
+        // ---- online softmax (base-2 exponent), keys of this lane: k0 + (e&3) + 8*(e>>2) + 4*lh
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const float v = key < p.n_k ? s[e] * p.scale_log2e : -INFINITY;
+            s[e] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float pe = exp2f(s[e] - m_new);
+            s[e] = pe;
+            psum += pe;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float* vrow = Vs + ((e & 3) + 8 * (e >> 2) + 4 * lh) * HD + l31;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[t * 32], s[e], o[t], 0, 0, 0);
+        }
+    }
+
+    // ---- normalise and store: lane holds q = l31; o[t][e] is d = t*32 + (e&3) + 8*(e>>2) + 4*lh
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_tot;
+    if (qi < p.n_q) {
+        long orow;
+        bool keep = true;
+        if (d.mode == 0) {
+            orow = qpix;
+        } else {
+            const int fr = qpix / (d.nh * d.nw), rem = qpix - fr * (d.nh * d.nw);
+            const int y = rem / d.nw, x = rem - y * d.nw;
+            keep = y < d.h && x < d.w;
+            orow = ((long)fr * d.h + y) * d.w + x;
+        }
+        if (keep) {
+            float* op = p.O + orow * d.ldo + choff + 4 * lh;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const float4 v = make_float4(o[t][4 * e4 + 0] * inv, o[t][4 * e4 + 1] * inv,
+                                                 o[t][4 * e4 + 2] * inv, o[t][4 * e4 + 3] * inv);
+                    *reinterpret_cast<float4*>(op + t * 32 + 8 * e4) = v;
+                }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int fgt_attention(const fgt_attn_desc* dd, const float* Q, const float* K, const float* V,
+                             const float* KG, const float* VG, float* O, void* stream) {
+    FGT_REQUIRE(dd && Q && K && V && O, "fgt_attention: null pointer");
+    AttnP p;
+    p.d = *dd;
+    const fgt_attn_desc& d = p.d;
+    FGT_REQUIRE(d.heads > 0 && d.nh > 0 && d.nw > 0 && d.b > 0 && d.t > 0, "fgt_attention: bad sizes");
+    FGT_REQUIRE(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.ldo % 4 == 0 && d.qoff % 4 == 0 &&
+                d.koff % 4 == 0 && d.voff % 4 == 0, "fgt_attention: strides/offsets must be multiples of 4 floats");
+    FGT_REQUIRE((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)KG | (uintptr_t)VG) & 15) == 0,
+                "fgt_attention: pointers must be 16-byte aligned");
+    p.Q = Q; p.K = K; p.V = V; p.KG = KG; p.VG = VG; p.O = O;
+    p.scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
+    p.zh = p.zw = p.gh = p.gw = 0;
+    int problems;
+    if (d.mode == 0) {
+        FGT_REQUIRE(d.group > 0 && d.nh % d.group == 0 && d.nw % d.group == 0, "fgt_attention: grid %dx%d not divisible into %d zones", d.nh, d.nw, d.group);
+        p.zh = d.nh / d.group; p.zw = d.nw / d.group;
+        p.n_q = p.n_k = p.n_loc = d.t * p.zh * p.zw;
+        problems = d.b * d.group * d.group * d.heads;
+    } else if (d.mode == 1) {
+        FGT_REQUIRE(d.ws > 0 && d.nh % d.ws == 0 && d.nw % d.ws == 0 && d.h <= d.nh && d.w <= d.nw && d.h > 0 && d.w > 0, "fgt_attention: bad window geometry");
+        FGT_REQUIRE(d.n_global >= 0 && (d.n_global == 0 || (KG && VG && d.ldg_k % 4 == 0 && d.ldg_v % 4 == 0)), "fgt_attention: global tokens missing");
+        p.gh = d.nh / d.ws; p.gw = d.nw / d.ws;
+        p.n_q = p.n_loc = d.ws * d.ws;
+        p.n_k = p.n_loc + d.n_global;
+        problems = d.b * d.t * p.gh * p.gw * d.heads;
+    } else {
+        fgt_set_error("fgt_attention: unknown mode %d", d.mode);
+        return FGT_EINVAL;
+    }
+    FGT_REQUIRE(problems <= 65535, "fgt_attention: too many problems (%d) for grid.y", problems);
+    hipStream_t s = (hipStream_t)stream;
+    if (p.n_q <= 64) {
+        dim3 grid(cdiv(p.n_q, 64), problems);
+        hipLaunchKernelGGL((attn_kernel<2>), grid, dim3(128), 0, s, p);
+    } else {
+        dim3 grid(cdiv(p.n_q, 128), problems);
+        hipLaunchKernelGGL((attn_kernel<4>), grid, dim3(256), 0, s, p);
+    }
+    return fgt_check_launch("attn_kernel");
+}

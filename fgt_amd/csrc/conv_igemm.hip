@@ -1,0 +1,342 @@
+// Implicit-GEMM convolution / GEMM for gfx950 on the fp32 matrix cores.
+//
+//   M = N*Ho*Wo output pixels, N = Cout per group, K = kh*kw*Cin_per_group (k = (ky*kw+kx)*Cg + ci).
+//
+// One workgroup computes a BM x BN tile with WM x WN wavefronts; each wavefront owns (BM/WM) x (BN/WN)
+// outputs as TM x TN accumulators of v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 157 TF peak).
+// Per K-step of 32: every thread gathers float4 runs of the channels-last input (im2col on the fly:
+// stride, dilation, zero/replicate padding, nearest x2 upsample, two concatenated sources, optional
+// ReLU on the gathered value) and float4 runs of the packed weights into registers while the previous
+// step's LDS tiles feed the MFMAs; LDS is double buffered with one barrier per step.
+// LDS tiles are [rows][33] floats: both the 4 x ds_write_b32 of a float4 run and the per-lane
+// ds_read_b32 of an MFMA operand (row = lane&31, k = 2*kk + lane>>5) are bank-conflict free.
+#include <vector>
+#include "common.h"
+
+namespace {
+
+struct ConvP {
+    fgt_conv_desc d;
+    const float *x0, *x1, *w, *cscale, *cbias, *aux1, *aux2;
+    float* out;
+    int M, HoWo, Cg0, Cg1, Cg, K, Cout_g, Hin, Win, nk;
+};
+
+constexpr int BK = 32;
+constexpr int LDS_LD = 33;
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int RPP = NT / 8;  // tile rows covered per pass of the loader
+    constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    constexpr int STAGE = (BM + BN) * LDS_LD;
+    static_assert(A_IT >= 1 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile too small for the thread count");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const fgt_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int q = tid & 7, r = tid >> 3;
+    const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN, g = blockIdx.z;
+
+    // ---- per-thread im2col row state (fixed over the K loop)
+    int a_iy0[A_IT], a_ix0[A_IT];
+    int a_nb[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int m = bm0 + r + it * RPP;
+        if (m < p.M) {
+            const int n_img = m / p.HoWo, rem = m - n_img * p.HoWo;
+            const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
+            a_iy0[it] = oy * d.sh - d.ph;
+            a_ix0[it] = ox * d.sw - d.pw;
+            a_nb[it] = n_img * d.H * d.W;
+        } else {
+            a_iy0[it] = 0; a_ix0[it] = 0; a_nb[it] = -1;
+        }
+    }
+    // k-decomposition of this thread's float4 column, advanced incrementally by BK per step
+    int k_cur = q * 4;
+    int tap = k_cur / p.Cg;
+    int ci = k_cur - tap * p.Cg;
+    int ky = tap / d.kw, kx = tap - ky * d.kw;
+
+    const float* wrow[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+        wrow[it] = p.w + ((long)g * d.Npad + bn0 + r + it * RPP) * d.Kpad + q * 4;
+
+    float4 va[A_IT], vb[B_IT];
+
+    auto load_tiles = [&]() {
+        // A: gather
+        const bool kval = k_cur < p.K;
+        const float* src; int ld, ch;
+        if (ci < p.Cg0) { src = p.x0; ld = d.ld0; ch = d.off0 + g * p.Cg0 + ci; }
+        else            { src = p.x1; ld = d.ld1; ch = d.off1 + g * p.Cg1 + (ci - p.Cg0); }
+        const int dy = ky * d.dh, dx = kx * d.dw;
+        const int ush = d.upsample ? 1 : 0;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int iy = a_iy0[it] + dy, ix = a_ix0[it] + dx;
+            if (d.pad_mode) {
+                iy = min(max(iy, 0), p.Hin - 1);
+                ix = min(max(ix, 0), p.Win - 1);
+            }
+            const bool ok = kval && a_nb[it] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            // branch-free: invalid lanes read the (always mapped) first float4 of the source and discard it
+            const long off = ok ? ((long)(a_nb[it] + (iy >> ush) * d.W + (ix >> ush)) * ld + ch) : 0l;
+            float4 v = *reinterpret_cast<const float4*>(src + off);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d.in_relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            va[it] = v;
+        }
+        // B: packed weights, always in bounds (zero padded to Npad x Kpad)
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            vb[it] = *reinterpret_cast<const float4*>(wrow[it]);
+            wrow[it] += BK;
+        }
+        // advance the k decomposition
+        k_cur += BK;
+        ci += BK;
+        while (ci >= p.Cg) {
+            ci -= p.Cg;
+            if (++kx == d.kw) { kx = 0; ++ky; }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + BM * LDS_LD;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            float* dst = As + (r + it * RPP) * LDS_LD + q * 4;
+            dst[0] = va[it].x; dst[1] = va[it].y; dst[2] = va[it].z; dst[3] = va[it].w;
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            float* dst = Bs + (r + it * RPP) * LDS_LD + q * 4;
+            dst[0] = vb[it].x; dst[1] = vb[it].y; dst[2] = vb[it].z; dst[3] = vb[it].w;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    load_tiles();
+    store_tiles(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < p.nk; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < p.nk;
+        if (more) load_tiles();
+        const float* Ab = smem + buf * STAGE + (wm * WTM + l31) * LDS_LD + lh;
+        const float* Bb = smem + buf * STAGE + BM * LDS_LD + (wn * WTN + l31) * LDS_LD + lh;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = Ab[i * 32 * LDS_LD + 2 * kk];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bb[j * 32 * LDS_LD + 2 * kk];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  The accumulators go through LDS (the tile buffers are free now) so that the
+    // global side is a compact, coalesced float4 loop shared by every epilogue flavour.
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+    constexpr int EP_PASSES = (BM * BN > 2 * STAGE) ? 2 : 1;
+    constexpr int EP_BM = BM / EP_PASSES;
+    constexpr int WM_PER_PASS = WM / EP_PASSES;
+    static_assert(EP_BM * BN <= 2 * STAGE, "epilogue staging does not fit in the tile buffers");
+    float* Cs = smem;
+    const bool vec_ok = (p.Cout_g % 4 == 0) && !d.out_nchw && (d.ldo % 4 == 0) && (d.ooff % 4 == 0) &&
+                        (d.epi == FGT_EPI_NONE || d.ld_aux1 % 4 == 0) && (d.epi != FGT_EPI_GRU || d.ld_aux2 % 4 == 0);
+#pragma unroll
+    for (int ps = 0; ps < EP_PASSES; ++ps) {
+        if (ps > 0) __syncthreads();
+        if (wm / WM_PER_PASS == ps) {
+            const int wml = wm % WM_PER_PASS;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        Cs[(wml * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * BN + wn * WTN + j * 32 + l31] = acc[i][j][e];
+        }
+        __syncthreads();
+        const int mbase = bm0 + ps * EP_BM;
+        for (int idx = tid; idx < EP_BM * (BN / 4); idx += NT) {
+            const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
+            const int m = mbase + row;
+            const int n = bn0 + c4 * 4;
+            if (m >= p.M || n >= p.Cout_g) continue;
+            const float4 cv = *reinterpret_cast<const float4*>(Cs + row * BN + c4 * 4);
+            float v[4] = {cv.x, cv.y, cv.z, cv.w};
+            const int co = g * p.Cout_g + n;
+            const int nvalid = min(4, p.Cout_g - n);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u < nvalid) {
+                    const float cs = p.cscale ? p.cscale[co + u] : 1.f;
+                    const float cb = p.cbias ? p.cbias[co + u] : 0.f;
+                    float x = fgt_act(v[u] * cs + cb, d.act, d.slope) * d.out_scale;
+                    if (d.epi == FGT_EPI_MUL) {
+                        x *= p.aux1[(long)m * d.ld_aux1 + co + u];
+                    } else if (d.epi == FGT_EPI_ADD) {
+                        x = fgt_act(x + p.aux1[(long)m * d.ld_aux1 + co + u], d.act2, d.slope);
+                    } else if (d.epi == FGT_EPI_GRU) {
+                        const float z = p.aux1[(long)m * d.ld_aux1 + co + u];
+                        const float hh = p.aux2[(long)m * d.ld_aux2 + co + u];
+                        x = (1.f - z) * hh + z * x;
+                    }
+                    v[u] = x;
+                }
+            }
+            if (vec_ok) {
+                *reinterpret_cast<float4*>(p.out + (long)m * d.ldo + d.ooff + co) = make_float4(v[0], v[1], v[2], v[3]);
+            } else if (d.out_nchw) {
+                const int n_img = m / p.HoWo, rem = m - n_img * p.HoWo;
+                for (int u = 0; u < nvalid; ++u) p.out[((long)n_img * d.Cout + co + u) * p.HoWo + rem] = v[u];
+            } else {
+                for (int u = 0; u < nvalid; ++u) p.out[(long)m * d.ldo + d.ooff + co + u] = v[u];
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch(const ConvP& p, hipStream_t s) {
+    constexpr int NT = WM * WN * 64;
+    constexpr size_t smem = 2ul * (BM + BN) * LDS_LD * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            fgt_set_error("hipFuncSetAttribute(conv_igemm %dx%d): %s", BM, BN, hipGetErrorString(e));
+            return FGT_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    dim3 grid(cdiv(p.M, BM), cdiv(p.Cout_g, BN), p.d.groups);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(NT), smem, s, p);
+    return fgt_check_launch("conv_igemm");
+}
+
+// ---- optional per-launch timing (bench roofline block) -------------------------------------------
+struct ProfRec { hipEvent_t a, b; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_event_pool;
+
+hipEvent_t get_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+
+}  // namespace
+
+extern "C" void fgt_prof_enable(int on) { g_prof_on = on != 0; }
+
+extern "C" int fgt_prof_collect(double* total_ms, double* total_flops, long* launches) {
+    double ms = 0, fl = 0;
+    for (auto& r : g_prof) {
+        hipEventSynchronize(r.b);
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) { fgt_set_error("hipEventElapsedTime failed"); return FGT_ELAUNCH; }
+        ms += t; fl += r.flops;
+        g_event_pool.push_back(r.a); g_event_pool.push_back(r.b);
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    if (launches) *launches = (long)g_prof.size();
+    g_prof.clear();
+    return FGT_OK;
+}
+
+extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const float* x0, const float* x1, const float* w_packed,
+                          const float* cscale, const float* cbias, const float* aux1, const float* aux2,
+                          float* out, void* stream) {
+    FGT_REQUIRE(dd && x0 && w_packed && out, "fgt_conv2d: null pointer");
+    ConvP p;
+    p.d = *dd;
+    const fgt_conv_desc& d = p.d;
+    FGT_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.Cout > 0 && d.groups > 0, "fgt_conv2d: bad sizes");
+    FGT_REQUIRE(d.C0 > 0 && d.C0 % d.groups == 0 && d.C1 % d.groups == 0 && d.Cout % d.groups == 0,
+                "fgt_conv2d: channels (%d,%d,%d) not divisible by groups %d", d.C0, d.C1, d.Cout, d.groups);
+    p.Cg0 = d.C0 / d.groups; p.Cg1 = d.C1 / d.groups; p.Cg = p.Cg0 + p.Cg1; p.Cout_g = d.Cout / d.groups;
+    FGT_REQUIRE(p.Cg0 % 4 == 0 && p.Cg1 % 4 == 0, "fgt_conv2d: per-group channels (%d,%d) must be multiples of 4 (pad the tensor)", p.Cg0, p.Cg1);
+    FGT_REQUIRE(d.ld0 % 4 == 0 && d.off0 % 4 == 0 && (d.C1 == 0 || (x1 && d.ld1 % 4 == 0 && d.off1 % 4 == 0)),
+                "fgt_conv2d: source strides/offsets must be multiples of 4 floats");
+    FGT_REQUIRE(((uintptr_t)x0 & 15) == 0 && ((uintptr_t)x1 & 15) == 0 && ((uintptr_t)w_packed & 15) == 0,
+                "fgt_conv2d: pointers must be 16-byte aligned");
+    FGT_REQUIRE(d.kh > 0 && d.kw > 0 && d.sh > 0 && d.sw > 0 && d.dh > 0 && d.dw > 0 && d.ph >= 0 && d.pw >= 0, "fgt_conv2d: bad kernel geometry");
+    p.Hin = d.H * (d.upsample ? 2 : 1); p.Win = d.W * (d.upsample ? 2 : 1);
+    const int Ho = (p.Hin + 2 * d.ph - d.dh * (d.kh - 1) - 1) / d.sh + 1;
+    const int Wo = (p.Win + 2 * d.pw - d.dw * (d.kw - 1) - 1) / d.sw + 1;
+    FGT_REQUIRE(Ho == d.Ho && Wo == d.Wo, "fgt_conv2d: output size (%d,%d) != expected (%d,%d)", d.Ho, d.Wo, Ho, Wo);
+    p.K = d.kh * d.kw * p.Cg;
+    FGT_REQUIRE(d.Kpad % BK == 0 && d.Kpad >= p.K, "fgt_conv2d: Kpad %d invalid for K %d", d.Kpad, p.K);
+    FGT_REQUIRE(d.Npad % 128 == 0 && d.Npad >= p.Cout_g, "fgt_conv2d: Npad %d invalid for Cout/groups %d", d.Npad, p.Cout_g);
+    if (d.epi != FGT_EPI_NONE) FGT_REQUIRE(aux1 != nullptr, "fgt_conv2d: epilogue needs aux1");
+    if (d.epi == FGT_EPI_GRU) FGT_REQUIRE(aux2 != nullptr, "fgt_conv2d: GRU epilogue needs aux2");
+    const long M = (long)d.N * Ho * Wo;
+    FGT_REQUIRE(M < (1l << 31), "fgt_conv2d: M too large");
+    p.M = (int)M; p.HoWo = Ho * Wo; p.nk = d.Kpad / BK;
+    p.x0 = x0; p.x1 = x1 ? x1 : x0; p.w = w_packed; p.cscale = cscale; p.cbias = cbias; p.aux1 = aux1; p.aux2 = aux2; p.out = out;
+
+    int tile = d.tile;
+    if (tile == 0) {
+        if (p.Cout_g <= 32) tile = FGT_TILE_128x32;
+        else if (p.Cout_g <= 64) tile = FGT_TILE_128x64;
+        else {
+            const long blocks128 = (long)cdiv(M, 128) * cdiv(p.Cout_g, 128) * d.groups;
+            if (blocks128 >= 384) tile = FGT_TILE_128x128;
+            else if (blocks128 * 2 >= 256) tile = FGT_TILE_128x64;
+            else tile = FGT_TILE_64x64;
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfRec rec{};
+    if (g_prof_on) {
+        rec.a = get_event(); rec.b = get_event();
+        rec.flops = 2.0 * (double)M * p.Cout_g * p.K * d.groups;
+        hipEventRecord(rec.a, s);
+    }
+    int rc;
+    switch (tile) {
+        case FGT_TILE_128x128: rc = launch<128, 128, 2, 2>(p, s); break;
+        case FGT_TILE_128x64: rc = launch<128, 64, 2, 2>(p, s); break;
+        case FGT_TILE_64x64: rc = launch<64, 64, 2, 2>(p, s); break;
+        case FGT_TILE_128x32: rc = launch<128, 32, 4, 1>(p, s); break;
+        case FGT_TILE_256x128: rc = launch<256, 128, 4, 2>(p, s); break;
+        default: fgt_set_error("fgt_conv2d: unknown tile %d", tile); return FGT_EINVAL;
+    }
+    if (g_prof_on) {
+        hipEventRecord(rec.b, s);
+        g_prof.push_back(rec);
+    }
+    return rc;
+}

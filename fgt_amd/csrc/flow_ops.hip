@@ -1,0 +1,278 @@
+// Flow-side bandwidth kernels: bilinear warps (image_warp / bilinear_sampler), forward-backward
+// consistency, RAFT correlation pyramid pooling + lookup, convex upsampling and instance norm.
+// All gather/HBM-bound; channels-last so that a warp's 4 corner reads are contiguous channel runs.
+#include "common.h"
+
+namespace {
+
+inline int grid_for(long total, int block = 256) {
+    long g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+// Source pixel coordinate of output pixel (x, y), following the reference's arithmetic in fp32.
+//  align_corners = 0 / relative flow : LAFC/models/utils/fbConsistencyCheck.py:15-25 then grid_sample's
+//      unnormalise ((g + 1) * size - 1) / 2                      (linspace base grid is float64 -> float32)
+//  align_corners = 1 / absolute coords: RAFT/utils/utils.py:60-65 then ((g + 1) / 2) * (size - 1)
+__device__ __forceinline__ void sample_coord(float fx, float fy, int x, int y, int W, int H, int align_corners, int absolute,
+                                             float& ix, float& iy) {
+    if (!absolute) {
+        const float bx = (float)(-1.0 + (double)x * (2.0 / (double)(W - 1)));
+        const float by = (float)(-1.0 + (double)y * (2.0 / (double)(H - 1)));
+        const float gx = bx + fx / (float)((W - 1.0) / 2.0);
+        const float gy = by + fy / (float)((H - 1.0) / 2.0);
+        if (align_corners) { ix = ((gx + 1.f) / 2.f) * (float)(W - 1); iy = ((gy + 1.f) / 2.f) * (float)(H - 1); }
+        else { ix = ((gx + 1.f) * (float)W - 1.f) / 2.f; iy = ((gy + 1.f) * (float)H - 1.f) / 2.f; }
+    } else {
+        const float gx = 2.f * fx / (float)(W - 1) - 1.f;
+        const float gy = 2.f * fy / (float)(H - 1) - 1.f;
+        if (align_corners) { ix = ((gx + 1.f) / 2.f) * (float)(W - 1); iy = ((gy + 1.f) / 2.f) * (float)(H - 1); }
+        else { ix = ((gx + 1.f) * (float)W - 1.f) / 2.f; iy = ((gy + 1.f) * (float)H - 1.f) / 2.f; }
+    }
+}
+
+struct Bilin { int x0, y0; float wnw, wne, wsw, wse; };
+__device__ __forceinline__ Bilin bilin(float ix, float iy) {
+    Bilin b;
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    b.x0 = (int)fx0; b.y0 = (int)fy0;
+    const float x1 = fx0 + 1.f, y1 = fy0 + 1.f;
+    b.wnw = (x1 - ix) * (y1 - iy);
+    b.wne = (ix - fx0) * (y1 - iy);
+    b.wsw = (x1 - ix) * (iy - fy0);
+    b.wse = (ix - fx0) * (iy - fy0);
+    return b;
+}
+
+__global__ void __launch_bounds__(256) warp_kernel(const float* img, int ldi, const float* flow, int B, int H, int W, int C,
+                                                   int align_corners, int absolute, float* out, int ldo) {
+    const long total = (long)B * H * W;
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(pix % W); const long r = pix / W;
+        const int y = (int)(r % H); const long b = r / H;
+        float ix, iy;
+        sample_coord(flow[pix * 2], flow[pix * 2 + 1], x, y, W, H, align_corners, absolute, ix, iy);
+        const Bilin bl = bilin(ix, iy);
+        const bool vx0 = bl.x0 >= 0 && bl.x0 < W, vx1 = bl.x0 + 1 >= 0 && bl.x0 + 1 < W;
+        const bool vy0 = bl.y0 >= 0 && bl.y0 < H, vy1 = bl.y0 + 1 >= 0 && bl.y0 + 1 < H;
+        const float* base = img + b * H * W * ldi;
+        for (int c = 0; c < C; ++c) {
+            float v = 0.f;
+            if (vx0 && vy0) v += base[((long)bl.y0 * W + bl.x0) * ldi + c] * bl.wnw;
+            if (vx1 && vy0) v += base[((long)bl.y0 * W + bl.x0 + 1) * ldi + c] * bl.wne;
+            if (vx0 && vy1) v += base[((long)(bl.y0 + 1) * W + bl.x0) * ldi + c] * bl.wsw;
+            if (vx1 && vy1) v += base[((long)(bl.y0 + 1) * W + bl.x0 + 1) * ldi + c] * bl.wse;
+            out[pix * ldo + c] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ void warp2(const float* src, const float* flw, long b, int x, int y, int H, int W, float& ox, float& oy) {
+    const long pix = (b * H + y) * W + x;
+    float ix, iy;
+    sample_coord(flw[pix * 2], flw[pix * 2 + 1], x, y, W, H, 0, 0, ix, iy);
+    const Bilin bl = bilin(ix, iy);
+    ox = oy = 0.f;
+    const float* base = src + b * H * W * 2;
+    const int xs[4] = {bl.x0, bl.x0 + 1, bl.x0, bl.x0 + 1}, ys[4] = {bl.y0, bl.y0, bl.y0 + 1, bl.y0 + 1};
+    const float ws[4] = {bl.wnw, bl.wne, bl.wsw, bl.wse};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (xs[k] >= 0 && xs[k] < W && ys[k] >= 0 && ys[k] < H) {
+            ox += base[((long)ys[k] * W + xs[k]) * 2] * ws[k];
+            oy += base[((long)ys[k] * W + xs[k]) * 2 + 1] * ws[k];
+        }
+}
+
+// fbConsistencyCheck.py:33-47
+__global__ void __launch_bounds__(256) fb_kernel(const float* ffw, const float* fbw, int B, int H, int W, float a1, float a2,
+                                                 float* occ_fw, float* occ_bw) {
+    const long total = (long)B * H * W;
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(pix % W); const long r = pix / W;
+        const int y = (int)(r % H); const long b = r / H;
+        float bwx, bwy, fwx, fwy;
+        warp2(fbw, ffw, b, x, y, H, W, bwx, bwy);  // flow_bw warped by flow_fw
+        warp2(ffw, fbw, b, x, y, H, W, fwx, fwy);  // flow_fw warped by flow_bw
+        const float fx = ffw[pix * 2], fy = ffw[pix * 2 + 1], gx = fbw[pix * 2], gy = fbw[pix * 2 + 1];
+        const float dfx = fx + bwx, dfy = fy + bwy, dbx = gx + fwx, dby = gy + fwy;
+        const float mag_fw = (fx * fx + fy * fy) + (bwx * bwx + bwy * bwy);
+        const float mag_bw = (gx * gx + gy * gy) + (fwx * fwx + fwy * fwy);
+        occ_fw[pix] = (dfx * dfx + dfy * dfy) > (a1 * mag_fw + a2) ? 1.f : 0.f;
+        occ_bw[pix] = (dbx * dbx + dby * dby) > (a1 * mag_bw + a2) ? 1.f : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) avgpool2_kernel(const float* src, long rows, int H, int W, float* dst) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = rows * Ho * Wo;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % Wo); const long r = idx / Wo;
+        const int y = (int)(r % Ho); const long row = r / Ho;
+        const float* s = src + row * H * W + (long)(2 * y) * W + 2 * x;
+        dst[idx] = (((s[0] + s[1]) + s[W]) + s[W + 1]) * 0.25f;
+    }
+}
+
+struct PyrPtrs { const float* p[4]; };
+
+// RAFT/corr.py:29-50.  Output channel = lvl*(2r+1)^2 + a*(2r+1) + b samples level lvl at
+// (x/2^lvl + (a - r), y/2^lvl + (b - r))  -- the reference adds meshgrid(dy, dx) to (x, y).
+__global__ void __launch_bounds__(256) corr_lookup_kernel(PyrPtrs pyr, int levels, int B, int H1, int W1, int radius,
+                                                          const float* coords, float* out, int ldo) {
+    const int win = 2 * radius + 1, per_lvl = win * win, nch = levels * per_lvl;
+    const long total = (long)B * H1 * W1 * nch;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % nch); const long q = idx / nch;
+        const int lvl = ch / per_lvl, t = ch - lvl * per_lvl;
+        const int a = t / win, b = t - a * win;
+        const int Hl = H1 >> lvl, Wl = W1 >> lvl;
+        const float scale = (float)(1 << lvl);
+        const float cx = coords[q * 2] / scale + (float)(a - radius);
+        const float cy = coords[q * 2 + 1] / scale + (float)(b - radius);
+        float ix, iy;
+        sample_coord(cx, cy, 0, 0, Wl, Hl, 1, 1, ix, iy);
+        const Bilin bl = bilin(ix, iy);
+        const float* vol = pyr.p[lvl] + q * Hl * Wl;
+        float v = 0.f;
+        const bool vx0 = bl.x0 >= 0 && bl.x0 < Wl, vx1 = bl.x0 + 1 >= 0 && bl.x0 + 1 < Wl;
+        const bool vy0 = bl.y0 >= 0 && bl.y0 < Hl, vy1 = bl.y0 + 1 >= 0 && bl.y0 + 1 < Hl;
+        if (vx0 && vy0) v += vol[(long)bl.y0 * Wl + bl.x0] * bl.wnw;
+        if (vx1 && vy0) v += vol[(long)bl.y0 * Wl + bl.x0 + 1] * bl.wne;
+        if (vx0 && vy1) v += vol[(long)(bl.y0 + 1) * Wl + bl.x0] * bl.wsw;
+        if (vx1 && vy1) v += vol[(long)(bl.y0 + 1) * Wl + bl.x0 + 1] * bl.wse;
+        out[q * ldo + ch] = v;
+    }
+}
+
+// RAFT/raft.py:73-84
+__global__ void __launch_bounds__(256) convex_up_kernel(const float* flow, int ldf, const float* mask, int ldm, int B, int H,
+                                                        int W, float* out) {
+    const long total = (long)B * H * W * 64;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ij = (int)(idx & 63); const long pix = idx >> 6;
+        const int i = ij >> 3, j = ij & 7;
+        const int x = (int)(pix % W); const long r = pix / W;
+        const int y = (int)(r % H); const long b = r / H;
+        float mk[9], mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { mk[k] = mask[pix * ldm + k * 64 + ij]; mx = fmaxf(mx, mk[k]); }
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { mk[k] = expf(mk[k] - mx); den += mk[k]; }
+        float ux = 0.f, uy = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const float* f = flow + ((b * H + yy) * W + xx) * ldf;
+                const float wgt = mk[k] / den;
+                ux += wgt * (8.f * f[0]);
+                uy += wgt * (8.f * f[1]);
+            }
+        }
+        const long HW8 = (long)(8 * H) * (8 * W);
+        const long o = (long)(8 * y + i) * (8 * W) + 8 * x + j;
+        out[(b * 2 + 0) * HW8 + o] = ux;
+        out[(b * 2 + 1) * HW8 + o] = uy;
+    }
+}
+
+// ---- instance norm: double atomics into stats[N][C][2] = (sum, sumsq)
+__global__ void __launch_bounds__(256) in_stats_kernel(const float* x, int ld, int HW, int C, int chunk, double* stats) {
+    // grid: (pixel chunks, N).  Consecutive threads own consecutive channels (coalesced); when C < 256 the
+    // remaining threads split the chunk's pixels ("sub" lanes).
+    const int n = blockIdx.y;
+    const long p0 = (long)blockIdx.x * chunk, p1 = min((long)HW, p0 + chunk);
+    const int cpb = min(C, 256), lpc = 256 / cpb;
+    const int t = threadIdx.x;
+    if (t >= cpb * lpc) return;
+    const int c0 = t % cpb, sub = t / cpb;
+    for (int c = c0; c < C; c += cpb) {
+        double s = 0.0, ss = 0.0;
+        for (long p = p0 + sub; p < p1; p += lpc) {
+            const float v = x[((long)n * HW + p) * ld + c];
+            s += v; ss += (double)v * v;
+        }
+        atomicAdd(&stats[((long)n * C + c) * 2], s);
+        atomicAdd(&stats[((long)n * C + c) * 2 + 1], ss);
+    }
+}
+
+__global__ void __launch_bounds__(256) in_apply_kernel(const float* x, int ld, int N, int HW, int C, const double* stats, float eps,
+                                                       int act, const float* res, int ldres, int act2, float* out, int ldo) {
+    const long total = (long)N * HW * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C); const long pix = idx / C;
+        const long n = pix / HW;
+        const double mean = stats[(n * C + c) * 2] / HW;
+        const double var = stats[(n * C + c) * 2 + 1] / HW - mean * mean;
+        const float rstd = (float)(1.0 / sqrt((var > 0 ? var : 0.0) + (double)eps));
+        float v = (x[pix * ld + c] - (float)mean) * rstd;
+        v = fgt_act(v, act, 0.2f);
+        if (res) { v += res[pix * ldres + c]; v = fgt_act(v, act2, 0.2f); }
+        out[pix * ldo + c] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int fgt_warp(const float* img, int ldi, const float* flow, int B, int H, int W, int C, int align_corners,
+                        int absolute_coords, float* out, int ldo, void* stream) {
+    FGT_REQUIRE(img && flow && out && B > 0 && H > 1 && W > 1 && C > 0, "fgt_warp: bad arguments");
+    hipLaunchKernelGGL(warp_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, img, ldi, flow, B, H, W, C,
+                       align_corners, absolute_coords, out, ldo);
+    return fgt_check_launch("warp");
+}
+
+extern "C" int fgt_fb_consistency(const float* flow_fw, const float* flow_bw, int B, int H, int W, float alpha1, float alpha2,
+                                  float* occ_fw, float* occ_bw, void* stream) {
+    FGT_REQUIRE(flow_fw && flow_bw && occ_fw && occ_bw && H > 1 && W > 1, "fgt_fb_consistency: bad arguments");
+    hipLaunchKernelGGL(fb_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, flow_fw, flow_bw, B, H, W,
+                       alpha1, alpha2, occ_fw, occ_bw);
+    return fgt_check_launch("fb_consistency");
+}
+
+extern "C" int fgt_avgpool2(const float* src, long rows, int H, int W, float* dst, void* stream) {
+    FGT_REQUIRE(src && dst && rows > 0 && H >= 2 && W >= 2, "fgt_avgpool2: bad arguments");
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(grid_for(rows * (H / 2) * (W / 2))), dim3(256), 0, (hipStream_t)stream, src, rows, H, W, dst);
+    return fgt_check_launch("avgpool2");
+}
+
+extern "C" int fgt_corr_lookup(const float* const* pyr, int levels, int B, int H1, int W1, int radius, const float* coords,
+                               float* out, int ldo, void* stream) {
+    FGT_REQUIRE(pyr && coords && out && levels >= 1 && levels <= 4, "fgt_corr_lookup: bad arguments");
+    PyrPtrs pp{};
+    for (int l = 0; l < levels; ++l) { FGT_REQUIRE(pyr[l], "fgt_corr_lookup: null level"); pp.p[l] = pyr[l]; }
+    FGT_REQUIRE((H1 >> (levels - 1)) >= 2 && (W1 >> (levels - 1)) >= 2, "fgt_corr_lookup: coarsest level smaller than 2x2");
+    const long total = (long)B * H1 * W1 * levels * (2 * radius + 1) * (2 * radius + 1);
+    hipLaunchKernelGGL(corr_lookup_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, pp, levels, B, H1, W1, radius,
+                       coords, out, ldo);
+    return fgt_check_launch("corr_lookup");
+}
+
+extern "C" int fgt_convex_upsample(const float* flow, int ldf, const float* mask, int ldm, int B, int H, int W, float* out,
+                                   void* stream) {
+    FGT_REQUIRE(flow && mask && out, "fgt_convex_upsample: bad arguments");
+    hipLaunchKernelGGL(convex_up_kernel, dim3(grid_for((long)B * H * W * 64)), dim3(256), 0, (hipStream_t)stream, flow, ldf, mask,
+                       ldm, B, H, W, out);
+    return fgt_check_launch("convex_upsample");
+}
+
+extern "C" int fgt_instnorm_stats(const float* x, int ld, int N, int HW, int C, double* stats, void* stream) {
+    FGT_REQUIRE(x && stats && N > 0 && HW > 0 && C > 0 && C <= 1024, "fgt_instnorm_stats: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * N * C, s) != hipSuccess) { fgt_set_error("fgt_instnorm_stats: memset failed"); return FGT_ELAUNCH; }
+    const int chunk = 512;
+    dim3 grid(cdiv(HW, chunk), N);
+    hipLaunchKernelGGL(in_stats_kernel, grid, dim3(256), 0, s, x, ld, HW, C, chunk, stats);
+    return fgt_check_launch("instnorm_stats");
+}
+
+extern "C" int fgt_instnorm_apply(const float* x, int ld, int N, int HW, int C, const double* stats, float eps, int act,
+                                  const float* res, int ldres, int act2, float* out, int ldo, void* stream) {
+    FGT_REQUIRE(x && stats && out, "fgt_instnorm_apply: bad arguments");
+    hipLaunchKernelGGL(in_apply_kernel, dim3(grid_for((long)N * HW * C)), dim3(256), 0, (hipStream_t)stream, x, ld, N, HW, C, stats,
+                       eps, act, res, ldres, act2, out, ldo);
+    return fgt_check_launch("instnorm_apply");
+}

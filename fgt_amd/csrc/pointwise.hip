@@ -1,0 +1,315 @@
+// Bandwidth-bound kernels of the FGT path: LayerNorm, depthwise convs, fold (overlap-add gather),
+// layout packing, zero padding, axpby and the tool's compose/blend step.  All are HBM-bound:
+// float4 accesses along the channel dimension of channels-last tensors, one pass over the data.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------ LayerNorm: one wavefront per row
+constexpr int LN_MAXV = 4;  // float4 per lane -> C <= 1024
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1,
+                                                        long rows, float eps, const float* gA, const float* bA, float* outA,
+                                                        int ldA, const float* gB, const float* bB, float* outB, int ldB) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int C = C0 + C1, nv = C >> 2;
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < C) {
+            v[i] = c < C0 ? *reinterpret_cast<const float4*>(x0 + row * ld0 + c)
+                          : *reinterpret_cast<const float4*>(x1 + row * ld1 + (c - C0));
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        if ((lane + 64 * i) < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+            ss += (a * a + b * b) + (c * c + e * e);
+        }
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < C) {
+            const float4 n = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd,
+                                         (v[i].w - mean) * rstd);
+            const float4 g = *reinterpret_cast<const float4*>(gA + c), b = *reinterpret_cast<const float4*>(bA + c);
+            *reinterpret_cast<float4*>(outA + row * ldA + c) =
+                make_float4(n.x * g.x + b.x, n.y * g.y + b.y, n.z * g.z + b.z, n.w * g.w + b.w);
+            if (outB) {
+                const float4 g2 = *reinterpret_cast<const float4*>(gB + c), b2 = *reinterpret_cast<const float4*>(bB + c);
+                *reinterpret_cast<float4*>(outB + row * ldB + c) =
+                    make_float4(n.x * g2.x + b2.x, n.y * g2.y + b2.y, n.z * g2.z + b2.z, n.w * g2.w + b2.w);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ depthwise k x k stride k ("global tokens")
+__global__ void __launch_bounds__(256) dw_pool_kernel(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1,
+                                                      int bt, int nh, int nw, int k, const float* w, const float* bias,
+                                                      float* out, int ldo) {
+    const int C = C0 + C1, c4n = C >> 2;
+    const int gh = nh / k, gw = nw / k;
+    const long total = (long)bt * gh * gw * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        long tok = idx / c4n;
+        const int gx = (int)(tok % gw); long r = tok / gw;
+        const int gy = (int)(r % gh); const int f = (int)(r / gh);
+        float acc[4] = {bias[c], bias[c + 1], bias[c + 2], bias[c + 3]};
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b < k; ++b) {
+                const long pix = ((long)f * nh + gy * k + a) * nw + gx * k + b;
+                const float4 v = c < C0 ? *reinterpret_cast<const float4*>(x0 + pix * ld0 + c)
+                                        : *reinterpret_cast<const float4*>(x1 + pix * ld1 + (c - C0));
+                const int wi = a * k + b, kk = k * k;
+                acc[0] += v.x * w[(c + 0) * kk + wi];
+                acc[1] += v.y * w[(c + 1) * kk + wi];
+                acc[2] += v.z * w[(c + 2) * kk + wi];
+                acc[3] += v.w * w[(c + 3) * kk + wi];
+            }
+        *reinterpret_cast<float4*>(out + tok * ldo + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+// ------------------------------------------------------------------ depthwise 3x3 + identity (AddPosEmb)
+__global__ void __launch_bounds__(256) dw3x3_res_kernel(const float* x, int bt, int h, int w, int C, const float* wgt,
+                                                        const float* bias, float* out) {
+    const int c4n = C >> 2;
+    const long total = (long)bt * h * w * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        long pix = idx / c4n;
+        const int px = (int)(pix % w); long r = pix / w;
+        const int py = (int)(r % h); const int f = (int)(r / h);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < 3; ++a) {
+            const int yy = py + a - 1;
+            if (yy < 0 || yy >= h) continue;
+            for (int b = 0; b < 3; ++b) {
+                const int xx = px + b - 1;
+                if (xx < 0 || xx >= w) continue;
+                const float4 v = *reinterpret_cast<const float4*>(x + (((long)f * h + yy) * w + xx) * C + c);
+                const int wi = a * 3 + b;
+                acc[0] += v.x * wgt[(c + 0) * 9 + wi];
+                acc[1] += v.y * wgt[(c + 1) * 9 + wi];
+                acc[2] += v.z * wgt[(c + 2) * 9 + wi];
+                acc[3] += v.w * wgt[(c + 3) * 9 + wi];
+            }
+        }
+        const float4 ctr = *reinterpret_cast<const float4*>(x + pix * C + c);
+        *reinterpret_cast<float4*>(out + pix * C + c) =
+            make_float4((acc[0] + bias[c]) + ctr.x, (acc[1] + bias[c + 1]) + ctr.y, (acc[2] + bias[c + 2]) + ctr.z,
+                        (acc[3] + bias[c + 3]) + ctr.w);
+    }
+}
+
+// ------------------------------------------------------------------ fold as a gather
+__global__ void __launch_bounds__(256) fold_kernel(const float* Y, int ldy, int frames, int th, int tw, int C, int k, int s,
+                                                   int p, int Hf, int Wf, int normalize, const float* res, int ldres,
+                                                   float* out, int ldo) {
+    const int c4n = C >> 2;
+    const long total = (long)frames * Hf * Wf * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        long pix = idx / c4n;
+        const int x = (int)(pix % Wf); long r = pix / Wf;
+        const int y = (int)(r % Hf); const int f = (int)(r / Hf);
+        // tokens (i, j) with i*s - p <= y <= i*s - p + k - 1
+        const int i_lo = max(0, (y + p - k + 1 + s - 1) / s), i_hi = min(th - 1, (y + p) / s);
+        const int j_lo = max(0, (x + p - k + 1 + s - 1) / s), j_hi = min(tw - 1, (x + p) / s);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int cnt = 0;
+        for (int i = i_lo; i <= i_hi; ++i) {
+            const int ky = y + p - i * s;
+            for (int j = j_lo; j <= j_hi; ++j) {
+                const int kx = x + p - j * s;
+                const float4 v = *reinterpret_cast<const float4*>(Y + ((long)f * th * tw + i * tw + j) * ldy + (ky * k + kx) * C + c);
+                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+                ++cnt;
+            }
+        }
+        if (normalize) {
+            const float fc = (float)cnt;
+            acc[0] /= fc; acc[1] /= fc; acc[2] /= fc; acc[3] /= fc;
+        }
+        if (res) {
+            const float4 rv = *reinterpret_cast<const float4*>(res + pix * ldres + c);
+            acc[0] = rv.x + acc[0]; acc[1] = rv.y + acc[1]; acc[2] = rv.z + acc[2]; acc[3] = rv.w + acc[3];
+        }
+        *reinterpret_cast<float4*>(out + pix * ldo + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+// ------------------------------------------------------------------ layout packing
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* src, int N, int C, int H, int W, float* dst, int ldd,
+                                                           int coff, int zero_to, float scale, float shift) {
+    const long HW = (long)H * W, total = (long)N * HW;
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long)gridDim.x * blockDim.x) {
+        const long n = pix / HW, rem = pix - n * HW;
+        float* d = dst + pix * ldd + coff;
+        for (int c = 0; c < C; ++c) d[c] = src[(n * C + c) * HW + rem] * scale + shift;
+        for (int c = C; c < zero_to; ++c) d[c] = 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* src, int lds, int coff, int N, int C, int H, int W,
+                                                           float* dst) {
+    const long HW = (long)H * W, total = (long)N * HW;
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long)gridDim.x * blockDim.x) {
+        const long n = pix / HW, rem = pix - n * HW;
+        const float* s = src + pix * lds + coff;
+        for (int c = 0; c < C; ++c) dst[(n * C + c) * HW + rem] = s[c];
+    }
+}
+
+__global__ void __launch_bounds__(256) pad_tokens_kernel(const float* src, int lds, int bt, int h, int w, int C, int nh,
+                                                         int nw, float* dst, int ldd) {
+    const int c4n = C >> 2;
+    const long total = (long)bt * nh * nw * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        long pix = idx / c4n;
+        const int x = (int)(pix % nw); long r = pix / nw;
+        const int y = (int)(r % nh); const int f = (int)(r / nh);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y < h && x < w) v = *reinterpret_cast<const float4*>(src + (((long)f * h + y) * w + x) * lds + c);
+        *reinterpret_cast<float4*>(dst + pix * ldd + c) = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) axpby_kernel(const float* a, int lda, float sa, const float* b, int ldb, float sb,
+                                                    long rows, int C, int act, float* out, int ldo) {
+    const long total = rows * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / C; const int c = (int)(idx - r * C);
+        float v = a[r * lda + c] * sa;
+        if (b) v += b[r * ldb + c] * sb;
+        out[r * ldo + c] = fgt_act(v, act, 0.2f);
+    }
+}
+
+// tool/video_inpainting.py:725-740
+__global__ void __launch_bounds__(256) compose_kernel(const float* out_nchw, const int* ids, const int* first, int n,
+                                                      const float* frames01, const float* masks, int H, int W, float* comp) {
+    const long HW = (long)H * W, total = (long)n * HW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(idx / HW); const long rem = idx - (long)i * HW;
+        const int fid = ids[i];
+        const float m = masks[(long)fid * HW + rem];
+        for (int c = 0; c < 3; ++c) {
+            const float o = out_nchw[((long)i * 3 + c) * HW + rem];
+            const float filled = ((o + 1.f) / 2.f) * 255.f;
+            const float fu = (float)(unsigned char)(int)filled;                         // astype(uint8): truncation
+            const float vu = (float)(unsigned char)(int)(frames01[((long)fid * 3 + c) * HW + rem] * 255.0f);
+            const float cv = fu * m + vu * (1.f - m);
+            float* dst = comp + ((long)fid * HW + rem) * 3 + c;
+            *dst = first[i] ? cv : (*dst * 0.5f + cv * 0.5f);
+        }
+    }
+}
+
+inline int grid_for(long total, int block = 256) {
+    long g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+}  // namespace
+
+extern "C" int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, long rows, float eps,
+                             const float* gA, const float* bA, float* outA, int ldA, const float* gB, const float* bB,
+                             float* outB, int ldB, void* stream) {
+    FGT_REQUIRE(x0 && gA && bA && outA && rows > 0, "fgt_layernorm: null pointer / empty");
+    FGT_REQUIRE(C0 > 0 && C0 % 4 == 0 && C1 % 4 == 0 && (C0 + C1) <= 256 * LN_MAXV, "fgt_layernorm: C=(%d,%d) unsupported", C0, C1);
+    FGT_REQUIRE(ld0 % 4 == 0 && (C1 == 0 || (x1 && ld1 % 4 == 0)) && ldA % 4 == 0 && (!outB || (gB && bB && ldB % 4 == 0)),
+                "fgt_layernorm: strides must be multiples of 4 floats");
+    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, rows,
+                       eps, gA, bA, outA, ldA, gB, bB, outB, ldB);
+    return fgt_check_launch("layernorm");
+}
+
+extern "C" int fgt_dw_pool(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, int bt, int nh, int nw, int k,
+                           const float* w, const float* bias, float* out, int ldo, void* stream) {
+    FGT_REQUIRE(x0 && w && bias && out, "fgt_dw_pool: null pointer");
+    FGT_REQUIRE(C0 % 4 == 0 && C1 % 4 == 0 && ld0 % 4 == 0 && (C1 == 0 || (x1 && ld1 % 4 == 0)) && ldo % 4 == 0, "fgt_dw_pool: alignment");
+    FGT_REQUIRE(k > 0 && nh % k == 0 && nw % k == 0, "fgt_dw_pool: grid %dx%d not divisible by %d", nh, nw, k);
+    const long total = (long)bt * (nh / k) * (nw / k) * ((C0 + C1) / 4);
+    hipLaunchKernelGGL(dw_pool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, bt, nh,
+                       nw, k, w, bias, out, ldo);
+    return fgt_check_launch("dw_pool");
+}
+
+extern "C" int fgt_dw3x3_residual(const float* x, int bt, int h, int w, int C, const float* wgt, const float* bias, float* out,
+                                  void* stream) {
+    FGT_REQUIRE(x && wgt && bias && out && C % 4 == 0, "fgt_dw3x3_residual: bad arguments");
+    const long total = (long)bt * h * w * (C / 4);
+    hipLaunchKernelGGL(dw3x3_res_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, bt, h, w, C, wgt, bias, out);
+    return fgt_check_launch("dw3x3_residual");
+}
+
+extern "C" int fgt_fold(const float* Y, int ldy, int frames, int th, int tw, int C, int k, int s, int p, int Hf, int Wf,
+                        int normalize, const float* res, int ldres, float* out, int ldo, void* stream) {
+    FGT_REQUIRE(Y && out && C % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && (!res || ldres % 4 == 0), "fgt_fold: bad arguments");
+    FGT_REQUIRE((Hf + 2 * p - k) / s + 1 == th && (Wf + 2 * p - k) / s + 1 == tw, "fgt_fold: token grid %dx%d does not match output %dx%d", th, tw, Hf, Wf);
+    const long total = (long)frames * Hf * Wf * (C / 4);
+    hipLaunchKernelGGL(fold_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, Y, ldy, frames, th, tw, C, k, s, p,
+                       Hf, Wf, normalize, res, ldres, out, ldo);
+    return fgt_check_launch("fold");
+}
+
+extern "C" int fgt_nchw_to_nhwc(const float* src, int N, int C, int H, int W, float* dst, int ldd, int coff, int zero_to,
+                                float scale, float shift, void* stream) {
+    FGT_REQUIRE(src && dst && C > 0, "fgt_nchw_to_nhwc: bad arguments");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, src, N, C, H, W,
+                       dst, ldd, coff, zero_to, scale, shift);
+    return fgt_check_launch("nchw_to_nhwc");
+}
+
+extern "C" int fgt_nhwc_to_nchw(const float* src, int lds, int coff, int N, int C, int H, int W, float* dst, void* stream) {
+    FGT_REQUIRE(src && dst && C > 0, "fgt_nhwc_to_nchw: bad arguments");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, src, lds, coff, N,
+                       C, H, W, dst);
+    return fgt_check_launch("nhwc_to_nchw");
+}
+
+extern "C" int fgt_pad_tokens(const float* src, int lds, int bt, int h, int w, int C, int nh, int nw, float* dst, int ldd,
+                              void* stream) {
+    FGT_REQUIRE(src && dst && C % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0, "fgt_pad_tokens: bad arguments");
+    const long total = (long)bt * nh * nw * (C / 4);
+    hipLaunchKernelGGL(pad_tokens_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, lds, bt, h, w, C, nh, nw,
+                       dst, ldd);
+    return fgt_check_launch("pad_tokens");
+}
+
+extern "C" int fgt_axpby(const float* a, int lda, float sa, const float* b, int ldb, float sb, long rows, int C, int act,
+                         float* out, int ldo, void* stream) {
+    FGT_REQUIRE(a && out && rows > 0 && C > 0, "fgt_axpby: bad arguments");
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, a, lda, sa, b, ldb, sb, rows, C,
+                       act, out, ldo);
+    return fgt_check_launch("axpby");
+}
+
+extern "C" int fgt_compose_blend(const float* out_nchw, const int* ids, const int* first, int n, const float* frames01,
+                                 const float* masks, int H, int W, float* comp, void* stream) {
+    FGT_REQUIRE(out_nchw && ids && first && frames01 && masks && comp && n > 0, "fgt_compose_blend: bad arguments");
+    hipLaunchKernelGGL(compose_kernel, dim3(grid_for((long)n * H * W)), dim3(256), 0, (hipStream_t)stream, out_nchw, ids, first, n,
+                       frames01, masks, H, W, comp);
+    return fgt_check_launch("compose_blend");
+}

@@ -1,0 +1,443 @@
+"""MI355X-native FGT generator behind the reference's nn.Module API.
+
+`Model(config).forward(masked_frames[b,t,3,H,W], flows[b,t,2,H,W], masks[b,t,1,H,W]) -> [b*t,3,H,W]`
+has the constructor keys, forward signature and state_dict keys of FGT/models/model.py:12-25 (the
+reference's `Model`), so `tool/video_inpainting.py:217-230,724` can import it unchanged.
+
+The nn.Module tree below only *holds parameters* under the reference's names; no torch operator runs on
+activations.  `forward` drives libfgt_hip.so (fgt_amd/ops.py): fp32-MFMA implicit-GEMM convolutions and
+projections, flash attention with the zone/window gathers folded into addressing, fused LN / fold kernels.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import PackedConv
+
+
+# ----------------------------------------------------------------------------- parameter holders
+class ConvParams(nn.Module):
+    """weight [Cout, Cin/groups, kh, kw] + bias [Cout] (same names/shapes as nn.Conv2d)."""
+
+    def __init__(self, cin, cout, k, groups=1, bias=True):
+        super().__init__()
+        kh, kw = (k, k) if isinstance(k, int) else k
+        self.groups = groups
+        self.weight = nn.Parameter(torch.empty(cout, cin // groups, kh, kw))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        nn.init.normal_(self.weight, 0.0, 0.02)
+
+
+class LinearParams(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        nn.init.normal_(self.weight, 0.0, 0.02)
+
+
+class LayerNormParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class Slot(nn.Module):
+    """Parameter-free placeholder keeping the reference's Sequential/ModuleList indices (activations, pads)."""
+
+
+class ConvBlockParams(nn.Module):
+    """VanillaConv / GatedConv parameter names (FGT/models/utils/network_blocks_2d.py:7-95)."""
+
+    def __init__(self, cin, cout, k, gated, bias=True):
+        super().__init__()
+        self.featureConv = ConvParams(cin, cout, k, bias=bias)
+        if gated:
+            self.gatingConv = ConvParams(cin, cout, k, bias=bias)
+
+
+class DeconvBlockParams(nn.Module):
+    def __init__(self, cin, cout, k, gated, bias=True):
+        super().__init__()
+        self.conv = ConvBlockParams(cin, cout, k, gated, bias)
+
+
+class EncoderParams(nn.Module):
+    """FGT/models/model.py:28-51."""
+    SPEC = [(None, 64, 2, 1), (64, 64, 1, 1), (64, 128, 2, 1), (128, 256, 1, 1), (256, 384, 1, 1),
+            (640, 512, 1, 2), (768, 384, 1, 4), (640, 256, 1, 8), (512, 128, 1, 1)]  # (cin, cout, stride, groups)
+
+    def __init__(self, in_channels):
+        super().__init__()
+        mods = []
+        for cin, cout, _, g in self.SPEC:
+            mods += [ConvParams(cin or in_channels, cout, 3, groups=g), Slot()]
+        self.layers = nn.ModuleList(mods)
+
+
+class TMHSAParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.query_embedding = LinearParams(c, c)
+        self.key_embedding = LinearParams(c, c)
+        self.value_embedding = LinearParams(c, c)
+        self.output_linear = LinearParams(c, c)
+
+
+class SWMHSAParams(nn.Module):
+    def __init__(self, c, cf, gd):
+        super().__init__()
+        self.query_embedding = LinearParams(c + cf, c)
+        self.key_embedding = LinearParams(c + cf, c)
+        self.value_embedding = LinearParams(c, c)
+        self.output_linear = LinearParams(c, c)
+        self.global_extract_v = ConvParams(c, c, gd, groups=c)
+        self.global_extract_k = ConvParams(c + cf, c + cf, gd, groups=c + cf)
+        self.q_norm = LayerNormParams(c + cf)
+        self.k_norm = LayerNormParams(c + cf)
+        self.v_norm = LayerNormParams(c)
+        self.reweightFlow = nn.ModuleList([LinearParams(c + cf, cf), Slot()])
+
+
+class FFNParams(nn.Module):
+    """FusionFeedForward names: conv1, conv2.2 (ffn_base.py:39-45)."""
+
+    def __init__(self, c, hidden):
+        super().__init__()
+        self.conv1 = LinearParams(c, hidden)
+        self.conv2 = nn.ModuleList([Slot(), Slot(), LinearParams(hidden, c), Slot()])
+
+
+class TemporalParams(nn.Module):
+    def __init__(self, c, hidden):
+        super().__init__()
+        self.attention = TMHSAParams(c)
+        self.ffn = FFNParams(c, hidden)
+        self.norm1 = LayerNormParams(c)
+        self.norm2 = LayerNormParams(c)
+
+
+class SpatialParams(nn.Module):
+    def __init__(self, c, cf, gd, hidden):
+        super().__init__()
+        self.attention = SWMHSAParams(c, cf, gd)
+        self.ffn = FFNParams(c, hidden)
+        self.norm = LayerNormParams(c)
+
+
+class BlockParams(nn.Module):
+    def __init__(self, c, cf, gd, hidden):
+        super().__init__()
+        self.t_transformer = TemporalParams(c, hidden)
+        self.s_transformer = SpatialParams(c, cf, gd, hidden)
+
+
+class PosEmbParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.proj = ConvParams(c, c, 3, groups=c)
+
+
+class Vec2PatchParams(nn.Module):
+    def __init__(self, c, cout):
+        super().__init__()
+        self.embedding = LinearParams(c, cout)
+
+
+class DecoderParams(nn.Module):
+    def __init__(self, c, gated, bias):
+        super().__init__()
+        self.layer1 = DeconvBlockParams(c, c, 3, gated, bias)
+        self.layer2 = ConvBlockParams(c, c // 2, 3, gated, bias)
+        self.layer3 = DeconvBlockParams(c // 2, c // 2, 3, gated, bias)
+        self.final = ConvBlockParams(c // 2, 3, 3, gated, bias)
+
+
+# ----------------------------------------------------------------------------- the network
+class FGT(nn.Module):
+    """Parameter tree of FGT/models/model.py:196-247 + the HIP forward of :249-283."""
+
+    def __init__(self, t_groupSize, s_windowSize, g_downSize, input_resolution, in_channels, cnum, flow_inChannel,
+                 flow_cnum, frame_hidden, flow_hidden, passmask, numBlocks, kernel_size, stride, padding, num_heads,
+                 conv_type, norm, use_bias, ape, mlp_ratio=4, drop=0, init_weights=True):
+        super().__init__()
+        if conv_type not in ("vanilla", "gated"):
+            raise NotImplementedError(f"conv_type={conv_type!r}: only 'vanilla' and 'gated' FGT variants are built "
+                                      "(the reference's 'partial' blocks take (x, mask) tuples and cannot run in FGT.forward)")
+        if norm not in (None, "None", "none"):
+            raise NotImplementedError(f"norm={norm!r}: shipped FGT configs use norm='None' (FGT/config/train.yaml:76)")
+        if drop != 0:
+            raise NotImplementedError("dropout > 0 is training-only; inference path built with drop=0 (FGT/config/train.yaml:81)")
+        if frame_hidden // num_heads != 128:
+            raise NotImplementedError("attention kernels are built for head dim 128 (frame_hidden 512, 4 heads)")
+        gated = conv_type == "gated"
+        bias = bool(use_bias)
+        self.cfg = dict(group=t_groupSize, ws=s_windowSize, gd=g_downSize, in_channels=in_channels, passmask=passmask,
+                        heads=num_heads, k=tuple(kernel_size), s=tuple(stride), p=tuple(padding), ape=ape, gated=gated,
+                        c=frame_hidden, cf=flow_hidden, cnum=cnum, mlp=mlp_ratio, flow_in=flow_inChannel)
+        assert self.cfg["k"][0] == self.cfg["k"][1] and self.cfg["s"][0] == self.cfg["s"][1] and self.cfg["p"][0] == self.cfg["p"][1]
+        self.in_channels = in_channels
+        self.passmask = passmask
+        self.ape = ape
+        self.frame_endoder = EncoderParams(in_channels)  # (sic) reference key name, FGT/models/model.py:205
+        self.flow_encoder = nn.ModuleList([
+            Slot(),
+            ConvBlockParams(flow_inChannel, flow_cnum, 5, gated, bias),
+            ConvBlockParams(flow_cnum, flow_cnum * 2, 3, gated, bias),
+            ConvBlockParams(flow_cnum * 2, flow_cnum * 2, 3, gated, bias),
+            ConvBlockParams(flow_cnum * 2, flow_cnum * 2, 3, gated, bias)])
+        self.patch2vec = ConvParams(cnum * 2, frame_hidden, kernel_size)
+        self.f_patch2vec = ConvParams(flow_cnum * 2, flow_hidden, kernel_size)
+        out_shape = (input_resolution[0] // 4, input_resolution[1] // 4)
+        self.token_size = [int((out_shape[i] + 2 * padding[i] - kernel_size[i]) / stride[i] + 1) for i in range(2)]
+        hidden = kernel_size[0] * kernel_size[1] * mlp_ratio
+        if ape:
+            self.add_pos_emb = PosEmbParams(frame_hidden)
+        self.first_t_transformer = TemporalParams(frame_hidden, hidden)
+        self.first_s_transformer = SpatialParams(frame_hidden, flow_hidden, g_downSize, hidden)
+        self.transformer = nn.ModuleList([BlockParams(frame_hidden, flow_hidden, g_downSize, hidden)
+                                          for _ in range(numBlocks // 2 - 1)])
+        self.vec2patch = Vec2PatchParams(frame_hidden, kernel_size[0] * kernel_size[1] * cnum * 2)
+        self.decoder = DecoderParams(cnum * 2, gated, bias)
+        self._packed = None
+        self._packed_key = None
+
+    # ---- weight cache --------------------------------------------------------------------------
+    def _cache_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def packed(self):
+        key = self._cache_key()
+        if self._packed is None or key != self._packed_key:
+            self._packed = self._pack()
+            self._packed_key = key
+        return self._packed
+
+    def _pack_block(self, blk):
+        """ConvBlockParams -> (feature PackedConv, gating PackedConv | None)"""
+        f = PackedConv(blk.featureConv.weight, blk.featureConv.bias)
+        g = PackedConv(blk.gatingConv.weight, blk.gatingConv.bias) if self.cfg["gated"] else None
+        return f, g
+
+    def _pack_ffn(self, ffn):
+        k2 = self.cfg["k"][0] * self.cfg["k"][1]
+        w1, b1 = ffn.conv1.weight, ffn.conv1.bias
+        cc = w1.shape[0] // k2
+        # tap-major output columns: row (c*k2 + tap) -> (tap*cc + c)   (ffn_base.py:39 + Fold channel order)
+        w1p = w1.detach().view(cc, k2, -1).permute(1, 0, 2).reshape(cc * k2, -1)
+        b1p = b1.detach().view(cc, k2).permute(1, 0).reshape(-1)
+        w2 = ffn.conv2[2].weight.detach()
+        # Linear(hidden -> c) on unfold(...) == k x k / stride s conv over the folded map (ffn_base.py:40-45,56-75)
+        w2c = w2.view(w2.shape[0], cc, self.cfg["k"][0], self.cfg["k"][1])
+        return dict(conv1=PackedConv(w1p, b1p), conv2=PackedConv(w2c, ffn.conv2[2].bias), cc=cc)
+
+    def _pack_temporal(self, m):
+        a = m.attention
+        wqkv = torch.cat([a.query_embedding.weight, a.key_embedding.weight, a.value_embedding.weight], 0)
+        bqkv = torch.cat([a.query_embedding.bias, a.key_embedding.bias, a.value_embedding.bias], 0)
+        return dict(qkv=PackedConv(wqkv, bqkv), out=PackedConv(a.output_linear.weight, a.output_linear.bias),
+                    ffn=self._pack_ffn(m.ffn), n1=(m.norm1.weight.detach(), m.norm1.bias.detach()),
+                    n2=(m.norm2.weight.detach(), m.norm2.bias.detach()))
+
+    def _pack_spatial(self, m):
+        a = m.attention
+        f32 = lambda p: p.detach().float().contiguous()
+        return dict(rw=PackedConv(a.reweightFlow[0].weight, a.reweightFlow[0].bias),
+                    q=PackedConv(a.query_embedding.weight, a.query_embedding.bias),
+                    k=PackedConv(a.key_embedding.weight, a.key_embedding.bias),
+                    v=PackedConv(a.value_embedding.weight, a.value_embedding.bias),
+                    out=PackedConv(a.output_linear.weight, a.output_linear.bias),
+                    gk=(f32(a.global_extract_k.weight), f32(a.global_extract_k.bias)),
+                    gv=(f32(a.global_extract_v.weight), f32(a.global_extract_v.bias)),
+                    qn=(f32(a.q_norm.weight), f32(a.q_norm.bias)), kn=(f32(a.k_norm.weight), f32(a.k_norm.bias)),
+                    vn=(f32(a.v_norm.weight), f32(a.v_norm.bias)),
+                    ffn=self._pack_ffn(m.ffn), n=(f32(m.norm.weight), f32(m.norm.bias)))
+
+    def _pack(self):
+        P = {}
+        P["enc"] = [PackedConv(self.frame_endoder.layers[2 * i].weight, self.frame_endoder.layers[2 * i].bias, groups=g)
+                    for i, (_, _, _, g) in enumerate(EncoderParams.SPEC)]
+        P["fenc"] = [self._pack_block(self.flow_encoder[i]) for i in range(1, 5)]
+        P["p2v"] = PackedConv(self.patch2vec.weight, self.patch2vec.bias)
+        P["fp2v"] = PackedConv(self.f_patch2vec.weight, self.f_patch2vec.bias)
+        if self.ape:
+            P["pos"] = (self.add_pos_emb.proj.weight.detach().float().contiguous(),
+                        self.add_pos_emb.proj.bias.detach().float().contiguous())
+        P["t0"] = self._pack_temporal(self.first_t_transformer)
+        P["s0"] = self._pack_spatial(self.first_s_transformer)
+        P["blocks"] = [(self._pack_temporal(b.t_transformer), self._pack_spatial(b.s_transformer)) for b in self.transformer]
+        k2 = self.cfg["k"][0] * self.cfg["k"][1]
+        we, be = self.vec2patch.embedding.weight.detach(), self.vec2patch.embedding.bias.detach()
+        cc = we.shape[0] // k2
+        P["v2p"] = PackedConv(we.view(cc, k2, -1).permute(1, 0, 2).reshape(cc * k2, -1), be.view(cc, k2).permute(1, 0).reshape(-1))
+        P["v2p_c"] = cc
+        d = self.decoder
+        P["dec"] = [self._pack_block(d.layer1.conv), self._pack_block(d.layer2), self._pack_block(d.layer3.conv),
+                    self._pack_block(d.final)]
+        return P
+
+    # ---- conv block helper (vanilla / gated) ---------------------------------------------------
+    def _block(self, x, packed, act="lrelu", **kw):
+        f, g = packed
+        if g is None:
+            return ops.conv2d(x, f, act=act, **kw)
+        gate = ops.conv2d(x, g, act="sigmoid", **kw)                      # network_blocks_2d.py:86-91
+        return ops.conv2d(x, f, act=act, epi="mul", aux1=gate, **kw)
+
+    # ---- transformer pieces --------------------------------------------------------------------
+    def _ffn(self, y, x_res, P, bt, th, tw, Hf, Wf):
+        """x_res + FusionFeedForward(y)  (ffn_base.py:53-77)."""
+        k, s, p = self.cfg["k"][0], self.cfg["s"][0], self.cfg["p"][0]
+        Y = ops.linear(y, P["conv1"])                                       # [bt*n, k*k*cc] tap-major
+        F = ops.fold(Y, bt, th, tw, P["cc"], k, s, p, Hf, Wf, normalize=True)  # fold(x) / fold(ones)
+        out = torch.empty_like(x_res)
+        ops.conv2d(F, P["conv2"], stride=s, pad=p, in_relu=True, epi="add", aux1=x_res, out=out.view(bt, th, tw, -1))
+        return out
+
+    def _temporal(self, x, P, b, t, th, tw, Hf, Wf):
+        """FGT/models/model.py:124-130 + attention_base.py:44-74."""
+        cfg = self.cfg
+        G, c, bt = cfg["group"], cfg["c"], b * t
+        zh, zw = math.ceil(th / G), math.ceil(tw / G)
+        pad_r, pad_b = (zw - tw % zw) % zw, (zh - th % zh) % zh
+        nh, nw = th + pad_b, tw + pad_r
+        s = ops.layernorm(x, *P["n1"])
+        if pad_r or pad_b:
+            s = ops.pad_tokens(s, bt, th, tw, nh, nw)
+        qkv = ops.linear(s, P["qkv"])
+        a = ops.attention_temporal(qkv, b, t, nh, nw, cfg["heads"], G, c)
+        if pad_r or pad_b:
+            a = ops.pad_tokens(a, bt, nh, nw, th, tw)                      # crop (attention_base.py:71-72)
+        x = ops.linear(a, P["out"], epi="add", aux1=x)
+        y = ops.layernorm(x, *P["n2"])
+        return self._ffn(y, x, P["ffn"], bt, th, tw, Hf, Wf)
+
+    def _spatial(self, x, f, P, bt, th, tw, Hf, Wf):
+        """FGT/models/model.py:144-149 + attention_flow.py:57-113, global tokens projected once per frame."""
+        cfg = self.cfg
+        ws, gd, c, cf = cfg["ws"], cfg["gd"], cfg["c"], cfg["cf"]
+        pad_r, pad_b = (ws - tw % ws) % ws, (ws - th % ws) % ws
+        nh, nw = th + pad_b, tw + pad_r
+        rows = bt * nh * nw
+        if pad_r or pad_b:
+            xp = ops.pad_tokens(x, bt, th, tw, nh, nw)
+            fp = ops.pad_tokens(f, bt, th, tw, nh, nw)
+        else:
+            xp, fp = x, f
+        fw = ops.linear(xp, P["rw"], x1=fp, act="sigmoid", epi="mul", aux1=fp)          # f * sigmoid(Linear([x|f]))
+        ng = (nh // gd) * (nw // gd)
+        dev = x.device
+        kin = torch.empty(rows + bt * ng, c + cf, dtype=torch.float32, device=dev)
+        vin = torch.empty(rows + bt * ng, c, dtype=torch.float32, device=dev)
+        gk = torch.empty(bt * ng, c + cf, dtype=torch.float32, device=dev)
+        gv = torch.empty(bt * ng, c, dtype=torch.float32, device=dev)
+        ops.dw_pool(xp, fw, bt, nh, nw, gd, *P["gk"], out=gk)
+        ops.dw_pool(xp, None, bt, nh, nw, gd, *P["gv"], out=gv)
+        q_ln = torch.empty(rows, c + cf, dtype=torch.float32, device=dev)
+        ops.layernorm(xp, *P["qn"], x1=fw, gB=P["kn"][0], bB=P["kn"][1], outA=q_ln, outB=kin[:rows])
+        ops.layernorm(gk, *P["kn"], outA=kin[rows:])
+        ops.layernorm(xp, *P["vn"], outA=vin[:rows])
+        ops.layernorm(gv, *P["vn"], outA=vin[rows:])
+        q = ops.linear(q_ln, P["q"])
+        kk = ops.linear(kin, P["k"])
+        vv = ops.linear(vin, P["v"])
+        a = ops.attention_spatial(q, kk[:rows], vv[:rows], kk[rows:], vv[rows:], bt, th, tw, nh, nw, cfg["heads"], ws, ng)
+        x = ops.linear(a, P["out"], epi="add", aux1=x)
+        y = ops.layernorm(x, *P["n"])
+        return self._ffn(y, x, P["ffn"], bt, th, tw, Hf, Wf)
+
+    # ---- per-frame stages (exposed separately so the clip scheduler can cache them) -------------
+    def encode_frames(self, masked_frames, flows, masks):
+        """model.py:253-262: returns (enc_feats [bt,Hf,Wf,2cnum], tokens [bt*n,c], flow tokens [bt*n,cf], th, tw)."""
+        P = self.packed()
+        cfg = self.cfg
+        b, t, _, H, W = masked_frames.shape
+        if H % 4 or W % 4:
+            raise ValueError(f"FGT needs H, W divisible by 4, got {H}x{W}")
+        bt = b * t
+        dev = masked_frames.device
+        cin = ops.ceil_to(self.in_channels, 4)
+        x_in = torch.empty(bt, H, W, cin, dtype=torch.float32, device=dev)
+        ops.nchw_to_nhwc(masked_frames.reshape(bt, 3, H, W).float(), x_in, coff=0,
+                         zero_to=cin if not self.passmask else 0)
+        if self.passmask:
+            ops.nchw_to_nhwc(masks.reshape(bt, 1, H, W).float(), x_in, coff=3, zero_to=cin - 3)
+        fin = ops.ceil_to(cfg["flow_in"], 4)
+        f_in = torch.empty(bt, H, W, fin, dtype=torch.float32, device=dev)
+        ops.nchw_to_nhwc(flows.reshape(bt, cfg["flow_in"], H, W).float(), f_in, coff=0, zero_to=fin)
+        E = P["enc"]
+        strides = [sp[2] for sp in EncoderParams.SPEC]
+        e = x_in
+        x0 = None
+        for i in range(9):
+            if i == 4:
+                x0 = e                                                         # model.py:58-59
+            if i <= 4:
+                e = ops.conv2d(e, E[i], stride=strides[i], pad=1, act="lrelu")
+            else:
+                e = ops.conv2d(x0, E[i], x1=e, stride=1, pad=1, act="lrelu")    # grouped concat, model.py:60-65
+        enc = e
+        FE = P["fenc"]
+        fe = self._block(f_in, FE[0], stride=1, pad=2, pad_mode="replicate")    # ReplicationPad2d(2) + 5x5 conv
+        fe = self._block(fe, FE[1], stride=2, pad=1)
+        fe = self._block(fe, FE[2], stride=1, pad=1)
+        fe = self._block(fe, FE[3], stride=2, pad=1)
+        s, p = cfg["s"][0], cfg["p"][0]
+        tok = ops.conv2d(enc, P["p2v"], stride=s, pad=p)
+        ftok = ops.conv2d(fe, P["fp2v"], stride=s, pad=p)
+        th, tw = tok.shape[1], tok.shape[2]
+        return enc, tok.view(bt * th * tw, -1), ftok.view(bt * th * tw, -1), th, tw
+
+    def transform_decode(self, enc, x, f, b, t, th, tw):
+        """model.py:272-283 given per-frame features."""
+        P = self.packed()
+        cfg = self.cfg
+        bt = b * t
+        Hf, Wf = enc.shape[1], enc.shape[2]
+        x = self._temporal(x, P["t0"], b, t, th, tw, Hf, Wf)
+        if self.ape:
+            x = ops.dw3x3_residual(x.view(bt, th, tw, -1), bt, th, tw, *P["pos"]).view(bt * th * tw, -1)
+        x = self._spatial(x, f, P["s0"], bt, th, tw, Hf, Wf)
+        for pt, ps in P["blocks"]:
+            x = self._temporal(x, pt, b, t, th, tw, Hf, Wf)
+            x = self._spatial(x, f, ps, bt, th, tw, Hf, Wf)
+        Y = ops.linear(x, P["v2p"])
+        feat = ops.fold(Y, bt, th, tw, P["v2p_c"], cfg["k"][0], cfg["s"][0], cfg["p"][0], Hf, Wf, normalize=False, res=enc)
+        D = P["dec"]
+        y = self._block(feat, D[0], stride=1, pad=1, upsample=True)
+        y = self._block(y, D[1], stride=1, pad=1)
+        y = self._block(y, D[2], stride=1, pad=1, upsample=True)
+        if D[3][1] is None:
+            return ops.conv2d(y, D[3][0], stride=1, pad=1, act="tanh", out_nchw=True)   # final conv + torch.tanh
+        y = self._block(y, D[3], act=None, stride=1, pad=1)
+        return ops.nhwc_to_nchw(ops.axpby(y, act="tanh").view(y.shape))
+
+    def forward(self, masked_frames, flows, masks):
+        b, t = masked_frames.shape[:2]
+        with torch.no_grad():
+            enc, x, f, th, tw = self.encode_frames(masked_frames, flows, masks)
+            return self.transform_decode(enc, x, f, b, t, th, tw)
+
+
+class Model(nn.Module):
+    """Drop-in for FGT.models.model.Model (FGT/models/model.py:12-25)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.net = FGT(config['tw'], config['sw'], config['gd'], config['input_resolution'], config['in_channel'],
+                       config['cnum'], config['flow_inChannel'], config['flow_cnum'], config['frame_hidden'],
+                       config['flow_hidden'], config['PASSMASK'], config['numBlocks'], config['kernel_size'],
+                       config['stride'], config['padding'], config['num_head'], config['conv_type'], config['norm'],
+                       config['use_bias'], config['ape'], config['mlp_ratio'], config['drop'], config['init_weights'])
+
+    def forward(self, frames, flows, masks):
+        return self.net(frames, flows, masks)
+
+
+DEFAULT_CONFIG = dict(tw=2, sw=8, gd=4, input_resolution=(240, 432), in_channel=4, cnum=64, flow_inChannel=2,
+                      flow_cnum=64, frame_hidden=512, flow_hidden=256, PASSMASK=1, numBlocks=8, kernel_size=(7, 7),
+                      stride=(3, 3), padding=(3, 3), num_head=4, conv_type='vanilla', norm='None', use_bias=1, ape=1,
+                      mlp_ratio=40, drop=0, init_weights=1)   # FGT/config/train.yaml:59-85 + FGT/inputs.py:48

@@ -1,0 +1,340 @@
+"""Tensor-level wrappers over the C ABI (include/fgt_hip.h).
+
+PyTorch is used here only for device memory (torch.empty through the caching allocator), the current HIP
+stream and one-time weight re-layout; every computation on activations is a libfgt_hip.so kernel.
+Activations are channels-last fp32 tensors [N, H, W, C] (or [rows, C] token matrices); channel slices of wider
+buffers are ordinary torch views (stride(-1) == 1, pixel stride = stride(-2)), so concatenations are never copied.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ACT, EPI, TILE, AttnDesc, ConvDesc, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _require_dev(*ts):
+    for t in ts:
+        if t is not None:
+            if not t.is_cuda:
+                raise RuntimeError("fgt_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
+            if t.dtype != torch.float32:
+                raise RuntimeError(f"fgt_amd ops compute in fp32, got {t.dtype}")
+
+
+def _as_map(x):
+    """[N,H,W,C] (or [rows,C]) view -> (x4, N, H, W, C, pixel stride) after validating channels-last strides."""
+    if x.dim() == 2:
+        x = x.unsqueeze(0).unsqueeze(0)
+    if x.dim() != 4:
+        raise RuntimeError(f"expected a [N,H,W,C] or [rows,C] tensor, got shape {tuple(x.shape)}")
+    N, H, W, Cc = x.shape
+    if Cc > 1 and x.stride(3) != 1:
+        raise RuntimeError("activation must be channels-last (stride(-1) == 1)")
+    if W > 1:
+        ld = x.stride(2)
+    elif H > 1:
+        ld = x.stride(1)
+    elif N > 1:
+        ld = x.stride(0)
+    else:
+        ld = Cc
+    if (H > 1 and W > 1 and x.stride(1) != W * ld) or (N > 1 and H * W > 1 and x.stride(0) != H * W * ld):
+        raise RuntimeError(f"activation pixels must be uniformly strided: shape {tuple(x.shape)} strides {x.stride()}")
+    return x, N, H, W, Cc, ld
+
+
+def ceil_to(a, m):
+    return (a + m - 1) // m * m
+
+
+class PackedConv:
+    """Weights of one conv / linear in the kernel's layout: [groups, Npad, Kpad], k = (ky*kw+kx)*Cg + ci."""
+
+    def __init__(self, w, bias=None, groups=1, scale=None, pad_cin_to4=True):
+        if w.dim() == 2:
+            w = w[:, :, None, None]
+        Cout, Cg, kh, kw = w.shape
+        assert Cout % groups == 0
+        self.Cout, self.groups, self.kh, self.kw = Cout, groups, kh, kw
+        Cg_p = ceil_to(Cg, 4) if pad_cin_to4 else Cg
+        self.Cg = Cg_p
+        self.Cin = Cg_p * groups
+        K = kh * kw * Cg_p
+        self.K = K
+        self.Kpad = ceil_to(K, 32)
+        Cout_g = Cout // groups
+        self.Npad = ceil_to(Cout_g, 128)
+        wp = w.detach().float().reshape(groups, Cout_g, Cg, kh, kw).permute(0, 1, 3, 4, 2)  # [G, Cout_g, kh, kw, Cg]
+        packed = torch.zeros(groups, self.Npad, self.Kpad, dtype=torch.float32, device=w.device)
+        tmp = torch.zeros(groups, Cout_g, kh, kw, Cg_p, dtype=torch.float32, device=w.device)
+        tmp[..., :Cg] = wp
+        packed[:, :Cout_g, :K] = tmp.reshape(groups, Cout_g, K)
+        self.w = packed.contiguous()
+        self.bias = None if bias is None else bias.detach().float().contiguous()
+        self.scale = None if scale is None else scale.detach().float().contiguous()
+
+
+def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
+           epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None):
+    """fgt_conv2d.  x (and optional x1) are channels-last maps; returns/outputs a channels-last map (or NCHW)."""
+    _require_dev(x, x1, aux1, aux2, out)
+    x, N, H, W, C0, ld0 = _as_map(x)
+    C1, ld1 = 0, 0
+    if x1 is not None:
+        x1, N1, H1, W1, C1, ld1 = _as_map(x1)
+        assert (N1, H1, W1) == (N, H, W), "conv2d: sources differ in geometry"
+    assert C0 + C1 == pc.Cin, f"conv2d: input channels {C0}+{C1} != packed {pc.Cin}"
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    dh, dw = (dil, dil) if isinstance(dil, int) else dil
+    Hin, Win = H * (2 if upsample else 1), W * (2 if upsample else 1)
+    Ho = (Hin + 2 * ph - dh * (pc.kh - 1) - 1) // sh + 1
+    Wo = (Win + 2 * pw - dw * (pc.kw - 1) - 1) // sw + 1
+    if out is None:
+        out = torch.empty((N, pc.Cout, Ho, Wo) if out_nchw else (N, Ho, Wo, pc.Cout), dtype=torch.float32, device=x.device)
+    if out_nchw:
+        assert out.is_contiguous() and tuple(out.shape) == (N, pc.Cout, Ho, Wo)
+        ldo = 0
+    else:
+        o4, oN, oH, oW, oC, ldo = _as_map(out)
+        assert (oN * oH * oW, oC) == (N * Ho * Wo, pc.Cout), f"conv2d: out shape {tuple(out.shape)} != {(N, Ho, Wo, pc.Cout)}"
+    d = ConvDesc()
+    d.N, d.H, d.W = N, H, W
+    d.C0, d.ld0, d.off0 = C0, ld0, 0
+    d.C1, d.ld1, d.off1 = C1, ld1, 0
+    d.Cout, d.groups = pc.Cout, pc.groups
+    d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.dh, d.dw = pc.kh, pc.kw, sh, sw, ph, pw, dh, dw
+    d.upsample, d.pad_mode, d.in_relu = int(upsample), {"zeros": 0, "replicate": 1}[pad_mode], int(in_relu)
+    d.Ho, d.Wo, d.ldo, d.ooff, d.out_nchw = Ho, Wo, ldo, 0, int(out_nchw)
+    d.act, d.slope, d.epi, d.act2 = ACT[act], float(slope), EPI[epi], ACT[act2]
+    d.ld_aux1 = 0 if aux1 is None else _as_map(aux1)[5]
+    d.ld_aux2 = 0 if aux2 is None else _as_map(aux2)[5]
+    d.out_scale = float(out_scale)
+    d.Kpad, d.Npad, d.tile = pc.Kpad, pc.Npad, TILE[tile]
+    check(_lib.lib().fgt_conv2d(C.byref(d), _ptr(x), _ptr(x1), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(aux1),
+                                _ptr(aux2), _ptr(out), _stream()), "fgt_conv2d")
+    return out
+
+
+def linear(x, pc, **kw):
+    """Linear on a [rows, C] token matrix (a 1x1 conv over a 1 x rows image)."""
+    rows = x.shape[0]
+    out = kw.pop("out", None)
+    if out is None:
+        out = torch.empty(rows, pc.Cout, dtype=torch.float32, device=x.device)
+    x1 = kw.pop("x1", None)
+    conv2d(x.unsqueeze(0).unsqueeze(0), pc, x1=None if x1 is None else x1.unsqueeze(0).unsqueeze(0),
+           out=out.unsqueeze(0).unsqueeze(0), **kw)
+    return out
+
+
+def layernorm(x0, gA, bA, x1=None, gB=None, bB=None, outA=None, outB=None, eps=1e-5):
+    """Row LayerNorm over [x0 | x1]; optional second affine output sharing the statistics."""
+    _require_dev(x0, x1, gA, bA, gB, bB, outA, outB)
+    rows, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[1]
+    if outA is None:
+        outA = torch.empty(rows, C0 + C1, dtype=torch.float32, device=x0.device)
+    if gB is not None and outB is None:
+        outB = torch.empty(rows, C0 + C1, dtype=torch.float32, device=x0.device)
+    check(_lib.lib().fgt_layernorm(_ptr(x0), C0, x0.stride(0), _ptr(x1), C1, 0 if x1 is None else x1.stride(0), rows, eps,
+                                   _ptr(gA), _ptr(bA), _ptr(outA), outA.stride(0), _ptr(gB), _ptr(bB), _ptr(outB),
+                                   0 if outB is None else outB.stride(0), _stream()), "fgt_layernorm")
+    return (outA, outB) if gB is not None else outA
+
+
+def attention_temporal(qkv, b, t, nh, nw, heads, group, c):
+    """Temporal zone attention reading q/k/v in place from a fused [b*t*nh*nw, 3c] projection buffer."""
+    _require_dev(qkv)
+    out = torch.empty(b * t * nh * nw, c, dtype=torch.float32, device=qkv.device)
+    d = AttnDesc()
+    d.mode, d.b, d.t, d.h, d.w, d.nh, d.nw, d.heads, d.group = 0, b, t, nh, nw, nh, nw, heads, group
+    d.ws, d.n_global = 0, 0
+    d.ldq = d.ldk = d.ldv = qkv.stride(0)
+    d.qoff, d.koff, d.voff = 0, c, 2 * c
+    d.ldg_k = d.ldg_v = 0
+    d.ldo = c
+    check(_lib.lib().fgt_attention(C.byref(d), _ptr(qkv), _ptr(qkv), _ptr(qkv), None, None, _ptr(out), _stream()),
+          "fgt_attention(temporal)")
+    return out
+
+
+def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global):
+    """Window attention + shared global tokens; q/k/v are [bt*nh*nw, c] maps on the padded grid, output cropped."""
+    _require_dev(q, k, v, kg, vg)
+    c = q.shape[1]
+    out = torch.empty(bt * h * w, c, dtype=torch.float32, device=q.device)
+    d = AttnDesc()
+    d.mode, d.b, d.t, d.h, d.w, d.nh, d.nw, d.heads, d.group = 1, 1, bt, h, w, nh, nw, heads, 0
+    d.ws, d.n_global = ws, n_global
+    d.ldq, d.ldk, d.ldv = q.stride(0), k.stride(0), v.stride(0)
+    d.qoff = d.koff = d.voff = 0
+    d.ldg_k, d.ldg_v = kg.stride(0), vg.stride(0)
+    d.ldo = c
+    check(_lib.lib().fgt_attention(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(kg), _ptr(vg), _ptr(out), _stream()),
+          "fgt_attention(spatial)")
+    return out
+
+
+def dw_pool(x0, x1, bt, nh, nw, k, w, bias, out):
+    """Depthwise kxk/stride-k conv over [x0 | x1] padded maps ([bt*nh*nw, C]) -> out [bt*(nh/k)*(nw/k), C0+C1]."""
+    _require_dev(x0, x1, w, bias, out)
+    check(_lib.lib().fgt_dw_pool(_ptr(x0), x0.shape[1], x0.stride(0), _ptr(x1), 0 if x1 is None else x1.shape[1],
+                                 0 if x1 is None else x1.stride(0), bt, nh, nw, k, _ptr(w), _ptr(bias), _ptr(out),
+                                 out.stride(0), _stream()), "fgt_dw_pool")
+    return out
+
+
+def dw3x3_residual(x, bt, h, w, wgt, bias):
+    _require_dev(x, wgt, bias)
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    check(_lib.lib().fgt_dw3x3_residual(_ptr(x), bt, h, w, x.shape[-1], _ptr(wgt), _ptr(bias), _ptr(out), _stream()),
+          "fgt_dw3x3_residual")
+    return out
+
+
+def fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize, res=None, out=None):
+    """Overlap-add of [frames*th*tw, k*k*Cc] (tap-major columns) to [frames, Hf, Wf, Cc]."""
+    _require_dev(Y, res, out)
+    if out is None:
+        out = torch.empty(frames, Hf, Wf, Cc, dtype=torch.float32, device=Y.device)
+    ldres = 0 if res is None else _as_map(res)[5]
+    check(_lib.lib().fgt_fold(_ptr(Y), Y.stride(0), frames, th, tw, Cc, k, s, p, Hf, Wf, int(normalize), _ptr(res), ldres,
+                              _ptr(out), _as_map(out)[5], _stream()), "fgt_fold")
+    return out
+
+
+def nchw_to_nhwc(src, dst, coff=0, zero_to=0, scale=1.0, shift=0.0):
+    """src [N,C,H,W] contiguous -> dst[..., coff:coff+C] of a channels-last buffer [N,H,W,ld]."""
+    _require_dev(src, dst)
+    src = src.contiguous()
+    N, Cc, H, W = src.shape
+    _, dN, dH, dW, dC, ldd = _as_map(dst)
+    assert (dN, dH, dW) == (N, H, W)
+    check(_lib.lib().fgt_nchw_to_nhwc(_ptr(src), N, Cc, H, W, _ptr(dst), ldd, coff, zero_to, scale, shift, _stream()),
+          "fgt_nchw_to_nhwc")
+    return dst
+
+
+def nhwc_to_nchw(src):
+    _require_dev(src)
+    src4, N, H, W, Cc, lds = _as_map(src)
+    out = torch.empty(N, Cc, H, W, dtype=torch.float32, device=src.device)
+    check(_lib.lib().fgt_nhwc_to_nchw(_ptr(src4), lds, 0, N, Cc, H, W, _ptr(out), _stream()), "fgt_nhwc_to_nchw")
+    return out
+
+
+def pad_tokens(src, bt, h, w, nh, nw, out=None):
+    """[bt*h*w, C] -> [bt*nh*nw, C]: zero pad where (nh,nw) is larger, crop where it is smaller."""
+    _require_dev(src, out)
+    Cc = src.shape[1]
+    if out is None:
+        out = torch.empty(bt * nh * nw, Cc, dtype=torch.float32, device=src.device)
+    check(_lib.lib().fgt_pad_tokens(_ptr(src), src.stride(0), bt, h, w, Cc, nh, nw, _ptr(out), out.stride(0), _stream()),
+          "fgt_pad_tokens")
+    return out
+
+
+def warp(img, flow, align_corners=False, absolute=False):
+    """img [B,H,W,C] channels-last, flow [B,H,W,2] -> bilinear backward warp (zeros padding)."""
+    _require_dev(img, flow)
+    img4, B, H, W, Cc, ldi = _as_map(img)
+    flow = flow.contiguous()
+    out = torch.empty(B, H, W, Cc, dtype=torch.float32, device=img.device)
+    check(_lib.lib().fgt_warp(_ptr(img4), ldi, _ptr(flow), B, H, W, Cc, int(align_corners), int(absolute), _ptr(out), Cc,
+                              _stream()), "fgt_warp")
+    return out
+
+
+def fb_consistency(flow_fw, flow_bw, alpha1=0.01, alpha2=0.5):
+    """flows [B,H,W,2] channels-last -> (occ_fw, occ_bw) [B,H,W]."""
+    _require_dev(flow_fw, flow_bw)
+    flow_fw, flow_bw = flow_fw.contiguous(), flow_bw.contiguous()
+    B, H, W, _ = flow_fw.shape
+    o1 = torch.empty(B, H, W, dtype=torch.float32, device=flow_fw.device)
+    o2 = torch.empty_like(o1)
+    check(_lib.lib().fgt_fb_consistency(_ptr(flow_fw), _ptr(flow_bw), B, H, W, alpha1, alpha2, _ptr(o1), _ptr(o2), _stream()),
+          "fgt_fb_consistency")
+    return o1, o2
+
+
+def avgpool2(src, rows, H, W):
+    _require_dev(src)
+    out = torch.empty(rows, H // 2, W // 2, dtype=torch.float32, device=src.device)
+    check(_lib.lib().fgt_avgpool2(_ptr(src), rows, H, W, _ptr(out), _stream()), "fgt_avgpool2")
+    return out
+
+
+def corr_lookup(pyr, B, H1, W1, radius, coords, out):
+    """pyr: list of level volumes; coords [B,H1,W1,2]; out channels-last [B,H1,W1,levels*(2r+1)^2] (may be a slice)."""
+    _require_dev(coords, out, *pyr)
+    arr = (C.c_void_p * len(pyr))(*[p.data_ptr() for p in pyr])
+    check(_lib.lib().fgt_corr_lookup(arr, len(pyr), B, H1, W1, radius, _ptr(coords.contiguous()), _ptr(out), _as_map(out)[5],
+                                     _stream()), "fgt_corr_lookup")
+    return out
+
+
+def convex_upsample(flow, mask):
+    """flow [B,H,W,2(+pad)] channels-last view, mask [B,H,W,576] -> [B,2,8H,8W] NCHW."""
+    _require_dev(flow, mask)
+    f4, B, H, W, _, ldf = _as_map(flow)
+    m4, _, _, _, _, ldm = _as_map(mask)
+    out = torch.empty(B, 2, 8 * H, 8 * W, dtype=torch.float32, device=flow.device)
+    check(_lib.lib().fgt_convex_upsample(_ptr(f4), ldf, _ptr(m4), ldm, B, H, W, _ptr(out), _stream()), "fgt_convex_upsample")
+    return out
+
+
+def instnorm(x, act=None, res=None, act2=None, eps=1e-5, out=None):
+    """InstanceNorm2d(affine=False) over a channels-last map, fused act / residual / act2."""
+    _require_dev(x, res, out)
+    x4, N, H, W, Cc, ld = _as_map(x)
+    stats = torch.empty(N * Cc * 2, dtype=torch.float64, device=x.device)
+    check(_lib.lib().fgt_instnorm_stats(_ptr(x4), ld, N, H * W, Cc, _ptr(stats), _stream()), "fgt_instnorm_stats")
+    if out is None:
+        out = torch.empty(N, H, W, Cc, dtype=torch.float32, device=x.device)
+    ldres = 0 if res is None else _as_map(res)[5]
+    check(_lib.lib().fgt_instnorm_apply(_ptr(x4), ld, N, H * W, Cc, _ptr(stats), eps, ACT[act], _ptr(res), ldres, ACT[act2],
+                                        _ptr(out), _as_map(out)[5], _stream()), "fgt_instnorm_apply")
+    return out
+
+
+def axpby(a, sa=1.0, b=None, sb=1.0, act=None, out=None):
+    """out = act(a*sa + b*sb) over [rows, C] views."""
+    _require_dev(a, b, out)
+    a2 = a.reshape(-1, a.shape[-1]) if a.is_contiguous() else a
+    rows, Cc = a2.shape
+    if out is None:
+        out = torch.empty(rows, Cc, dtype=torch.float32, device=a.device)
+    check(_lib.lib().fgt_axpby(_ptr(a2), a2.stride(0), sa, _ptr(b), 0 if b is None else b.stride(0), sb, rows, Cc, ACT[act],
+                               _ptr(out), out.stride(0), _stream()), "fgt_axpby")
+    return out
+
+
+def compose_blend(out_nchw, ids, first, frames01, masks, comp):
+    _require_dev(out_nchw, frames01, masks, comp)
+    n = ids.numel()
+    H, W = out_nchw.shape[-2:]
+    check(_lib.lib().fgt_compose_blend(_ptr(out_nchw.contiguous()), C.c_void_p(ids.data_ptr()), C.c_void_p(first.data_ptr()), n,
+                                       _ptr(frames01), _ptr(masks), H, W, _ptr(comp), _stream()), "fgt_compose_blend")
+    return comp
+
+
+def prof_enable(on):
+    _lib.lib().fgt_prof_enable(int(on))
+
+
+def prof_collect():
+    ms, fl, n = C.c_double(), C.c_double(), C.c_long()
+    check(_lib.lib().fgt_prof_collect(C.byref(ms), C.byref(fl), C.byref(n)), "fgt_prof_collect")
+    return ms.value, fl.value, n.value

@@ -1,0 +1,210 @@
+/*
+ * fgt_hip.h — C ABI of libfgt_hip.so, the MI355X (gfx950) hot path of hitachinsk/FGT.
+ *
+ * Every entry point takes raw device pointers (fp32 unless noted), plain ints and the HIP stream
+ * (as void*) to enqueue on.  Nothing here allocates, synchronises or touches global state.
+ * Return value: 0 on success, a negative FGT_E* code on a rejected argument or a failed launch
+ * (never throws across the ABI).  `fgt_last_error()` returns a static description of the last
+ * failure on the calling thread.
+ *
+ * Activations are channels-last: an "image" tensor is [N, H, W, C] fp32, a "token" tensor is
+ * [rows, C].  Every tensor argument comes with a pixel/row stride `ld*` (in floats) and a channel
+ * offset so that kernels can read and write slices of wider buffers without copies.
+ *
+ * The reference is pure PyTorch: it has no FFI for this path.  Each entry point below therefore
+ * cites the reference ATen call site(s) it replaces (paths relative to the reference root);
+ * INTEGRATION.md shows the ctypes binding used by the drop-in nn.Modules.
+ */
+#ifndef FGT_HIP_H
+#define FGT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FGT_OK 0
+#define FGT_EINVAL (-1)  /* rejected argument (shape, alignment, unsupported combination) */
+#define FGT_ELAUNCH (-2) /* hipLaunch / hipGetLastError reported a failure */
+
+/* activation codes shared by all epilogues */
+#define FGT_ACT_NONE 0
+#define FGT_ACT_LRELU 1 /* LeakyReLU(slope) */
+#define FGT_ACT_RELU 2
+#define FGT_ACT_SIGMOID 3
+#define FGT_ACT_TANH 4
+
+/* epilogue combine modes of fgt_conv2d (applied after bias + activation) */
+#define FGT_EPI_NONE 0
+#define FGT_EPI_MUL 1     /* v *= aux1[m, n]                                         */
+#define FGT_EPI_ADD 2     /* v += aux1[m, n]; then act2                              */
+#define FGT_EPI_GRU 3     /* v = (1 - aux1[m,n]) * aux2[m,n] + aux1[m,n] * v  (z, h) */
+
+const char* fgt_last_error(void);
+int fgt_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+ *
+ * out[n, oy, ox, ooff + g*Cout_g + co] = epi( act( cscale[co] * sum_{ky,kx,ci} x(...) * w + cbias[co] ) )
+ *
+ * Input: one or two channels-last sources concatenated per group: group g reads channels
+ *   [g*C0/groups, (g+1)*C0/groups) of x0 followed by [g*C1/groups, ...) of x1 (C1 = 0: single source).
+ *   This is the reference Encoder's group-interleaved concat (FGT/models/model.py:57-66) and plain
+ *   torch.cat for groups = 1 (LAFC/models/lafc.py:100-103, RAFT/update.py:52,97,126).
+ * upsample = 1 applies nearest x2 to the input first (network_blocks_2d.py:46-60 VanillaDeconv).
+ * pad_mode = 1 clamps coordinates (nn.ReplicationPad2d, FGT/models/model.py:207) instead of zeros.
+ * in_relu = 1 applies ReLU to input values as they are gathered (ffn_base.py:40-45: conv2 = ReLU -> Linear).
+ * A Linear / matmul is the kh = kw = 1 case with H = 1, W = rows.
+ *
+ * Replaces: F.conv2d / nn.Conv2d, nn.Conv3d with (1,k,k) or (k,1,1) kernels, nn.Linear and torch.matmul at
+ *   FGT/models/model.py:32-51,206-216,96,179-186; transformer_base/attention_base.py:37-40;
+ *   attention_flow.py:34-37,52-55; ffn_base.py:39-45; LAFC/models/lafc.py:23-80,111-115,131-139;
+ *   RAFT/extractor.py:118-192; RAFT/update.py:6-136; RAFT/corr.py:52-60.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct fgt_conv_desc {
+    int N, H, W;            /* images, input height/width BEFORE the optional x2 upsample            */
+    int C0, ld0, off0;      /* source 0: channels used, pixel stride, first channel                   */
+    int C1, ld1, off1;      /* source 1 (C1 = 0: absent)                                              */
+    int Cout, groups;
+    int kh, kw, sh, sw, ph, pw, dh, dw;
+    int upsample;           /* 0 | 1                                                                  */
+    int pad_mode;           /* 0 zeros | 1 replicate                                                  */
+    int in_relu;            /* 0 | 1                                                                  */
+    int Ho, Wo;             /* output spatial size (caller computes; validated)                       */
+    int ldo, ooff;          /* output pixel stride and first channel                                  */
+    int out_nchw;           /* 1: write out[n, co, oy, ox] (contiguous NCHW, ldo/ooff ignored)         */
+    int act;  float slope;  /* FGT_ACT_*                                                              */
+    int epi;                /* FGT_EPI_*                                                              */
+    int act2;               /* activation after FGT_EPI_ADD                                           */
+    int ld_aux1, ld_aux2;   /* row strides of aux tensors (indexed [m*ld + g*Cout_g + co])            */
+    float out_scale;        /* multiplies the value after act (before epi); 1.0f = off                */
+    int Kpad, Npad;         /* packed-weight geometry: w is [groups, Npad, Kpad], k = (ky*kw+kx)*Cg+ci */
+    int tile;               /* 0 = auto; otherwise a FGT_TILE_* override (tuning / tests)             */
+} fgt_conv_desc;
+
+#define FGT_TILE_128x128 1
+#define FGT_TILE_128x64 2
+#define FGT_TILE_64x64 3
+#define FGT_TILE_128x32 4
+#define FGT_TILE_256x128 5
+
+int fgt_conv2d(const fgt_conv_desc* d, const float* x0, const float* x1, const float* w_packed,
+               const float* cscale /* [Cout] or NULL */, const float* cbias /* [Cout] or NULL */,
+               const float* aux1, const float* aux2, float* out, void* stream);
+
+/* Row LayerNorm over the concatenation [x0 | x1] (C1 = 0: single source), eps inside rsqrt.
+ * Writes up to two outputs with different affine parameters from one pass over the row:
+ *   outA = norm * gA + bA,  outB = norm * gB + bB  (outB = NULL: skipped).
+ * Replaces nn.LayerNorm at FGT/models/model.py:126,128,147 and attention_flow.py:84-85,96 (q_norm/k_norm
+ * share statistics for window tokens; v_norm). */
+int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, long rows, float eps,
+                  const float* gA, const float* bA, float* outA, int ldA,
+                  const float* gB, const float* bB, float* outB, int ldB, void* stream);
+
+/* Fused softmax(Q K^T / sqrt(d)) V with streaming (flash) softmax, d = 128, on fp32 MFMA.
+ * mode 0 — temporal zone attention (attention_base.py:16-22 called from :61-69,93-101): tokens of all
+ *   `t` frames inside one of group x group spatial zones attend to each other.  Q/K/V are
+ *   [b*t, nh, nw, ld] maps (channel offsets qoff/koff/voff select the projection inside a fused QKV
+ *   buffer); head hd reads channels [hd*128, hd*128+128).  O has the same geometry (ldo, no offset).
+ * mode 1 — spatial window attention with shared global tokens (attention_flow.py:16-22 from :98-108):
+ *   each ws x ws window of the padded nh x nw grid attends to its own ws*ws tokens followed by
+ *   n_global tokens of the same frame (KG/VG: [bt, n_global, ldg]).  O is written to the CROPPED
+ *   [bt, h, w, ldo] grid; rows outside (h, w) are dropped (attention_flow.py:109-110). */
+typedef struct fgt_attn_desc {
+    int mode;
+    int b, t;               /* batch, frames per batch element (mode 1: only b*t is used)             */
+    int h, w;               /* un-padded token grid (mode 1 crop)                                     */
+    int nh, nw;             /* padded grid the Q/K/V maps live on                                     */
+    int heads;              /* head dim is fixed at 128                                               */
+    int group;              /* mode 0: zones per side                                                 */
+    int ws, n_global;       /* mode 1                                                                 */
+    int ldq, qoff, ldk, koff, ldv, voff, ldg_k, ldg_v, ldo;
+} fgt_attn_desc;
+
+int fgt_attention(const fgt_attn_desc* d, const float* Q, const float* K, const float* V,
+                  const float* KG, const float* VG, float* O, void* stream);
+
+/* Depthwise kxk stride-k convolution over [x0 | x1] maps -> global tokens [bt, (nh/k)*(nw/k), C0+C1]
+ * (attention_flow.py:44-48,80-81,87-91).  w is the reference layout [C,1,k,k], bias [C]. */
+int fgt_dw_pool(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, int bt, int nh, int nw,
+                int k, const float* w, const float* bias, float* out, int ldo, void* stream);
+
+/* Depthwise 3x3, stride 1, pad 1, plus identity: out = dwconv(x) + x  (FGT/models/model.py:76-88). */
+int fgt_dw3x3_residual(const float* x, int bt, int h, int w, int C, const float* wgt, const float* bias,
+                       float* out, void* stream);
+
+/* Overlap-add "fold" of token patches back to a feature map, as a gather:
+ *   out[f, y, x, c] = (sum over tokens (i,j) covering (y,x) of Y[f, i*tw+j, ((y-i*s+p)*k + (x-j*s+p))*C + c])
+ *                     [/ count(y,x) if normalize] [+ res[f,y,x,c] if res]
+ * Y's column order is tap-major (ky,kx,c) — the packed Linear weights are permuted accordingly.
+ * Replaces F.fold / nn.Fold at ffn_base.py:56-75 (normalize=1: fold(x)/fold(ones)) and
+ * FGT/models/model.py:102-110 (normalize=0) fused with the residual add at model.py:279. */
+int fgt_fold(const float* Y, int ldy, int frames, int th, int tw, int C, int k, int s, int p, int Hf, int Wf,
+             int normalize, const float* res, int ldres, float* out, int ldo, void* stream);
+
+/* NCHW -> channels-last slice: dst[n, y, x, coff + c] = src[n, c, y, x] * scale + shift for c < C;
+ * zero_to > C additionally zero-fills channels [C, zero_to).  (input packing: model.py:253-257) */
+int fgt_nchw_to_nhwc(const float* src, int N, int C, int H, int W, float* dst, int ldd, int coff, int zero_to,
+                     float scale, float shift, void* stream);
+/* channels-last slice -> NCHW */
+int fgt_nhwc_to_nchw(const float* src, int lds, int coff, int N, int C, int H, int W, float* dst, void* stream);
+
+/* copy a token map [bt,h,w,C] (row stride lds) into [bt,nh,nw,C]: zero pad where the destination grid is larger
+ * (attention_flow.py:66-68, attention_base.py:55-57), crop where it is smaller (attention_base.py:71-72). */
+int fgt_pad_tokens(const float* src, int lds, int bt, int h, int w, int C, int nh, int nw, float* dst, int ldd,
+                   void* stream);
+
+/* Backward bilinear warp, zeros padding (LAFC/models/utils/fbConsistencyCheck.py:8-26 image_warp:
+ * grid_sample default align_corners=False on a linspace(-1,1) base grid + flow/((W-1)/2)).
+ * img [B,H,W,C] channels-last (ld), flow [B,H,W,2] channels-last; align_corners = 1 gives
+ * RAFT/utils/utils.py:57-71 bilinear_sampler semantics with absolute pixel coords in `flow`. */
+int fgt_warp(const float* img, int ldi, const float* flow, int B, int H, int W, int C, int align_corners,
+             int absolute_coords, float* out, int ldo, void* stream);
+
+/* Forward/backward consistency occlusion masks (fbConsistencyCheck.py:29-47).
+ * flow_fw/flow_bw [B,H,W,2]; occ_fw/occ_bw [B,H,W] (1.0 = occluded). */
+int fgt_fb_consistency(const float* flow_fw, const float* flow_bw, int B, int H, int W, float alpha1, float alpha2,
+                       float* occ_fw, float* occ_bw, void* stream);
+
+/* RAFT correlation pyramid: 2x2 average pooling of a [rows, H, W] volume (RAFT/corr.py:23-27). */
+int fgt_avgpool2(const float* src, long rows, int H, int W, float* dst, void* stream);
+
+/* RAFT correlation lookup (RAFT/corr.py:29-50): for every query pixel, 4 levels x (2r+1)^2 bilinear taps
+ * (align_corners=True, zeros outside).  pyr[l] is [B*H1*W1, H1>>l, W1>>l]; coords [B,H1,W1,2] (x,y);
+ * out [B,H1,W1, 4*(2r+1)^2] channels-last with the reference's channel order (level, dx-major "transposed" window). */
+int fgt_corr_lookup(const float* const* pyr, int levels, int B, int H1, int W1, int radius, const float* coords,
+                    float* out, int ldo, void* stream);
+
+/* RAFT convex upsampling (RAFT/raft.py:73-84): flow [B,H,W,2] (ld), mask [B,H,W,576] (ld) -> up [B,2,8H,8W] NCHW */
+int fgt_convex_upsample(const float* flow, int ldf, const float* mask, int ldm, int B, int H, int W, float* out,
+                        void* stream);
+
+/* nn.InstanceNorm2d (affine=False, biased variance; RAFT/extractor.py:27-31) on a channels-last tensor:
+ * fgt_instnorm_stats accumulates (sum, sum of squares) per (image, channel) into stats[N][C][2] (fp64 scratch,
+ * zeroed by the call); fgt_instnorm_apply writes y = act2( act((x-mean)*rstd) + res ) (res = NULL: y = act(...)). */
+int fgt_instnorm_stats(const float* x, int ld, int N, int HW, int C, double* stats, void* stream);
+int fgt_instnorm_apply(const float* x, int ld, int N, int HW, int C, const double* stats, float eps, int act,
+                       const float* res, int ldres, int act2, float* out, int ldo, void* stream);
+
+/* Generic pointwise helper: out = act(a * sa + b * sb) over rows x C slices (b = NULL: single operand). */
+int fgt_axpby(const float* a, int lda, float sa, const float* b, int ldb, float sb, long rows, int C, int act,
+              float* out, int ldo, void* stream);
+
+/* tool/video_inpainting.py:725-740 on device: comp = trunc_u8((x+1)/2*255)*m + trunc_u8(frame*255)*(1-m);
+ * a frame's first visit stores, later visits average 0.5/0.5 (order dependent: call in ascending window order).
+ * out_nchw [n,3,H,W] model output for the window's neighbour frames; ids[i] = clip frame index of row i and
+ * first[i] = 1 when that frame has not been composed before (both device int32, decided by the host scheduler);
+ * frames01 [N,3,H,W], masks [N,1,H,W], comp [N,H,W,3] fp32. */
+int fgt_compose_blend(const float* out_nchw, const int* ids, const int* first, int n, const float* frames01,
+                      const float* masks, int H, int W, float* comp, void* stream);
+
+/* ---- per-kernel timing of fgt_conv2d launches with HIP events on the launch stream (bench roofline) ----
+ * fgt_prof_enable(1) makes every fgt_conv2d launch record an event pair and accumulate its algorithmic
+ * flops (2*M*Cout_g*K*groups); fgt_prof_collect synchronises the events and returns totals. */
+void fgt_prof_enable(int on);
+int fgt_prof_collect(double* total_ms, double* total_flops, long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FGT_HIP_H */
