@@ -1,0 +1,191 @@
+"""Executable CPU specification of the kernel contracts in include/fgt_hip.h (TEST INFRASTRUCTURE ONLY).
+
+Each function mirrors the signature of fgt_amd.ops and restates, with torch CPU ops, what the HIP kernel is
+specified to compute (packed-weight layout, two-source concat, tap-major fold columns, zone/window addressing ...).
+tests/test_host_logic.py monkeypatches it under the nn.Module mirrors to check the HOST logic (shapes, views,
+weight re-layouts, call order) against the oracle without a GPU.  The product never imports this file.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from fgt_amd.ops import PackedConv, ceil_to, _as_map  # noqa: F401  (host-side helpers are device agnostic)
+
+_ACT = {None: lambda v, s: v, "none": lambda v, s: v, "lrelu": lambda v, s: F.leaky_relu(v, s), "relu": lambda v, s: F.relu(v),
+        "sigmoid": lambda v, s: torch.sigmoid(v), "tanh": lambda v, s: torch.tanh(v)}
+
+
+def _dense_weight(pc):
+    G, Cout_g = pc.groups, pc.Cout // pc.groups
+    w = pc.w[:, :Cout_g, :pc.K].reshape(G, Cout_g, pc.kh, pc.kw, pc.Cg).permute(0, 1, 4, 2, 3)
+    return w.reshape(pc.Cout, pc.Cg, pc.kh, pc.kw)
+
+
+def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
+           epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None):
+    x, N, H, W, C0, _ = _as_map(x)
+    G = pc.groups
+    if x1 is not None:
+        x1, _, _, _, C1, _ = _as_map(x1)
+        cat = torch.cat([x.reshape(N, H, W, G, C0 // G), x1.reshape(N, H, W, G, C1 // G)], -1).reshape(N, H, W, C0 + C1)
+    else:
+        cat = x
+    assert cat.shape[-1] == pc.Cin
+    inp = cat.permute(0, 3, 1, 2)
+    if upsample:
+        inp = F.interpolate(inp, scale_factor=2)
+    if in_relu:
+        inp = F.relu(inp)
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    if pad_mode == "replicate":
+        inp = F.pad(inp, (pw, pw, ph, ph), mode="replicate")
+        ph = pw = 0
+    y = F.conv2d(inp, _dense_weight(pc), None, stride, (ph, pw), dil, G)
+    if pc.scale is not None:
+        y = y * pc.scale.view(1, -1, 1, 1)
+    if pc.bias is not None:
+        y = y + pc.bias.view(1, -1, 1, 1)
+    y = _ACT[act](y, slope) * out_scale
+    Nn, Co, Ho, Wo = y.shape
+    y = y.permute(0, 2, 3, 1)
+    if epi == "mul":
+        y = y * aux1.reshape(Nn, Ho, Wo, Co)
+    elif epi == "add":
+        y = _ACT[act2](y + aux1.reshape(Nn, Ho, Wo, Co), slope)
+    elif epi == "gru":
+        z, h = aux1.reshape(Nn, Ho, Wo, Co), aux2.reshape(Nn, Ho, Wo, Co)
+        y = (1 - z) * h + z * y
+    if out_nchw:
+        res = y.permute(0, 3, 1, 2).contiguous()
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+    if out is None:
+        return y.contiguous()
+    out.copy_(y.reshape(out.shape))
+    return out
+
+
+def linear(x, pc, **kw):
+    rows = x.shape[0]
+    out = kw.pop("out", None)
+    x1 = kw.pop("x1", None)
+    y = conv2d(x.unsqueeze(0).unsqueeze(0), pc, x1=None if x1 is None else x1.unsqueeze(0).unsqueeze(0), **kw).reshape(rows, pc.Cout)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def layernorm(x0, gA, bA, x1=None, gB=None, bB=None, outA=None, outB=None, eps=1e-5):
+    cat = x0 if x1 is None else torch.cat([x0, x1], 1)
+    C = cat.shape[1]
+    a = F.layer_norm(cat, (C,), gA, bA, eps)
+    if outA is not None:
+        outA.copy_(a)
+        a = outA
+    if gB is None:
+        return a
+    b = F.layer_norm(cat, (C,), gB, bB, eps)
+    if outB is not None:
+        outB.copy_(b)
+        b = outB
+    return a, b
+
+
+def _sdpa(q, k, v):
+    s = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(q.size(-1))
+    return torch.matmul(F.softmax(s, dim=-1), v)
+
+
+def attention_temporal(qkv, b, t, nh, nw, heads, group, c):
+    zh, zw, d = nh // group, nw // group, c // heads
+
+    def zones(y):
+        return y.reshape(b, t, group, zh, group, zw, heads, d).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, group * group, heads, -1, d)
+
+    a = _sdpa(zones(qkv[:, :c]), zones(qkv[:, c:2 * c]), zones(qkv[:, 2 * c:3 * c]))
+    return a.view(b, group, group, heads, t, zh, zw, d).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(b * t * nh * nw, c)
+
+
+def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global):
+    c = q.shape[1]
+    gh, gw, d = nh // ws, nw // ws, c // heads
+
+    def windows(y):
+        return y.reshape(bt, gh, ws, gw, ws, c).transpose(2, 3).reshape(bt, gh * gw, ws * ws, c)
+
+    def split(y):
+        return y.reshape(bt, gh * gw, -1, heads, d).permute(0, 1, 3, 2, 4)
+
+    K = torch.cat([windows(k), kg.reshape(bt, 1, n_global, c).expand(-1, gh * gw, -1, -1)], 2)
+    V = torch.cat([windows(v), vg.reshape(bt, 1, n_global, c).expand(-1, gh * gw, -1, -1)], 2)
+    a = _sdpa(split(windows(q)), split(K), split(V))
+    a = a.transpose(2, 3).reshape(bt, gh, gw, ws, ws, c).transpose(2, 3).reshape(bt, nh, nw, c)
+    return a[:, :h, :w].reshape(bt * h * w, c)
+
+
+def dw_pool(x0, x1, bt, nh, nw, k, w, bias, out):
+    cat = x0 if x1 is None else torch.cat([x0, x1], 1)
+    C = cat.shape[1]
+    y = F.conv2d(cat.reshape(bt, nh, nw, C).permute(0, 3, 1, 2), w, bias, stride=k, groups=C)
+    out.copy_(y.permute(0, 2, 3, 1).reshape(-1, C))
+    return out
+
+
+def dw3x3_residual(x, bt, h, w, wgt, bias):
+    C = x.shape[-1]
+    m = x.reshape(bt, h, w, C).permute(0, 3, 1, 2)
+    return (F.conv2d(m, wgt, bias, 1, 1, 1, C) + m).permute(0, 2, 3, 1).contiguous().reshape(x.shape)
+
+
+def fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize, res=None, out=None):
+    cols = Y.reshape(frames, th * tw, k * k, Cc).permute(0, 3, 2, 1).reshape(frames, Cc * k * k, th * tw)  # back to (c, tap)
+    f = F.fold(cols, (Hf, Wf), k, stride=s, padding=p)
+    if normalize:
+        f = f / F.fold(torch.ones(frames, k * k, th * tw), (Hf, Wf), k, stride=s, padding=p)
+    f = f.permute(0, 2, 3, 1)
+    if res is not None:
+        f = res.reshape(frames, Hf, Wf, Cc) + f
+    if out is not None:
+        out.copy_(f)
+        return out
+    return f.contiguous()
+
+
+def nchw_to_nhwc(src, dst, coff=0, zero_to=0, scale=1.0, shift=0.0):
+    C = src.shape[1]
+    dst[..., coff:coff + C] = src.permute(0, 2, 3, 1) * scale + shift
+    if zero_to > C:
+        dst[..., coff + C:coff + zero_to] = 0
+    return dst
+
+
+def nhwc_to_nchw(src):
+    return _as_map(src)[0].permute(0, 3, 1, 2).contiguous()
+
+
+def pad_tokens(src, bt, h, w, nh, nw, out=None):
+    C = src.shape[1]
+    m = src.reshape(bt, h, w, C)
+    o = torch.zeros(bt, nh, nw, C)
+    hh, ww = min(h, nh), min(w, nw)
+    o[:, :hh, :ww] = m[:, :hh, :ww]
+    o = o.reshape(bt * nh * nw, C)
+    if out is not None:
+        out.copy_(o)
+        return out
+    return o
+
+
+def axpby(a, sa=1.0, b=None, sb=1.0, act=None, out=None):
+    v = a.reshape(-1, a.shape[-1]) * sa
+    if b is not None:
+        v = v + b * sb
+    v = _ACT[act](v, 0.2)
+    if out is not None:
+        out.copy_(v)
+        return out
+    return v

@@ -1,0 +1,50 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every declared symbol."""
+import ctypes
+import os
+import re
+
+from fgt_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "fgt_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fgt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_library_exports_every_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "build first: python -m fgt_amd.build"
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    for s in declared_symbols():
+        assert hasattr(h, s), f"{s} not exported"
+    assert _lib.lib().fgt_abi_version() == 1
+
+
+def test_struct_sizes_match_header():
+    # 37 ints/floats in fgt_conv_desc, 20 ints in fgt_attn_desc (4 bytes each, no padding)
+    assert ctypes.sizeof(_lib.ConvDesc) == 37 * 4
+    assert ctypes.sizeof(_lib.AttnDesc) == 20 * 4
+
+
+def test_rejects_bad_arguments_without_gpu():
+    # argument validation happens before any HIP call: callable on a CPU-only box
+    d = _lib.ConvDesc()
+    rc = _lib.lib().fgt_conv2d(ctypes.byref(d), None, None, None, None, None, None, None, None, None)
+    assert rc == -1
+    assert b"null" in _lib.lib().fgt_last_error()
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    import pytest
+    import torch
+    from fgt_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.layernorm(torch.zeros(4, 8), torch.ones(8), torch.zeros(8))
