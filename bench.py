@@ -1,0 +1,150 @@
+#!/usr/bin/env python
+"""Headline benchmark: inpainted frames/sec of the FGT stage on a synthetic 432x240x80 clip (BASELINE.json).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over the clip: all 16 sliding-window Model.forward calls of the reference
+schedule (t = 13,17,18,... sum 275) + uint8 compose + ordered blend, inputs resident in HBM.  With N > 1 ranks the
+windows of the SAME clip are sharded round-robin and exchanged with one RCCL all-gather ("strong" scaling).
+Prints ONE JSON line on rank 0 (contract in the task statement), including `roofline` for the dominant kernel
+(the fp32-MFMA implicit-GEMM conv/GEMM, timed per launch with HIP events on the launch stream) and `cpu_baseline`
+(the oracle = PyTorch CPU restatement of the reference, timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def fgt_flops(t):
+    """Algorithmic FLOPs of one reference Model.forward at 240x432 (torch FlopCounterMode)."""
+    return (147.03 * t + 1.0618 * t * t) * 1e9
+
+
+def cpu_baseline(cfg, sd, frames, flows, masks, sched):
+    """Oracle (port of the reference CPU path) on a bounded sample: the first window of the schedule (t = 13)."""
+    from oracle import fgt_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    nb, ref = sched[0]
+    ids = nb + ref
+    m = masks[:, ids].cpu()
+    mf = (frames[:, ids].cpu() * 2 - 1) * (1 - m)
+    fl = flows[:, ids].cpu()
+    O.fgt_forward(sd, cfg, mf[:, :2], fl[:, :2], m[:, :2])          # warm-up (threads, allocator)
+    t0 = time.perf_counter()
+    O.fgt_forward(sd, cfg, mf, fl, m)
+    dt = time.perf_counter() - t0
+    total = sum(fgt_flops(len(a) + len(b)) for a, b in sched)
+    est_clip_s = dt * total / fgt_flops(len(ids))
+    return {"value": round(frames.shape[1] / est_clip_s, 4), "unit": "frames/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"oracle fgt_forward, window 0 (t={len(ids)}) of the 80-frame schedule at 240x432 in {dt:.2f} s; "
+                      f"clip time extrapolated by F(t)=147.03t+1.0618t^2 GFLOP over the 16 windows"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=80)
+    ap.add_argument("--height", type=int, default=240)
+    ap.add_argument("--width", type=int, default=432)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event timing of the conv kernel")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    torch.set_grad_enabled(False)
+
+    from fgt_amd import ops
+    from fgt_amd.fgt_model import DEFAULT_CONFIG, Model
+    from fgt_amd.scheduler import ClipRunner
+    from fgt_amd.synth import synth_clip, synth_state_dict
+
+    cfg = dict(DEFAULT_CONFIG, input_resolution=(240, 432))
+    model = Model(cfg).eval()
+    sd = synth_state_dict(model.state_dict(), seed=0)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    frames, flows, masks = synth_clip(args.frames, args.height, args.width, seed=1234, device=dev)
+    runner = ClipRunner(model, frames, flows, masks, rank=rank, world=world)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.run()
+    barrier()
+    if not args.no_prof:
+        ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        comp = runner.run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if not args.no_prof:
+        ops.prof_enable(False)
+        k_ms, k_flops, k_launches = ops.prof_collect()
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = tt.item()
+
+    if rank == 0:
+        fps = args.frames * args.steps / dt
+        clip_flops = sum(fgt_flops(len(a) + len(b)) for a, b in runner.sched) if (args.height, args.width) == (240, 432) else None
+        out = {
+            "metric": "inpainted frames/sec at 432x240x80 clip (FGT stage: 16 sliding-window forwards + compose/blend)",
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"full FGT forward, random (N(0,0.02)) weights, {args.width}x{args.height}x{args.frames} clip, "
+                                   f"reference window schedule (neighbor_stride 5, step 10; sum t = {sum(len(a) + len(b) for a, b in runner.sched)})",
+                       "windows": len(runner.sched), "sharding": f"windows round-robin over {world} rank(s)"},
+        }
+        if clip_flops:
+            out["effective_tflops"] = round(clip_flops * args.steps / dt / 1e12, 2)
+        if not args.no_prof and k_ms > 0:
+            ach = k_flops / (k_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 MFMA implicit-GEMM conv + all Linear layers)",
+                               "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                               "launches": k_launches, "kernel_ms_per_step": round(k_ms / args.steps, 3),
+                               "share_of_step": round(k_ms / (1e3 * dt), 3)}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, frames, flows, masks, runner.sched)
+        # sanity on the produced clip (finite, in range) so a broken run cannot report a number silently
+        c = comp.float()
+        out["output_sane"] = bool(torch.isfinite(c).all() and c.min().item() >= 0 and c.max().item() <= 255)
+        print(json.dumps(out))
+        assert out["output_sane"], "composited clip has NaN/inf or out-of-range values"
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""Host scheduling / compose logic on CPU: ClipRunner vs the oracle's restatement of tool/video_inpainting.py:687-740,
+single process and window-sharded over 2 gloo ranks (the N>1 path of bench.py)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fgt_amd.scheduler import ClipRunner, shard_windows, window_schedule
+from oracle import fgt_oracle as O
+
+torch.set_grad_enabled(False)
+
+
+def cheap_forward(mf, fl, ms):
+    """Stand-in for the model: any deterministic map [1,t,3,H,W] -> [t,3,H,W] in (-1,1) that depends on all inputs."""
+    x = mf[0] * 0.7 + fl[0].mean(1, keepdim=True) * 0.2 + ms[0] * 0.1
+    return torch.tanh(x + 0.05 * x.mean(0, keepdim=True))
+
+
+def clip(n, H=16, W=24, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    fr = torch.rand(1, n, 3, H, W, generator=g)
+    ms = (torch.rand(1, n, 1, H, W, generator=g) > 0.6).float()
+    fl = O.norm_flows(torch.randn(1, n, 2, H, W, generator=g))
+    return fr, fl, ms
+
+
+def test_schedule_matches_oracle_and_reference_log():
+    for n in (7, 20, 33, 80, 160):
+        assert window_schedule(n) == O.window_schedule(n)
+    assert window_schedule(40, 5, 10, 4) == O.window_schedule(40, 5, 10, 4)
+    s = window_schedule(80)
+    assert [len(a) + len(b) for a, b in s] == [13, 17, 18, 17, 18, 17, 18, 17, 18, 17, 18, 17, 18, 17, 18, 17]
+
+
+def test_shard_windows_is_a_partition():
+    for world in (1, 2, 3, 4, 8):
+        parts = [shard_windows(16, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(16))
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+@pytest.mark.parametrize("n", [6, 23, 40])
+def test_cliprunner_matches_oracle_clip(n):
+    fr, fl, ms = clip(n)
+    ref = O.fgt_clip(None, None, fr, fl, ms, forward=cheap_forward)
+    got = ClipRunner(None, fr, fl, ms, forward=cheap_forward).run()
+    assert torch.equal(got, ref)          # integer-valued uint8 compose + exact 0.5/0.5 averages: bit exact
+
+
+def _worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fr, fl, ms = clip(n)
+    got = ClipRunner(None, fr, fl, ms, forward=cheap_forward, rank=rank, world=world).run()
+    q.put((rank, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [23, 40])
+def test_window_sharding_two_ranks_gloo(n):
+    world, port = 2, 29500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    fr, fl, ms = clip(n)
+    ref = O.fgt_clip(None, None, fr, fl, ms, forward=cheap_forward)
+    for r in range(world):
+        assert torch.equal(res[r], ref), f"rank {r} differs from the single-process result"

@@ -1,0 +1,25 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, smoke, short bench, rocprofv3 kernel stats.  Everything lands in gpurun_out/.
+# usage (from the repo root on the GPU box):  bash tools/gpu_check.sh [quick]
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+echo "== pytest -m gpu" 
+timeout 1200 python -m pytest tests -m gpu -q -rA --durations=5 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest exit: $?" | tee -a gpurun_out/pytest_gpu.log
+grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -3
+echo "== smoke"
+timeout 300 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit: $?" | tee -a gpurun_out/smoke.log
+tail -2 gpurun_out/smoke.log
+echo "== bench"
+timeout 900 python bench.py --steps 2 --warmup 1 > gpurun_out/bench.log 2>&1; echo "bench exit: $?" | tee -a gpurun_out/bench.log
+tail -3 gpurun_out/bench.log
+if [ "${1:-}" != "quick" ]; then
+  echo "== rocprofv3 kernel stats"
+  rm -rf gpurun_out/prof
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o fgt -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-prof > "$GRAFT_REPO_ROOT/gpurun_out/rocprof.log" 2>&1)
+  echo "rocprof exit: $?"
+  find gpurun_out/prof -name "*stats*" | head
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && head -25 "$f"
+fi
