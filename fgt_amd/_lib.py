@@ -3,6 +3,9 @@ library raises at first use, and every non-zero return code raises RuntimeError 
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- MUST precede loading libfgt_hip.so: torch ships its own libamdhip64; loading ours first would
+#                              bring up a second HIP runtime with no device context ("no ROCm-capable device is detected").
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfgt_hip.so")
 
@@ -51,7 +54,7 @@ SIGNATURES = {
     "fgt_convex_upsample": [_P, _I, _P, _I, _I, _I, _I, _P, _P],
     "fgt_instnorm_stats": [_P, _I, _I, _I, _I, _P, _P],
     "fgt_instnorm_apply": [_P, _I, _I, _I, _I, _P, _F, _I, _P, _I, _I, _P, _I, _P],
-    "fgt_axpby": [_P, _I, _F, _P, _I, _F, _L, _I, _I, _P, _I, _P],
+    "fgt_axpby": [_P, _I, _F, _P, _I, _F, _L, _I, _I, _F, _P, _I, _P],
     "fgt_compose_blend": [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P],
     "fgt_prof_enable": [_I],
     "fgt_prof_collect": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)],

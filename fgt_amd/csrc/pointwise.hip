@@ -196,13 +196,13 @@ __global__ void __launch_bounds__(256) pad_tokens_kernel(const float* src, int l
 }
 
 __global__ void __launch_bounds__(256) axpby_kernel(const float* a, int lda, float sa, const float* b, int ldb, float sb,
-                                                    long rows, int C, int act, float* out, int ldo) {
+                                                    long rows, int C, int act, float slope, float* out, int ldo) {
     const long total = rows * C;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long r = idx / C; const int c = (int)(idx - r * C);
         float v = a[r * lda + c] * sa;
         if (b) v += b[r * ldb + c] * sb;
-        out[r * ldo + c] = fgt_act(v, act, 0.2f);
+        out[r * ldo + c] = fgt_act(v, act, slope);
     }
 }
 
@@ -299,10 +299,10 @@ extern "C" int fgt_pad_tokens(const float* src, int lds, int bt, int h, int w, i
 }
 
 extern "C" int fgt_axpby(const float* a, int lda, float sa, const float* b, int ldb, float sb, long rows, int C, int act,
-                         float* out, int ldo, void* stream) {
+                         float slope, float* out, int ldo, void* stream) {
     FGT_REQUIRE(a && out && rows > 0 && C > 0, "fgt_axpby: bad arguments");
     hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, a, lda, sa, b, ldb, sb, rows, C,
-                       act, out, ldo);
+                       act, slope, out, ldo);
     return fgt_check_launch("axpby");
 }
 

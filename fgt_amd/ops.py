@@ -309,7 +309,7 @@ def instnorm(x, act=None, res=None, act2=None, eps=1e-5, out=None):
     return out
 
 
-def axpby(a, sa=1.0, b=None, sb=1.0, act=None, out=None):
+def axpby(a, sa=1.0, b=None, sb=1.0, act=None, out=None, slope=0.2):
     """out = act(a*sa + b*sb) over [rows, C] views."""
     _require_dev(a, b, out)
     a2 = a.reshape(-1, a.shape[-1]) if a.is_contiguous() else a
@@ -317,7 +317,7 @@ def axpby(a, sa=1.0, b=None, sb=1.0, act=None, out=None):
     if out is None:
         out = torch.empty(rows, Cc, dtype=torch.float32, device=a.device)
     check(_lib.lib().fgt_axpby(_ptr(a2), a2.stride(0), sa, _ptr(b), 0 if b is None else b.stride(0), sb, rows, Cc, ACT[act],
-                               _ptr(out), out.stride(0), _stream()), "fgt_axpby")
+                               slope, _ptr(out), out.stride(0), _stream()), "fgt_axpby")
     return out
 
 

@@ -1,0 +1,240 @@
+"""MI355X-native RAFT optical-flow estimator behind the reference's nn.Module API.
+
+`RAFT(args).forward(image1[B,3,H,W] 0..255, image2, iters=12, flow_init=None, upsample=True, test_mode=False)`
+with the constructor/forward signature and state_dict keys of RAFT/raft.py:24-145 (basic model, `args.small=False`;
+`tool/video_inpainting.py:186-197,263`).  Returns `(flow_low, flow_up)` in test_mode, the list of up-sampled
+predictions otherwise.
+
+Feature / context encoders, the all-pairs correlation GEMM, the motion encoder, the separable ConvGRU (sigmoid/tanh and
+the gate blend fused into conv epilogues, `cat([h, x])` read as two sources), flow/mask heads: fgt_conv2d.  Instance
+norm, correlation pyramid pooling, the 4-level 9x9 bilinear lookup and convex up-sampling: dedicated HBM-bound kernels.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .fgt_model import ConvParams
+from .ops import PackedConv
+
+
+class BatchNormParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.eps = 1e-5
+
+
+class NoParams(nn.Module):
+    """InstanceNorm2d(affine=False) / activation placeholders: no state."""
+
+
+def _conv(cin, cout, k):
+    m = ConvParams(cin, cout, k)
+    nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+    return m
+
+
+class ResBlockParams(nn.Module):
+    """RAFT/extractor.py:6-44 attribute names (norm3 is shared with downsample.1)."""
+
+    def __init__(self, cin, cout, norm, stride):
+        super().__init__()
+        self.conv1, self.conv2 = _conv(cin, cout, 3), _conv(cout, cout, 3)
+        mk = (lambda: BatchNormParams(cout)) if norm == "batch" else NoParams
+        self.norm1, self.norm2 = mk(), mk()
+        self.stride = stride
+        if stride != 1:
+            self.norm3 = mk()
+            self.downsample = nn.ModuleList([_conv(cin, cout, 1), self.norm3])
+        else:
+            self.downsample = None
+
+
+class EncoderParams(nn.Module):
+    """RAFT/extractor.py:118-171 (BasicEncoder)."""
+
+    def __init__(self, output_dim, norm):
+        super().__init__()
+        self.norm_fn = norm
+        self.norm1 = BatchNormParams(64) if norm == "batch" else NoParams()
+        self.conv1 = _conv(3, 64, 7)
+        self.layer1 = nn.ModuleList([ResBlockParams(64, 64, norm, 1), ResBlockParams(64, 64, norm, 1)])
+        self.layer2 = nn.ModuleList([ResBlockParams(64, 96, norm, 2), ResBlockParams(96, 96, norm, 1)])
+        self.layer3 = nn.ModuleList([ResBlockParams(96, 128, norm, 2), ResBlockParams(128, 128, norm, 1)])
+        self.conv2 = _conv(128, output_dim, 1)
+
+
+class MotionEncoderParams(nn.Module):
+    def __init__(self, cor_planes):
+        super().__init__()
+        self.convc1, self.convc2 = ConvParams(cor_planes, 256, 1), ConvParams(256, 192, 3)
+        self.convf1, self.convf2 = ConvParams(2, 128, 7), ConvParams(128, 64, 3)
+        self.conv = ConvParams(64 + 192, 128 - 2, 3)
+
+
+class SepConvGRUParams(nn.Module):
+    def __init__(self, hidden, inp):
+        super().__init__()
+        for n in ("z", "r", "q"):
+            setattr(self, f"conv{n}1", ConvParams(hidden + inp, hidden, (1, 5)))
+        for n in ("z", "r", "q"):
+            setattr(self, f"conv{n}2", ConvParams(hidden + inp, hidden, (5, 1)))
+
+
+class FlowHeadParams(nn.Module):
+    def __init__(self, cin, hidden):
+        super().__init__()
+        self.conv1, self.conv2 = ConvParams(cin, hidden, 3), ConvParams(hidden, 2, 3)
+
+
+class UpdateBlockParams(nn.Module):
+    def __init__(self, cor_planes, hidden=128):
+        super().__init__()
+        self.encoder = MotionEncoderParams(cor_planes)
+        self.gru = SepConvGRUParams(hidden, 128 + hidden)
+        self.flow_head = FlowHeadParams(hidden, 256)
+        self.mask = nn.ModuleList([ConvParams(128, 256, 3), NoParams(), ConvParams(256, 64 * 9, 1)])
+
+
+class RAFT(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        if getattr(args, "small", False):
+            raise NotImplementedError("RAFT-small is not used by FGT (tool/video_inpainting.py:186-197 loads raft-things)")
+        if getattr(args, "alternate_corr", False):
+            raise NotImplementedError("alternate_corr is dead code in the reference (RAFT/raft.py:106 names an undefined class)")
+        self.hidden_dim = self.context_dim = 128
+        self.corr_levels, self.corr_radius = 4, 4
+        args.corr_levels, args.corr_radius = 4, 4                      # raft.py:36-37
+        if not hasattr(args, "dropout"):
+            args.dropout = 0
+        self.fnet = EncoderParams(256, "instance")
+        self.cnet = EncoderParams(256, "batch")
+        self.update_block = UpdateBlockParams(self.corr_levels * (2 * self.corr_radius + 1) ** 2)
+        self._packed, self._key = None, None
+
+    # ------------------------------------------------------------------ packing
+    @staticmethod
+    def _pk(conv, bn=None):
+        """PackedConv with an eval-mode BatchNorm folded into the epilogue's per-channel scale/bias."""
+        w, b = conv.weight.detach(), conv.bias.detach()
+        if bn is None or isinstance(bn, NoParams):
+            return PackedConv(w, b)
+        s = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+        return PackedConv(w, (b - bn.running_mean) * s + bn.bias.detach(), scale=s)
+
+    def _pack_encoder(self, e):
+        P = {"conv1": self._pk(e.conv1, e.norm1), "conv2": self._pk(e.conv2), "blocks": []}
+        for layer in (e.layer1, e.layer2, e.layer3):
+            for rb in layer:
+                P["blocks"].append(dict(c1=self._pk(rb.conv1, rb.norm1), c2=self._pk(rb.conv2, rb.norm2), stride=rb.stride,
+                                        down=None if rb.downsample is None else self._pk(rb.downsample[0], rb.norm3)))
+        return P
+
+    def packed(self):
+        key = tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        if self._packed is None or key != self._key:
+            u = self.update_block
+            P = {"fnet": self._pack_encoder(self.fnet), "cnet": self._pack_encoder(self.cnet)}
+            P["enc"] = {n: self._pk(getattr(u.encoder, n)) for n in ("convc1", "convc2", "convf1", "convf2", "conv")}
+            P["gru"] = {n: self._pk(getattr(u.gru, n)) for n in ("convz1", "convr1", "convq1", "convz2", "convr2", "convq2")}
+            P["fh"] = (self._pk(u.flow_head.conv1), self._pk(u.flow_head.conv2))
+            P["mask"] = (self._pk(u.mask[0]), self._pk(u.mask[2]))
+            self._packed, self._key = P, key
+        return self._packed
+
+    # ------------------------------------------------------------------ encoders
+    def _encode(self, x, P, instance):
+        """BasicEncoder.forward (extractor.py:173-192) on a channels-last batch."""
+        if instance:
+            y = ops.instnorm(ops.conv2d(x, P["conv1"], stride=2, pad=3), act="relu")
+        else:
+            y = ops.conv2d(x, P["conv1"], stride=2, pad=3, act="relu")
+        for b in P["blocks"]:
+            s = b["stride"]
+            if instance:
+                h = ops.instnorm(ops.conv2d(y, b["c1"], stride=s, pad=1), act="relu")
+                sk = y if b["down"] is None else ops.instnorm(ops.conv2d(y, b["down"], stride=s, pad=0))
+                y = ops.instnorm(ops.conv2d(h, b["c2"], stride=1, pad=1), act="relu", res=sk, act2="relu")
+            else:
+                h = ops.conv2d(y, b["c1"], stride=s, pad=1, act="relu")
+                sk = y if b["down"] is None else ops.conv2d(y, b["down"], stride=s, pad=0)
+                y = ops.conv2d(h, b["c2"], stride=1, pad=1, act="relu", epi="add", aux1=sk, act2="relu")
+        return ops.conv2d(y, P["conv2"])
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=False):
+        with torch.no_grad():
+            return self._forward(image1, image2, iters, flow_init, test_mode)
+
+    def _forward(self, image1, image2, iters, flow_init, test_mode):
+        P = self.packed()
+        B, _, H, W = image1.shape
+        if H % 8 or W % 8:
+            raise ValueError("RAFT needs H, W divisible by 8 (use InputPadder as the reference does)")
+        dev = image1.device
+        h8, w8 = H // 8, W // 8
+        # 2 * (x / 255) - 1, packed channels-last with a zero 4th channel (raft.py:90-94)
+        imgs = torch.empty(2 * B, H, W, 4, dtype=torch.float32, device=dev)
+        ops.nchw_to_nhwc(image1.float(), imgs[:B], coff=0, zero_to=4, scale=2.0 / 255.0, shift=-1.0)
+        ops.nchw_to_nhwc(image2.float(), imgs[B:], coff=0, zero_to=4, scale=2.0 / 255.0, shift=-1.0)
+        fmap = self._encode(imgs, P["fnet"], instance=True)                        # [2B, h8, w8, 256]
+        # all-pairs correlation volume (corr.py:52-60) as a GEMM against fmap2, then the avg-pool pyramid
+        n = h8 * w8
+        vol = torch.empty(B * n, n, dtype=torch.float32, device=dev)
+        for b in range(B):
+            pc = PackedConv(fmap[B + b].reshape(n, 256), None)
+            ops.linear(fmap[b].reshape(n, 256), pc, out=vol[b * n:(b + 1) * n], out_scale=1.0 / 16.0)
+        pyr = [vol]
+        hh, ww = h8, w8
+        for _ in range(self.corr_levels - 1):
+            pyr.append(ops.avgpool2(pyr[-1], B * n, hh, ww))
+            hh, ww = hh // 2, ww // 2
+        cmap = self._encode(imgs[:B], P["cnet"], instance=False)                   # [B, h8, w8, 256]
+        net = ops.axpby(cmap.view(B * n, 256)[:, :128], act="tanh")                # raft.py:112-115
+        xbuf = torch.empty(B * n, 256, dtype=torch.float32, device=dev)            # [inp | motion(126) | flow(2)]
+        ops.axpby(cmap.view(B * n, 256)[:, 128:], act="relu", out=xbuf[:, :128])
+        ys, xs = torch.meshgrid(torch.arange(h8, device=dev), torch.arange(w8, device=dev), indexing="ij")
+        coords0 = torch.stack([xs, ys], -1).float().unsqueeze(0).repeat(B, 1, 1, 1).reshape(B * n, 2).contiguous()
+        coords1 = coords0.clone()
+        if flow_init is not None:
+            coords1 = ops.axpby(coords1, 1.0, flow_init.permute(0, 2, 3, 1).reshape(B * n, 2).contiguous().float(), 1.0)
+        flow4 = torch.zeros(B * n, 4, dtype=torch.float32, device=dev)
+        corr = torch.empty(B * n, 324, dtype=torch.float32, device=dev)
+        E, G = P["enc"], P["gru"]
+        m4 = lambda t2: t2.view(B, h8, w8, t2.shape[1]) if t2.is_contiguous() else t2.unflatten(0, (B, h8, w8))
+        ups = []
+        for it in range(iters):
+            ops.corr_lookup(pyr, B, h8, w8, self.corr_radius, coords1, m4(corr))
+            ops.axpby(coords1, 1.0, coords0, -1.0, out=flow4[:, :2])               # flow = coords1 - coords0
+            # BasicMotionEncoder (update.py:62-76)
+            cor = ops.conv2d(m4(corr), E["convc1"], act="relu")
+            cor = ops.conv2d(cor, E["convc2"], pad=1, act="relu")
+            flo = ops.conv2d(m4(flow4), E["convf1"], pad=3, act="relu")
+            flo = ops.conv2d(flo, E["convf2"], pad=1, act="relu")
+            ops.conv2d(cor, E["conv"], x1=flo, pad=1, act="relu", out=m4(xbuf)[..., 128:254])
+            ops.axpby(flow4[:, :2], out=xbuf[:, 254:256])
+            # SepConvGRU (update.py:36-60): horizontal then vertical pass
+            for s, pad in (("1", (0, 2)), ("2", (2, 0))):
+                z = ops.conv2d(m4(net), G["convz" + s], x1=m4(xbuf), pad=pad, act="sigmoid")
+                rh = ops.conv2d(m4(net), G["convr" + s], x1=m4(xbuf), pad=pad, act="sigmoid", epi="mul", aux1=net)
+                net = ops.conv2d(rh, G["convq" + s], x1=m4(xbuf), pad=pad, act="tanh", epi="gru", aux1=z, aux2=net).view(B * n, 128)
+            # FlowHead + coords update (update.py:6-15, raft.py:131-132)
+            d = ops.conv2d(m4(net), P["fh"][0], pad=1, act="relu")
+            new_coords = torch.empty_like(coords1)
+            ops.conv2d(d, P["fh"][1], pad=1, epi="add", aux1=coords1, out=m4(new_coords))
+            coords1 = new_coords
+            if (not test_mode) or it == iters - 1:                                  # only the last mask is consumed in test_mode
+                mk = ops.conv2d(m4(net), P["mask"][0], pad=1, act="relu")
+                mk = ops.conv2d(mk, P["mask"][1], out_scale=0.25)
+                ops.axpby(coords1, 1.0, coords0, -1.0, out=flow4[:, :2])
+                ups.append(ops.convex_upsample(m4(flow4), mk))
+        if test_mode:
+            flow_low = ops.nhwc_to_nchw(m4(ops.axpby(coords1, 1.0, coords0, -1.0)))
+            return flow_low, ups[-1]
+        return ups

@@ -186,9 +186,10 @@ int fgt_instnorm_stats(const float* x, int ld, int N, int HW, int C, double* sta
 int fgt_instnorm_apply(const float* x, int ld, int N, int HW, int C, const double* stats, float eps, int act,
                        const float* res, int ldres, int act2, float* out, int ldo, void* stream);
 
-/* Generic pointwise helper: out = act(a * sa + b * sb) over rows x C slices (b = NULL: single operand). */
+/* Generic pointwise helper: out = act(a * sa + b * sb) over rows x C slices (b = NULL: single operand);
+ * slope is the LeakyReLU slope when act = FGT_ACT_LRELU. */
 int fgt_axpby(const float* a, int lda, float sa, const float* b, int ldb, float sb, long rows, int C, int act,
-              float* out, int ldo, void* stream);
+              float slope, float* out, int ldo, void* stream);
 
 /* tool/video_inpainting.py:725-740 on device: comp = trunc_u8((x+1)/2*255)*m + trunc_u8(frame*255)*(1-m);
  * a frame's first visit stores, later visits average 0.5/0.5 (order dependent: call in ascending window order).

@@ -180,12 +180,57 @@ def pad_tokens(src, bt, h, w, nh, nw, out=None):
     return o
 
 
-def axpby(a, sa=1.0, b=None, sb=1.0, act=None, out=None):
+def axpby(a, sa=1.0, b=None, sb=1.0, act=None, out=None, slope=0.2):
     v = a.reshape(-1, a.shape[-1]) * sa
     if b is not None:
         v = v + b * sb
-    v = _ACT[act](v, 0.2)
+    v = _ACT[act](v, slope)
     if out is not None:
         out.copy_(v)
         return out
     return v
+
+
+# ------------------------------------------------------------------ flow-side kernels (spec)
+def instnorm(x, act=None, res=None, act2=None, eps=1e-5, out=None):
+    x4 = _as_map(x)[0]
+    y = F.instance_norm(x4.permute(0, 3, 1, 2), eps=eps).permute(0, 2, 3, 1)
+    y = _ACT[act](y, 0.2)
+    if res is not None:
+        y = _ACT[act2](y + res.reshape(y.shape), 0.2)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y.contiguous()
+
+
+def avgpool2(src, rows, H, W):
+    return F.avg_pool2d(src.reshape(rows, 1, H, W), 2, stride=2).reshape(rows, H // 2, W // 2)
+
+
+def _sample(img, coords):
+    H, W = img.shape[-2:]
+    xg, yg = coords.split([1, 1], dim=-1)
+    return F.grid_sample(img, torch.cat([2 * xg / (W - 1) - 1, 2 * yg / (H - 1) - 1], dim=-1), align_corners=True)
+
+
+def corr_lookup(pyr, B, H1, W1, radius, coords, out):
+    r = radius
+    c = coords.reshape(B * H1 * W1, 1, 1, 2)
+    d = torch.linspace(-r, r, 2 * r + 1)
+    delta = torch.stack(torch.meshgrid(d, d, indexing="ij"), dim=-1).view(1, 2 * r + 1, 2 * r + 1, 2)
+    res = []
+    for i, lvl in enumerate(pyr):
+        Hl, Wl = H1 >> i, W1 >> i
+        res.append(_sample(lvl.reshape(B * H1 * W1, 1, Hl, Wl), c / 2 ** i + delta).view(B, H1, W1, -1))
+    out.copy_(torch.cat(res, -1))
+    return out
+
+
+def convex_upsample(flow, mask):
+    f4, B, H, W, _, _ = _as_map(flow)
+    fl = f4[..., :2].permute(0, 3, 1, 2)
+    mk = _as_map(mask)[0].permute(0, 3, 1, 2)
+    mk = torch.softmax(mk.reshape(B, 1, 9, 8, 8, H, W), dim=2)
+    up = F.unfold(8 * fl, [3, 3], padding=1).view(B, 2, 9, 1, 1, H, W)
+    return torch.sum(mk * up, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(B, 2, 8 * H, 8 * W)

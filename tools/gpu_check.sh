@@ -17,9 +17,8 @@ tail -3 gpurun_out/bench.log
 if [ "${1:-}" != "quick" ]; then
   echo "== rocprofv3 kernel stats"
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o fgt -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-prof > "$GRAFT_REPO_ROOT/gpurun_out/rocprof.log" 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o fgt -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-prof > "$GRAFT_REPO_ROOT/gpurun_out/rocprof.log" 2>&1)
   echo "rocprof exit: $?"
-  find gpurun_out/prof -name "*stats*" | head
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
-  [ -n "$f" ] && head -25 "$f"
+  [ -n "$f" ] && cut -c1-160 "$f" | head -16
 fi
