@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
 
 
 def fgt_flops(t):
@@ -31,24 +32,36 @@ def fgt_flops(t):
 
 
 def cpu_baseline(cfg, sd, frames, flows, masks, sched):
-    """Oracle (port of the reference CPU path) on a bounded sample: the first window of the schedule (t = 13)."""
+    """Oracle (PyTorch-CPU port of the reference path) on a bounded sample of the same workload: the first 6 frames of
+    window 0 of the schedule, after choosing the intra-op thread count that runs a 2-frame probe fastest (a 256-thread
+    pool on a 256-core host is ~8x slower than 32 threads for these conv sizes)."""
     from oracle import fgt_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
     nb, ref = sched[0]
-    ids = nb + ref
+    ids = (nb + ref)[:6]
     m = masks[:, ids].cpu()
     mf = (frames[:, ids].cpu() * 2 - 1) * (1 - m)
     fl = flows[:, ids].cpu()
-    O.fgt_forward(sd, cfg, mf[:, :2], fl[:, :2], m[:, :2])          # warm-up (threads, allocator)
+    ncpu = os.cpu_count() or 1
+    best, best_dt = 1, None
+    for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(th)
+        O.fgt_forward(sd, cfg, mf[:, :1], fl[:, :1], m[:, :1])
+        t0 = time.perf_counter()
+        O.fgt_forward(sd, cfg, mf[:, :2], fl[:, :2], m[:, :2])
+        dt = time.perf_counter() - t0
+        if best_dt is None or dt < best_dt:
+            best, best_dt = th, dt
+    torch.set_num_threads(best)
     t0 = time.perf_counter()
     O.fgt_forward(sd, cfg, mf, fl, m)
     dt = time.perf_counter() - t0
     total = sum(fgt_flops(len(a) + len(b)) for a, b in sched)
     est_clip_s = dt * total / fgt_flops(len(ids))
-    return {"value": round(frames.shape[1] / est_clip_s, 4), "unit": "frames/s", "cores": torch.get_num_threads(),
+    return {"value": round(frames.shape[1] / est_clip_s, 4), "unit": "frames/s", "cores": best, "host_cores": ncpu,
             "kind": "port",
-            "sample": f"oracle fgt_forward, window 0 (t={len(ids)}) of the 80-frame schedule at 240x432 in {dt:.2f} s; "
-                      f"clip time extrapolated by F(t)=147.03t+1.0618t^2 GFLOP over the 16 windows"}
+            "sample": f"oracle fgt_forward on {len(ids)} frames of window 0 at {frames.shape[-1]}x{frames.shape[-2]} in {dt:.2f} s with {best} threads "
+                      f"(fastest of a 2-frame probe); clip time extrapolated by F(t)=147.03t+1.0618t^2 GFLOP over the "
+                      f"{len(sched)}-window reference schedule ({total / 1e12:.1f} TFLOP)"}
 
 
 def main():
@@ -61,6 +74,9 @@ def main():
     ap.add_argument("--width", type=int, default=432)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event timing of the conv kernel")
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3"],
+                    help="arithmetic of the conv/GEMM kernel: exact fp32 MFMA or hi/lo bf16 split (default: fgt_amd.ops default)")
+    ap.add_argument("--no-cache", action="store_true", help="recompute the per-frame encoders in every window like the reference")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,13 +97,16 @@ def main():
     from fgt_amd.scheduler import ClipRunner
     from fgt_amd.synth import synth_clip, synth_state_dict
 
+    if args.precision:
+        ops.DEFAULT_CONV_PRECISION = args.precision
+    prec = ops.DEFAULT_CONV_PRECISION
     cfg = dict(DEFAULT_CONFIG, input_resolution=(240, 432))
     model = Model(cfg).eval()
     sd = synth_state_dict(model.state_dict(), seed=0)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
     frames, flows, masks = synth_clip(args.frames, args.height, args.width, seed=1234, device=dev)
-    runner = ClipRunner(model, frames, flows, masks, rank=rank, world=world)
+    runner = ClipRunner(model, frames, flows, masks, rank=rank, world=world, cache_features=not args.no_cache)
 
     def barrier():
         torch.cuda.synchronize()
@@ -120,18 +139,24 @@ def main():
             "metric": "inpainted frames/sec at 432x240x80 clip (FGT stage: 16 sliding-window forwards + compose/blend)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if prec == "fp32" else "f32 (conv/GEMM products as 3 bf16 MFMAs on hi/lo splits, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": f"full FGT forward, random (N(0,0.02)) weights, {args.width}x{args.height}x{args.frames} clip, "
                                    f"reference window schedule (neighbor_stride 5, step 10; sum t = {sum(len(a) + len(b) for a, b in runner.sched)})",
-                       "windows": len(runner.sched), "sharding": f"windows round-robin over {world} rank(s)"},
+                       "windows": len(runner.sched), "sharding": f"windows round-robin over {world} rank(s)",
+                       "conv_precision": prec, "per_frame_feature_cache": bool(runner.cache_features)},
         }
         if clip_flops:
             out["effective_tflops"] = round(clip_flops * args.steps / dt / 1e12, 2)
         if not args.no_prof and k_ms > 0:
-            ach = k_flops / (k_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 MFMA implicit-GEMM conv + all Linear layers)",
-                               "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            passes = 1 if prec == "fp32" else 3          # MFMA flops issued per algorithmic flop
+            peak = PEAK_FP32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            ach = passes * k_flops / (k_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": f"conv_igemm_kernel ({prec} implicit-GEMM conv + all Linear layers)",
+                               "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": None,
+                               "algorithmic_tflops": round(k_flops / (k_ms * 1e-3) / 1e12, 2), "mfma_passes_per_product": passes,
                                "launches": k_launches, "kernel_ms_per_step": round(k_ms / args.steps, 3),
                                "share_of_step": round(k_ms / (1e3 * dt), 3)}
         if not args.no_cpu_baseline:

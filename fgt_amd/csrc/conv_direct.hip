@@ -1,0 +1,106 @@
+// Direct convolution for very small output-channel counts (Cout <= 4: FGT decoder.final 64->3, LAFC decoder.2 24->2,
+// edge head 16->1, RAFT flow head 256->2).  An implicit-GEMM tile would waste >90 % of a 32-wide MFMA column block on
+// such layers; here LPP = Cin/4 (rounded up to a power of two) lanes share one output pixel, each lane keeps the
+// weights of its own 4 input channels for every tap in registers, gathers one float4 per tap (a pixel's channels are
+// read by adjacent lanes: fully coalesced) and the Cout partial sums are combined with xor-shuffles.  fp32 VALU FMAs,
+// HBM-bound: bytes = input map once + output.
+#include "common.h"
+#include "conv_params.h"
+
+namespace {
+
+template <int TAPS, int COUT>
+__global__ void __launch_bounds__(256) conv_direct_kernel(const ConvP p, int lpp_log2) {
+    const fgt_conv_desc& d = p.d;
+    const int lpp = 1 << lpp_log2;
+    const int sub = threadIdx.x & (lpp - 1);          // which float4 of the input channels
+    const int c4n = p.Cg >> 2;
+    const bool live = sub < c4n;
+    // this lane's weights: w[tap][co][4]
+    float w[TAPS][COUT][4];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live && co < p.Cout_g) v = *reinterpret_cast<const float4*>(p.w + (long)co * d.Kpad + t * p.Cg + sub * 4);
+            w[t][co][0] = v.x; w[t][co][1] = v.y; w[t][co][2] = v.z; w[t][co][3] = v.w;
+        }
+    const int ppb = 256 >> lpp_log2;                    // pixels per block iteration
+    const int ush = d.upsample ? 1 : 0;
+    for (long m0 = (long)blockIdx.x * ppb; m0 < p.M; m0 += (long)gridDim.x * ppb) {
+        const long m = m0 + (threadIdx.x >> lpp_log2);
+        const bool mval = m < p.M;
+        int n_img = 0, oy = 0, ox = 0;
+        if (mval) {
+            n_img = (int)(m / p.HoWo);
+            const int rem = (int)(m - (long)n_img * p.HoWo);
+            oy = rem / d.Wo; ox = rem - oy * d.Wo;
+        }
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int ky = t / d.kw, kx = t - ky * d.kw;
+            int iy = oy * d.sh - d.ph + ky * d.dh, ix = ox * d.sw - d.pw + kx * d.dw;
+            if (d.pad_mode) { iy = min(max(iy, 0), p.Hin - 1); ix = min(max(ix, 0), p.Win - 1); }
+            const bool ok = live && mval && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            const int ci = sub * 4;
+            const float* src; int ld, ch;
+            if (ci < p.Cg0) { src = p.x0; ld = d.ld0; ch = d.off0 + ci; } else { src = p.x1; ld = d.ld1; ch = d.off1 + ci - p.Cg0; }
+            const long off = ok ? ((long)(n_img * d.H * d.W + (iy >> ush) * d.W + (ix >> ush)) * ld + ch) : 0l;
+            float4 v = *reinterpret_cast<const float4*>(src + off);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+#pragma unroll
+            for (int co = 0; co < COUT; ++co)
+                acc[co] += (v.x * w[t][co][0] + v.y * w[t][co][1]) + (v.z * w[t][co][2] + v.w * w[t][co][3]);
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; ++co)
+            for (int o = lpp >> 1; o > 0; o >>= 1) acc[co] += __shfl_xor(acc[co], o);
+        if (sub == 0 && mval) {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                if (co >= p.Cout_g) break;
+                const float cs = p.cscale ? p.cscale[co] : 1.f, cb = p.cbias ? p.cbias[co] : 0.f;
+                float x = fgt_act(acc[co] * cs + cb, d.act, d.slope) * d.out_scale;
+                if (d.epi == FGT_EPI_MUL) x *= p.aux1[m * d.ld_aux1 + co];
+                else if (d.epi == FGT_EPI_ADD) x = fgt_act(x + p.aux1[m * d.ld_aux1 + co], d.act2, d.slope);
+                else if (d.epi == FGT_EPI_GRU) { const float z = p.aux1[m * d.ld_aux1 + co], hh = p.aux2[m * d.ld_aux2 + co]; x = (1.f - z) * hh + z * x; }
+                if (d.out_nchw) p.out[((long)n_img * d.Cout + co) * p.HoWo + (m - (long)n_img * p.HoWo)] = x;
+                else p.out[m * d.ldo + d.ooff + co] = x;
+            }
+        }
+    }
+}
+
+template <int TAPS, int COUT>
+int launch_direct(const ConvP& p, int lpp_log2, hipStream_t s) {
+    const int ppb = 256 >> lpp_log2;
+    long blocks = (p.M + ppb - 1) / ppb;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((conv_direct_kernel<TAPS, COUT>), dim3((unsigned)blocks), dim3(256), 0, s, p, lpp_log2);
+    return fgt_check_launch("conv_direct");
+}
+
+}  // namespace
+
+bool fgt_conv_direct_eligible(const ConvP& p) {
+    const int taps = p.d.kh * p.d.kw;
+    return p.d.groups == 1 && p.Cout_g <= 4 && (taps == 9 || taps == 1) && p.Cg <= 256 && p.Cg >= 4;
+}
+
+int fgt_conv_direct(const ConvP& p, hipStream_t s) {
+    int lpp_log2 = 0;
+    while ((1 << lpp_log2) < (p.Cg >> 2)) ++lpp_log2;
+    const int taps = p.d.kh * p.d.kw;
+    const int co = p.Cout_g;
+    if (taps == 9) {
+        if (co <= 2) return launch_direct<9, 2>(p, lpp_log2, s);
+        return launch_direct<9, 4>(p, lpp_log2, s);
+    }
+    if (co <= 2) return launch_direct<1, 2>(p, lpp_log2, s);
+    return launch_direct<1, 4>(p, lpp_log2, s);
+}

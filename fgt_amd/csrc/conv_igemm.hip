@@ -10,28 +10,49 @@
 // step's LDS tiles feed the MFMAs; LDS is double buffered with one barrier per step.
 // LDS tiles are [rows][33] floats: both the 4 x ds_write_b32 of a float4 run and the per-lane
 // ds_read_b32 of an MFMA operand (row = lane&31, k = 2*kk + lane>>5) are bank-conflict free.
+//
+// Two arithmetic modes share the loader and the epilogue (desc.precision):
+//   0  fp32      v_mfma_f32_32x32x2_f32 on fp32 LDS tiles ([rows][33] floats) — bit-exact fp32 FMA chains.
+//   1  bf16x3    every fp32 operand is split on the way into LDS into hi = bf16(x) and lo = bf16(x - hi) (RNE, one
+//                v_cvt_pk_bf16_f32 per pair) and each product is issued as three v_mfma_f32_32x32x16_bf16
+//                (lo*hi + hi*lo + hi*hi, fp32 accumulate): ~2^-16 relative error per product at 16/3 = 5.3x the
+//                fp32-MFMA rate.  LDS tiles are [rows][40] bf16 (80-byte rows: conflict-free ds_read_b128 operands).
 #include <vector>
 #include "common.h"
+#include "conv_params.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-struct ConvP {
-    fgt_conv_desc d;
-    const float *x0, *x1, *w, *cscale, *cbias, *aux1, *aux2;
-    float* out;
-    int M, HoWo, Cg0, Cg1, Cg, K, Cout_g, Hin, Win, nk;
-};
 
 constexpr int BK = 32;
 constexpr int LDS_LD = 33;
 
-template <int BM, int BN, int WM, int WN>
+constexpr int LDB = 40;  // bf16 elements per LDS row in bf16x3 mode (32 + 8 pad = 80 bytes)
+
+// hi/lo split of a float4 run: returns packed bf16 {hi0,hi1},{hi2,hi3} and {lo0,lo1},{lo2,lo3}
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+    const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+    const unsigned ha = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));
+    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2));
+    const f32x2 la = {v.x - __builtin_bit_cast(float, ha << 16), v.y - __builtin_bit_cast(float, ha & 0xFFFF0000u)};
+    const f32x2 lb = {v.z - __builtin_bit_cast(float, hb << 16), v.w - __builtin_bit_cast(float, hb & 0xFFFF0000u)};
+    hi = make_uint2(ha, hb);
+    lo = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(la, bf16x2)),
+                    __builtin_bit_cast(unsigned, __builtin_convertvector(lb, bf16x2)));
+}
+
+template <int BM, int BN, int WM, int WN, int PREC>
 __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP p) {
     constexpr int NT = WM * WN * 64;
     constexpr int RPP = NT / 8;  // tile rows covered per pass of the loader
     constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
-    constexpr int STAGE = (BM + BN) * LDS_LD;
+    // stage size in floats: fp32 tiles, or hi+lo bf16 tiles (2 * LDB * 2 bytes = LDB floats per row)
+    constexpr int STAGE = PREC == 0 ? (BM + BN) * LDS_LD : (BM + BN) * LDB;
     static_assert(A_IT >= 1 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile too small for the thread count");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -111,17 +132,39 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
     };
 
     auto store_tiles = [&](int buf) {
-        float* As = smem + buf * STAGE;
-        float* Bs = As + BM * LDS_LD;
+        if constexpr (PREC == 0) {
+            float* As = smem + buf * STAGE;
+            float* Bs = As + BM * LDS_LD;
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            float* dst = As + (r + it * RPP) * LDS_LD + q * 4;
-            dst[0] = va[it].x; dst[1] = va[it].y; dst[2] = va[it].z; dst[3] = va[it].w;
-        }
+            for (int it = 0; it < A_IT; ++it) {
+                float* dst = As + (r + it * RPP) * LDS_LD + q * 4;
+                dst[0] = va[it].x; dst[1] = va[it].y; dst[2] = va[it].z; dst[3] = va[it].w;
+            }
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            float* dst = Bs + (r + it * RPP) * LDS_LD + q * 4;
-            dst[0] = vb[it].x; dst[1] = vb[it].y; dst[2] = vb[it].z; dst[3] = vb[it].w;
+            for (int it = 0; it < B_IT; ++it) {
+                float* dst = Bs + (r + it * RPP) * LDS_LD + q * 4;
+                dst[0] = vb[it].x; dst[1] = vb[it].y; dst[2] = vb[it].z; dst[3] = vb[it].w;
+            }
+        } else {
+            // [A_hi | A_lo | B_hi | B_lo], rows of LDB bf16; this thread's float4 -> 8-byte runs at column q*4
+            __bf16* base = reinterpret_cast<__bf16*>(smem + buf * STAGE);
+            __bf16* Ahi = base; __bf16* Alo = Ahi + BM * LDB; __bf16* Bhi = Alo + BM * LDB; __bf16* Blo = Bhi + BN * LDB;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                uint2 hi, lo;
+                split4(va[it], hi, lo);
+                const int o = (r + it * RPP) * LDB + q * 4;
+                *reinterpret_cast<uint2*>(Ahi + o) = hi;
+                *reinterpret_cast<uint2*>(Alo + o) = lo;
+            }
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) {
+                uint2 hi, lo;
+                split4(vb[it], hi, lo);
+                const int o = (r + it * RPP) * LDB + q * 4;
+                *reinterpret_cast<uint2*>(Bhi + o) = hi;
+                *reinterpret_cast<uint2*>(Blo + o) = lo;
+            }
         }
     };
 
@@ -143,20 +186,50 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
         const int buf = kt & 1;
         const bool more = kt + 1 < p.nk;
         if (more) load_tiles();
-        const float* Ab = smem + buf * STAGE + (wm * WTM + l31) * LDS_LD + lh;
-        const float* Bb = smem + buf * STAGE + BM * LDS_LD + (wn * WTN + l31) * LDS_LD + lh;
+        if constexpr (PREC == 0) {
+            const float* Ab = smem + buf * STAGE + (wm * WTM + l31) * LDS_LD + lh;
+            const float* Bb = smem + buf * STAGE + BM * LDS_LD + (wn * WTN + l31) * LDS_LD + lh;
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[TM], b[TN];
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Ab[i * 32 * LDS_LD + 2 * kk];
+                for (int i = 0; i < TM; ++i) a[i] = Ab[i * 32 * LDS_LD + 2 * kk];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bb[j * 32 * LDS_LD + 2 * kk];
+                for (int j = 0; j < TN; ++j) b[j] = Bb[j * 32 * LDS_LD + 2 * kk];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            const __bf16* base = reinterpret_cast<const __bf16*>(smem + buf * STAGE);
+            const __bf16* Ahi = base + (wm * WTM + l31) * LDB + lh * 8;
+            const __bf16* Alo = Ahi + BM * LDB;
+            const __bf16* Bhi = base + 2 * BM * LDB + (wn * WTN + l31) * LDB + lh * 8;
+            const __bf16* Blo = Bhi + BN * LDB;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8*>(Ahi + i * 32 * LDB + ks * 16);
+                    al[i] = *reinterpret_cast<const bf16x8*>(Alo + i * 32 * LDB + ks * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + j * 32 * LDB + ks * 16);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(Blo + j * 32 * LDB + ks * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
         }
         if (more) store_tiles(buf ^ 1);
         __syncthreads();
@@ -165,10 +238,10 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
     // ---- epilogue.  The accumulators go through LDS (the tile buffers are free now) so that the
     // global side is a compact, coalesced float4 loop shared by every epilogue flavour.
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-    constexpr int EP_PASSES = (BM * BN > 2 * STAGE) ? 2 : 1;
+    constexpr int EP_PASSES = (BM * BN > 2 * STAGE) ? ((BM * BN > 4 * STAGE) ? 4 : 2) : 1;
     constexpr int EP_BM = BM / EP_PASSES;
     constexpr int WM_PER_PASS = WM / EP_PASSES;
-    static_assert(EP_BM * BN <= 2 * STAGE, "epilogue staging does not fit in the tile buffers");
+    static_assert(EP_BM * BN <= 2 * STAGE && WM % EP_PASSES == 0, "epilogue staging does not fit in the tile buffers");
     float* Cs = smem;
     const bool vec_ok = (p.Cout_g % 4 == 0) && !d.out_nchw && (d.ldo % 4 == 0) && (d.ooff % 4 == 0) &&
                         (d.epi == FGT_EPI_NONE || d.ld_aux1 % 4 == 0) && (d.epi != FGT_EPI_GRU || d.ld_aux2 % 4 == 0);
@@ -226,13 +299,13 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int PREC>
 int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
-    constexpr size_t smem = 2ul * (BM + BN) * LDS_LD * sizeof(float);
+    constexpr size_t smem = 2ul * (PREC == 0 ? (BM + BN) * LDS_LD : (BM + BN) * LDB) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, PREC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
             fgt_set_error("hipFuncSetAttribute(conv_igemm %dx%d): %s", BM, BN, hipGetErrorString(e));
@@ -241,8 +314,20 @@ int launch(const ConvP& p, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid(cdiv(p.M, BM), cdiv(p.Cout_g, BN), p.d.groups);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(NT), smem, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, PREC>), grid, dim3(NT), smem, s, p);
     return fgt_check_launch("conv_igemm");
+}
+
+template <int PREC>
+int launch_tile(int tile, const ConvP& p, hipStream_t s) {
+    switch (tile) {
+        case FGT_TILE_128x128: return launch<128, 128, 2, 2, PREC>(p, s);
+        case FGT_TILE_128x64: return launch<128, 64, 2, 2, PREC>(p, s);
+        case FGT_TILE_64x64: return launch<64, 64, 2, 2, PREC>(p, s);
+        case FGT_TILE_128x32: return launch<128, 32, 4, 1, PREC>(p, s);
+        case FGT_TILE_256x128: return launch<256, 128, 4, 2, PREC>(p, s);
+        default: fgt_set_error("fgt_conv2d: unknown tile %d", tile); return FGT_EINVAL;
+    }
 }
 
 // ---- optional per-launch timing (bench roofline block) -------------------------------------------
@@ -320,21 +405,18 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const float* x0, const float*
     }
     hipStream_t s = (hipStream_t)stream;
     ProfRec rec{};
-    if (g_prof_on) {
+    const bool direct = d.tile == 0 && fgt_conv_direct_eligible(p);
+    const bool prof = g_prof_on && !direct;   // the roofline block is about the MFMA kernel only
+    if (prof) {
         rec.a = get_event(); rec.b = get_event();
         rec.flops = 2.0 * (double)M * p.Cout_g * p.K * d.groups;
         hipEventRecord(rec.a, s);
     }
+    FGT_REQUIRE(d.precision == 0 || d.precision == 1, "fgt_conv2d: unknown precision %d", d.precision);
     int rc;
-    switch (tile) {
-        case FGT_TILE_128x128: rc = launch<128, 128, 2, 2>(p, s); break;
-        case FGT_TILE_128x64: rc = launch<128, 64, 2, 2>(p, s); break;
-        case FGT_TILE_64x64: rc = launch<64, 64, 2, 2>(p, s); break;
-        case FGT_TILE_128x32: rc = launch<128, 32, 4, 1>(p, s); break;
-        case FGT_TILE_256x128: rc = launch<256, 128, 4, 2>(p, s); break;
-        default: fgt_set_error("fgt_conv2d: unknown tile %d", tile); return FGT_EINVAL;
-    }
-    if (g_prof_on) {
+    if (direct) rc = fgt_conv_direct(p, s);   // Cout <= 4: VALU direct conv (fp32)
+    else rc = d.precision == 0 ? launch_tile<0>(tile, p, s) : launch_tile<1>(tile, p, s);
+    if (prof) {
         hipEventRecord(rec.b, s);
         g_prof.push_back(rec);
     }

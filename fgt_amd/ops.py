@@ -7,11 +7,15 @@ buffers are ordinary torch views (stride(-1) == 1, pixel stride = stride(-2)), s
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
 from . import _lib
-from ._lib import ACT, EPI, TILE, AttnDesc, ConvDesc, check
+from ._lib import ACT, EPI, PREC, TILE, AttnDesc, ConvDesc, check
+
+# arithmetic mode of fgt_conv2d when the caller does not pass `precision=`: 'fp32' (exact) or 'bf16x3'
+DEFAULT_CONV_PRECISION = os.environ.get("FGT_CONV_PRECISION", "fp32")
 
 
 def _stream():
@@ -85,7 +89,7 @@ class PackedConv:
 
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
-           epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None):
+           epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None):
     """fgt_conv2d.  x (and optional x1) are channels-last maps; returns/outputs a channels-last map (or NCHW)."""
     _require_dev(x, x1, aux1, aux2, out)
     x, N, H, W, C0, ld0 = _as_map(x)
@@ -121,6 +125,7 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     d.ld_aux2 = 0 if aux2 is None else _as_map(aux2)[5]
     d.out_scale = float(out_scale)
     d.Kpad, d.Npad, d.tile = pc.Kpad, pc.Npad, TILE[tile]
+    d.precision = PREC[precision if precision is not None else DEFAULT_CONV_PRECISION]
     check(_lib.lib().fgt_conv2d(C.byref(d), _ptr(x), _ptr(x1), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(aux1),
                                 _ptr(aux2), _ptr(out), _stream()), "fgt_conv2d")
     return out

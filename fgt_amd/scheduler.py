@@ -54,7 +54,7 @@ def compose_torch(out, nb, frames01, masks, comp, visited):
 
 class ClipRunner:
     def __init__(self, model, frames01, flows_normed, masks, neighbor_stride=5, ref_length=10, num_ref=-1,
-                 rank=0, world=1, forward=None, group=None):
+                 rank=0, world=1, forward=None, group=None, cache_features=None, encode_chunk=20):
         self.model = model
         self.frames01, self.flows, self.masks = frames01, flows_normed, masks
         self.n = frames01.shape[1]
@@ -75,6 +75,14 @@ class ClipRunner:
             seen.update(nb)
         self._nb = [torch.tensor(nb, dtype=torch.int32, device=self.dev) for nb, _ in self.sched]
         self.normed = frames01 * 2 - 1                       # tool/video_inpainting.py:697
+        # Exact dedup: the conv encoders / soft split depend only on the frame, yet the reference
+        # recomputes them for every window a frame appears in (275 frame passes for 80 frames).  With the cache each
+        # frame is encoded once per clip pass (frames sharded over ranks + one all-gather), windows only run the
+        # transformer + decoder.  Needs a model exposing encode_frames / transform_decode (fgt_amd.fgt_model.FGT).
+        net = getattr(model, "net", None)
+        can_cache = forward is None and hasattr(net, "encode_frames")
+        self.cache_features = can_cache if cache_features is None else (cache_features and can_cache)
+        self.encode_chunk = encode_chunk
 
     def run_window(self, wi):
         ids = self._ids[wi]
@@ -82,9 +90,53 @@ class ClipRunner:
         mf = self.normed[:, ids] * (1 - m)                   # :721
         return self.forward(mf, self.flows[:, ids], m)[: len(self.sched[wi][0])]
 
+    def encode_clip(self):
+        """Per-frame stages for the whole clip: (enc [N,Hf,Wf,C], tokens [N,n,c], flow tokens [N,n,cf], th, tw)."""
+        net = self.model.net
+        per = (self.n + self.world - 1) // self.world
+        lo, hi = min(self.n, self.rank * per), min(self.n, (self.rank + 1) * per)
+        masked = self.normed * (1 - self.masks)
+        parts, th, tw = [], 0, 0
+        for s0 in range(lo, hi, self.encode_chunk):
+            s1 = min(hi, s0 + self.encode_chunk)
+            enc, tok, ftok, th, tw = net.encode_frames(masked[:, s0:s1], self.flows[:, s0:s1], self.masks[:, s0:s1])
+            k = s1 - s0
+            parts.append(torch.cat([enc.reshape(k, -1), tok.reshape(k, -1), ftok.reshape(k, -1)], 1))
+        if self.world == 1:
+            flat = torch.cat(parts, 0)
+        else:
+            import torch.distributed as dist
+            if not parts:
+                raise RuntimeError("window sharding needs at least one frame per rank")
+            mine = torch.cat(parts, 0)
+            buf = torch.zeros(per, mine.shape[1], dtype=mine.dtype, device=mine.device)
+            buf[: mine.shape[0]] = mine
+            flat = torch.empty(self.world * per, mine.shape[1], dtype=mine.dtype, device=mine.device)
+            dist.all_gather_into_tensor(flat, buf, group=self.group)       # the "boundary feature" all-gather (RCCL / gloo)
+            flat = flat[: self.n]
+        Hf, Wf = self.H // 4, self.W // 4
+        n_tok = th * tw
+        C = net.cfg["cnum"] * 2
+        c, cf = net.cfg["c"], net.cfg["cf"]
+        o1, o2 = Hf * Wf * C, Hf * Wf * C + n_tok * c
+        return flat[:, :o1].reshape(self.n, Hf, Wf, C), flat[:, o1:o2].reshape(self.n, n_tok, c), flat[:, o2:].reshape(self.n, n_tok, cf), th, tw
+
+    def run_window_cached(self, wi, feats):
+        enc, tok, ftok, th, tw = feats
+        ids = self._ids[wi]
+        t = ids.numel()
+        out = self.model.net.transform_decode(enc[ids].contiguous(), tok[ids].reshape(t * th * tw, -1),
+                                              ftok[ids].reshape(t * th * tw, -1), 1, t, th, tw)
+        return out[: len(self.sched[wi][0])]
+
     def run(self):
         """One pass over the clip.  Returns comp [N,H,W,3] fp32 (0..255 scale, before the final astype(uint8))."""
-        outs = {wi: self.run_window(wi) for wi in self.mine}
+        if self.cache_features:
+            with torch.no_grad():
+                feats = self.encode_clip()
+                outs = {wi: self.run_window_cached(wi, feats) for wi in self.mine}
+        else:
+            outs = {wi: self.run_window(wi) for wi in self.mine}
         if self.world > 1:
             outs = self._exchange(outs)
         comp = torch.empty(self.n, self.H, self.W, 3, dtype=torch.float32, device=self.dev)

@@ -23,10 +23,10 @@ def synth_state_dict(template, seed=0, mode="normal"):
         if not torch.is_floating_point(ref):
             out[key] = torch.zeros_like(ref, device="cpu")
             continue
-        g = torch.Generator().manual_seed((zlib.crc32(key.encode()) + 7919 * seed) % (2 ** 31))
+        alias = key.replace("downsample.1.", "norm3.")   # RAFT/extractor.py:41-43: one module under two names
+        g = torch.Generator().manual_seed((zlib.crc32(alias.encode()) + 7919 * seed) % (2 ** 31))
         r = torch.randn(tuple(ref.shape), generator=g, dtype=torch.float32)
-        leaf = key.rsplit(".", 2)
-        is_norm = any(s in key for s in ("norm", "bn")) and ref.dim() == 1
+        is_norm = any(s in alias for s in ("norm", "bn")) and ref.dim() == 1
         if key.endswith("running_var"):
             t = 1.0 + 0.2 * r.abs()
         elif key.endswith("running_mean"):
@@ -39,7 +39,6 @@ def synth_state_dict(template, seed=0, mode="normal"):
         else:
             t = 0.02 * r
         out[key] = t
-        del leaf
     return out
 
 

@@ -80,7 +80,11 @@ typedef struct fgt_conv_desc {
     float out_scale;        /* multiplies the value after act (before epi); 1.0f = off                */
     int Kpad, Npad;         /* packed-weight geometry: w is [groups, Npad, Kpad], k = (ky*kw+kx)*Cg+ci */
     int tile;               /* 0 = auto; otherwise a FGT_TILE_* override (tuning / tests)             */
+    int precision;          /* FGT_PREC_FP32 (exact fp32 MFMA) | FGT_PREC_BF16X3 (hi/lo bf16 split, 3 MFMAs)  */
 } fgt_conv_desc;
+
+#define FGT_PREC_FP32 0
+#define FGT_PREC_BF16X3 1
 
 #define FGT_TILE_128x128 1
 #define FGT_TILE_128x64 2

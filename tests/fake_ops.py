@@ -23,7 +23,7 @@ def _dense_weight(pc):
 
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
-           epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None):
+           epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None):
     x, N, H, W, C0, _ = _as_map(x)
     G = pc.groups
     if x1 is not None:

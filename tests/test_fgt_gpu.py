@@ -92,3 +92,20 @@ def test_outputs_are_fresh_and_inputs_untouched(dev):
     assert torch.equal(o1, o2) and o1.data_ptr() != o2.data_ptr()
     assert all(torch.equal(a, b) for a, b in zip(keep, (mf, fl, ms)))
     assert o1.shape == (2, 3, 48, 64) and o1.device.type == "cuda"
+
+
+def test_fgt_bf16x3_conv_precision_within_fp32_bar(dev, monkeypatch):
+    """Same forward with every conv/GEMM product issued as 3 bf16 MFMAs on hi/lo splits: must still meet the 1e-3 bar
+    (and stay ~1e-5 relative): this is the fast path bench.py can select with --precision bf16x3."""
+    from fgt_amd import ops
+    monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", "bf16x3")
+    g = load_golden("fgt_vanilla_240x432x2.npz")
+    mf, fl, ms = fgt_inputs(240, 432, 2, 14)
+    m, _ = _model(dev)
+    out = m(mf.to(dev), fl.to(dev), ms.to(dev))
+    e, r = report("240x432x2 bf16x3", out, g["out"])
+    assert e < ABS_TOL and r < 2e-3
+    g2 = load_golden("fgt_vanilla_48x80x3.npz")
+    out = m(g2["masked_frames"].to(dev), g2["flows"].to(dev), g2["masks"].to(dev))
+    e, r = report("48x80x3 bf16x3", out, g2["out"])
+    assert e < ABS_TOL and r < 2e-3

@@ -1,0 +1,113 @@
+"""MI355X parity of the flow side: LAFC, RAFT, image_warp / fbConsistencyCheck and the RAFT helper kernels, against
+golden vectors from the reference and the CPU oracle."""
+import argparse
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fgt_amd import lafc_model, raft_model
+from fgt_amd.synth import synth_state_dict
+from oracle import lafc_oracle as LO
+from oracle import raft_oracle as RO
+from util import GOLDEN, load_golden, max_err, rel_err, report
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def _sd(name, mode="kaiming"):
+    keys = json.load(open(os.path.join(GOLDEN, name)))
+    tmpl = {k: torch.empty(v, dtype=torch.long if k.endswith("num_batches_tracked") else torch.float32) for k, v in keys.items()}
+    return synth_state_dict(tmpl, seed=0, mode=mode)
+
+
+@pytest.mark.parametrize("ct", ["vanilla", "gated"])
+def test_lafc_matches_reference_golden(ct, dev):
+    m = lafc_model.Model(dict(lafc_model.DEFAULT_CONFIG, conv_type=ct)).eval()
+    m.load_state_dict(_sd(f"lafc_{ct}_state_keys.json"), strict=True)
+    m = m.to(dev)
+    g = load_golden(f"lafc_{ct}_64x96.npz")
+    flow, edge = m(g["flows"].to(dev), g["masks"].to(dev))
+    e1, r1 = report(f"lafc {ct} flow", flow, g["flow"])
+    e2, r2 = report(f"lafc {ct} edge", edge, g["edge"])
+    assert r1 < 1e-4 and e2 < 1e-4           # fp32 bar 1e-3 absolute; observed ~1e-6
+
+
+def test_lafc_240x432_matches_oracle(dev):
+    """BASELINE config #4 shape: one LAFC call on 3 flows at 240x432."""
+    sd = _sd("lafc_vanilla_state_keys.json")
+    m = lafc_model.Model(dict(lafc_model.DEFAULT_CONFIG)).eval()
+    m.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(7)
+    fl = torch.randn(1, 2, 3, 240, 432, generator=g)
+    ms = (F.interpolate((torch.rand(3, 1, 30, 54, generator=g) > 0.6).float(), size=(240, 432))).view(1, 3, 1, 240, 432).permute(0, 2, 1, 3, 4).contiguous()
+    ref = LO.lafc_forward(sd, lafc_model.DEFAULT_CONFIG, fl * (1 - ms), ms)
+    out = m.to(dev)((fl * (1 - ms)).to(dev), ms.to(dev))
+    assert report("lafc 240x432 flow", out[0], ref[0])[1] < 1e-4 and report("lafc 240x432 edge", out[1], ref[1])[0] < 1e-4
+
+
+def test_raft_matches_reference_golden(dev):
+    m = raft_model.RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).eval()
+    m.load_state_dict(_sd("raft_state_keys.json"), strict=True)
+    m = m.to(dev)
+    g = load_golden("raft_128x160_it6.npz")
+    lo, up = m(g["image1"].to(dev), g["image2"].to(dev), iters=6, test_mode=True)
+    e1, r1 = report("raft flow_low", lo, g["flow_low"])
+    e2, r2 = report("raft flow_up", up, g["flow_up"])
+    assert r1 < 1e-3 and r2 < 1e-3           # 6 GRU iterations amplify fp32 round-off; flows are O(100) px with these weights
+
+
+def test_raft_240x432_two_iterations_matches_oracle(dev):
+    sd = _sd("raft_state_keys.json")
+    m = raft_model.RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).eval()
+    m.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(8)
+    base = F.interpolate(torch.rand(1, 3, 32, 56, generator=g), size=(248, 440), mode="bilinear", align_corners=False) * 255
+    i1, i2 = base[:, :, 4:244, 4:436].contiguous(), base[:, :, 3:243, 6:438].contiguous()
+    ref = RO.raft_forward(sd, i1, i2, iters=2)
+    lo, up = m.to(dev)(i1.to(dev), i2.to(dev), iters=2, test_mode=True)
+    assert report("raft 240x432 low", lo, ref[0])[1] < 1e-3 and report("raft 240x432 up", up, ref[1])[1] < 1e-3
+
+
+def test_warp_and_fb_consistency_match_reference_golden(dev):
+    from fgt_amd import ops
+    g = load_golden("warp_24x40.npz")
+    nhwc = lambda x: x.permute(0, 2, 3, 1).contiguous().to(dev)
+    out = ops.warp(nhwc(g["img"]), nhwc(g["flow"]))
+    assert report("image_warp", out.permute(0, 3, 1, 2), g["warped"])[0] < 1e-5
+    o1, o2 = ops.fb_consistency(nhwc(g["f1"]), nhwc(g["f2"]))
+    mism = ((o1.cpu() != g["occ_fw"][:, 0]).float().mean() + (o2.cpu() != g["occ_bw"][:, 0]).float().mean()).item()
+    print(f"[parity] fb_consistency mismatching pixels fraction: {mism:.2e}")
+    assert mism < 2e-3                       # thresholded output: only pixels within round-off of the threshold may flip
+
+
+def test_raft_helper_kernels(dev):
+    from fgt_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, H1, W1 = 2, 16, 24
+    vol = torch.randn(B * H1 * W1, H1, W1, generator=g)
+    p1 = ops.avgpool2(vol.to(dev), B * H1 * W1, H1, W1)
+    assert max_err(p1, F.avg_pool2d(vol[:, None], 2, stride=2)[:, 0]) < 1e-6
+    pyr = [vol[:, None]]
+    for _ in range(3):
+        pyr.append(F.avg_pool2d(pyr[-1], 2, stride=2))
+    coords = RO.coords_grid(B, H1, W1) + torch.randn(B, 2, H1, W1, generator=g) * 3
+    ref = RO.corr_lookup(pyr, coords)
+    dpyr = [p[:, 0].contiguous().to(dev) for p in pyr]
+    out = torch.empty(B, H1, W1, 324, device=dev)
+    ops.corr_lookup(dpyr, B, H1, W1, 4, coords.permute(0, 2, 3, 1).contiguous().to(dev), out)
+    assert report("corr_lookup", out.permute(0, 3, 1, 2), ref)[0] < 1e-4
+    flow = torch.randn(B, 2, H1, W1, generator=g)
+    mask = torch.randn(B, 576, H1, W1, generator=g)
+    f4 = torch.zeros(B, H1, W1, 4)
+    f4[..., :2] = flow.permute(0, 2, 3, 1)
+    up = ops.convex_upsample(f4.to(dev), mask.permute(0, 2, 3, 1).contiguous().to(dev))
+    assert report("convex_upsample", up, RO.upsample_flow(flow, mask))[0] < 1e-4
+    x = torch.randn(2, 96, 20, 28, generator=g) * 2 + 0.5
+    res = torch.randn(2, 96, 20, 28, generator=g)
+    ref = F.relu(F.relu(F.instance_norm(x)) + res)
+    out = ops.instnorm(x.permute(0, 2, 3, 1).contiguous().to(dev), act="relu", res=res.permute(0, 2, 3, 1).contiguous().to(dev), act2="relu")
+    assert report("instnorm", out.permute(0, 3, 1, 2), ref)[0] < 1e-4

@@ -259,3 +259,54 @@ def test_layout_and_pad(dev):
     assert max_err(back.cpu(), t) == 0
     a, b = _rand(50, 12, seed=5), _rand(50, 12, seed=6)
     assert max_err(ops.axpby(a.to(dev), 2.0, b.to(dev), -0.5, act="tanh").cpu(), torch.tanh(2 * a - 0.5 * b)) < 1e-6
+
+
+DIRECT_CASES = [
+    # name, Cin, Cout, k, act, epi, nchw
+    ("fgt_final_64to3", 64, 3, 3, "tanh", None, True),
+    ("lafc_flow_24to2", 24, 2, 3, None, None, False),
+    ("edge_16to1_1x1", 16, 1, 1, "sigmoid", None, True),
+    ("raft_flowhead_256to2_add", 256, 2, 3, None, "add", False),
+    ("cin4_to4", 4, 4, 3, "lrelu", None, False),
+]
+
+
+@pytest.mark.parametrize("case", DIRECT_CASES, ids=[c[0] for c in DIRECT_CASES])
+def test_conv2d_direct_small_cout(case, dev):
+    """Cout <= 4 layers take the VALU direct-conv kernel when tile='auto'; the MFMA tile path must agree."""
+    from fgt_amd import ops
+    name, Cin, Cout, k, act, epi, nchw_out = case
+    N, H, W = 2, 19, 27
+    x = _rand(N, Cin, H, W, seed=1)
+    w, b = _rand(Cout, Cin, k, k, seed=2, scale=1.0 / math.sqrt(Cin * k * k)), _rand(Cout, seed=3)
+    y = F.conv2d(x, w, b, 1, k // 2)
+    y = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "lrelu": lambda v: F.leaky_relu(v, 0.2), None: lambda v: v}[act](y)
+    aux = _rand(N, H, W, Cout, seed=4) if epi else None
+    if epi:
+        y = y + nchw(aux)
+    pc = ops.PackedConv(w.to(dev), b.to(dev))
+    for tile in ("auto", "128x32"):
+        out = ops.conv2d(nhwc(x).to(dev), pc, stride=1, pad=k // 2, act=act, epi=epi, aux1=None if aux is None else aux.to(dev),
+                         out_nchw=nchw_out, tile=tile)
+        got = out.cpu() if nchw_out else nchw(out.cpu())
+        assert report(f"direct conv {name} tile={tile}", got, y)[1] < 2e-5
+
+
+BF16X3_CASES = [c for c in CONV_CASES if c[0] in ("3x3_s1", "3x3_s2_cin4", "7x7_s3_p3", "1x1_linear", "g4", "3x3_cout_odd")]
+
+
+@pytest.mark.parametrize("case", BF16X3_CASES, ids=[c[0] for c in BF16X3_CASES])
+@pytest.mark.parametrize("tile", ["128x128", "128x64", "64x64", "128x32", "256x128"])
+def test_conv2d_bf16x3_split_precision(case, tile, dev):
+    """hi/lo bf16 split (3 bf16 MFMAs per product, fp32 accumulate): ~2^-16 relative error per product."""
+    from fgt_amd import ops
+    name, N, H, W, Cin, Cout, k, s, p, d, g = case
+    kh, kw = (k, k) if isinstance(k, int) else k
+    x = _rand(N, Cin, H, W, seed=1)
+    w = _rand(Cout, Cin // g, kh, kw, seed=2, scale=1.0 / math.sqrt(Cin // g * kh * kw))
+    b = _rand(Cout, seed=3)
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), s, p, d, g), 0.2).float()
+    pc = ops.PackedConv(w.to(dev), b.to(dev), groups=g)
+    out = ops.conv2d(nhwc(x).to(dev), pc, stride=s, pad=p, dil=d, act="lrelu", tile=tile, precision="bf16x3")
+    e, r = report(f"conv bf16x3 {name} tile={tile}", nchw(out.cpu()), ref)
+    assert r < 5e-5

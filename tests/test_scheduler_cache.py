@@ -1,0 +1,72 @@
+"""Per-frame feature cache + frame-sharded encode (exact dedup of the per-frame stages) on CPU over the kernel spec:
+cached ClipRunner == uncached ClipRunner == oracle clip, single process and 2 gloo ranks."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import fake_ops
+from fgt_amd import fgt_model
+from fgt_amd.fgt_model import DEFAULT_CONFIG, Model
+from fgt_amd.scheduler import ClipRunner
+from fgt_amd.synth import synth_state_dict
+from oracle import fgt_oracle as O
+
+torch.set_grad_enabled(False)
+N, H, W = 12, 32, 48
+
+
+def _setup():
+    fgt_model.ops = fake_ops
+    fgt_model.PackedConv = fake_ops.PackedConv
+    m = Model(dict(DEFAULT_CONFIG)).eval()
+    sd = synth_state_dict(m.state_dict(), seed=0)
+    m.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(0)
+    fr = torch.rand(1, N, 3, H, W, generator=g)
+    ms = (torch.rand(1, N, 1, H, W, generator=g) > 0.6).float()
+    fl = O.norm_flows(torch.randn(1, N, 2, H, W, generator=g))
+    return m, sd, fr, fl, ms
+
+
+def test_cached_equals_uncached_equals_oracle(monkeypatch):
+    real_ops, real_pc = fgt_model.ops, fgt_model.PackedConv
+    try:
+        m, sd, fr, fl, ms = _setup()
+        a = ClipRunner(m, fr, fl, ms, cache_features=False).run()
+        b = ClipRunner(m, fr, fl, ms, cache_features=True, encode_chunk=5).run()
+        ref = O.fgt_clip(sd, DEFAULT_CONFIG, fr, fl, ms)
+        # uint8 truncation makes the composed clip piecewise constant: allow rare +-1 flips from 1e-7 round-off
+        assert (a - ref).abs().max().item() <= 1.0 and ((a - ref).abs() > 0).float().mean().item() < 1e-3
+        assert (b - a).abs().max().item() <= 1.0 and ((b - a).abs() > 0).float().mean().item() < 1e-3
+    finally:
+        fgt_model.ops, fgt_model.PackedConv = real_ops, real_pc
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, sd, fr, fl, ms = _setup()
+    q.put((rank, ClipRunner(m, fr, fl, ms, rank=rank, world=world, cache_features=True).run()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_sharded_encode_and_window_sharding_two_ranks():
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=300) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    real_ops, real_pc = fgt_model.ops, fgt_model.PackedConv
+    try:
+        m, sd, fr, fl, ms = _setup()
+        single = ClipRunner(m, fr, fl, ms, cache_features=True).run()
+    finally:
+        fgt_model.ops, fgt_model.PackedConv = real_ops, real_pc
+    assert torch.equal(res[0], res[1])
+    assert (res[0] - single).abs().max().item() <= 1.0 and ((res[0] - single).abs() > 0).float().mean().item() < 1e-3
