@@ -21,12 +21,12 @@ echo "== bench (default, with cpu baseline)"
 timeout 900 python bench.py --steps 2 --warmup 1 > gpurun_out/bench.log 2>&1; echo "bench exit: $?" | tee -a gpurun_out/bench.log
 tail -3 gpurun_out/bench.log
 echo "== tune_conv"
-timeout 600 python tools/tune_conv.py --t 17 > gpurun_out/tune_conv_fp32.log 2>&1; tail -45 gpurun_out/tune_conv_fp32.log
+timeout 600 python tools/tune_conv.py --t 17 > gpurun_out/tune_conv_fp32.log 2>&1; cp gpurun_out/tune_conv.json gpurun_out/tune_conv_fp32.json; tail -45 gpurun_out/tune_conv_fp32.log
 FGT_CONV_PRECISION=bf16x3 timeout 600 python tools/tune_conv.py --t 17 > gpurun_out/tune_conv_bf16x3.log 2>&1; cp gpurun_out/tune_conv.json gpurun_out/tune_conv_bf16x3.json; tail -45 gpurun_out/tune_conv_bf16x3.log
 if [ "${1:-}" != "quick" ]; then
   echo "== rocprofv3 kernel stats"
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o fgt -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-prof > "$GRAFT_REPO_ROOT/gpurun_out/rocprof.log" 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o fgt -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-prof --precision bf16x3 > "$GRAFT_REPO_ROOT/gpurun_out/rocprof.log" 2>&1)
   echo "rocprof exit: $?"
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cut -c1-160 "$f" | head -16
