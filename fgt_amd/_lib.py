@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
 
 class AttnDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("mode", "b", "t", "h", "w", "nh", "nw", "heads", "group", "ws", "n_global",
-                                       "ldq", "qoff", "ldk", "koff", "ldv", "voff", "ldg_k", "ldg_v", "ldo")]
+                                       "ldq", "qoff", "ldk", "koff", "ldv", "voff", "ldg_k", "ldg_v", "ldo", "precision")]
 
 
 _P = C.c_void_p

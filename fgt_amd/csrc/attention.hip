@@ -44,12 +44,33 @@ __device__ __forceinline__ int local_pix(const AttnP& p, const Prob& pr, int n) 
     }
 }
 
+// Row pointers of the KT keys of a tile (zone / window / global-token addressing), computed by KT threads per tile so
+// that the tile loaders do no integer divisions.
+__device__ __forceinline__ void key_pointers(const AttnP& p, const Prob& pr, int choff, int k0, int tid,
+                                             const float** kptr, const float** vptr) {
+    if (tid < KT) {
+        const fgt_attn_desc& d = p.d;
+        const int key = min(k0 + tid, p.n_k - 1);
+        if (key < p.n_loc) {
+            const long pix = local_pix(p, pr, key);
+            kptr[tid] = p.K + pix * d.ldk + d.koff + choff;
+            vptr[tid] = p.V + pix * d.ldv + d.voff + choff;
+        } else {
+            const long gr = (long)pr.frame0 * d.n_global + (key - p.n_loc);
+            kptr[tid] = p.KG + gr * d.ldg_k + choff;
+            vptr[tid] = p.VG + gr * d.ldg_v + choff;
+        }
+    }
+}
+
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, 2) attn_kernel(const AttnP p) {
     constexpr int NT = NW * 64;
     constexpr int LD_IT = KT * (HD / 4) / NT;  // float4 per thread per tensor per tile
     __shared__ __attribute__((aligned(16))) float Ks[KT * KLD];
     __shared__ __attribute__((aligned(16))) float Vs[KT * HD];
+    __shared__ const float* kptr[KT];
+    __shared__ const float* vptr[KT];
 
     const fgt_attn_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -92,24 +113,14 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_kernel(const AttnP p) {
     float m_run = -INFINITY, l_run = 0.f;
 
     for (int k0 = 0; k0 < p.n_k; k0 += KT) {
-        __syncthreads();  // previous tile fully consumed
+        key_pointers(p, pr, choff, k0, tid, kptr, vptr);
+        __syncthreads();  // previous tile fully consumed, pointer table visible
 #pragma unroll
         for (int it = 0; it < LD_IT; ++it) {
             const int idx = tid + it * NT;
             const int row = idx >> 5, c4 = idx & 31;
-            const int key = min(k0 + row, p.n_k - 1);
-            const float *kp, *vp;
-            if (key < p.n_loc) {
-                const long pix = local_pix(p, pr, key);
-                kp = p.K + pix * d.ldk + d.koff + choff;
-                vp = p.V + pix * d.ldv + d.voff + choff;
-            } else {
-                const long gr = (long)pr.frame0 * d.n_global + (key - p.n_loc);
-                kp = p.KG + gr * d.ldg_k + choff;
-                vp = p.VG + gr * d.ldg_v + choff;
-            }
-            const float4 kv = *reinterpret_cast<const float4*>(kp + c4 * 4);
-            const float4 vv = *reinterpret_cast<const float4*>(vp + c4 * 4);
+            const float4 kv = *reinterpret_cast<const float4*>(kptr[row] + c4 * 4);
+            const float4 vv = *reinterpret_cast<const float4*>(vptr[row] + c4 * 4);
             *reinterpret_cast<float4*>(Ks + row * KLD + c4 * 4) = kv;
             *reinterpret_cast<float4*>(Vs + row * HD + c4 * 4) = vv;
         }
@@ -191,6 +202,207 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_kernel(const AttnP p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// bf16x3 variant: every fp32 operand (Q, K, P, V) is split into hi = bf16(x), lo = bf16(x - hi) and each product is
+// three v_mfma_f32_32x32x16_bf16 (lo*hi + hi*lo + hi*hi, fp32 accumulate) — 5.3x the fp32-MFMA rate at ~2^-16 relative
+// error per product.  Same swapped formulation as above; the k index of the 32x32x16 MFMA is (lane>>5)*8 + j:
+//   QK^T step s (8 per tile): d = 16*s + 8*h + j          -> K tile rows [key][d] (272-byte rows), Q in registers
+//   PV   step ks (2 per tile): key = key(e = 8*ks + j, h)  -> P straight from the S^T accumulator registers 8ks..8ks+7;
+//                                                             V is stored TRANSPOSED [d][pos], pos = (2*ks + h)*8 + j,
+//                                                             so a lane's 8 keys are one 16-byte LDS read.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int KLDB = HD + 8;   // bf16 per K row (272 bytes): conflict-free ds_read_b128 across 16 rows
+constexpr int VLDB = KT + 8;   // bf16 per V^T row (80 bytes)
+
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const f32x2 v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2 l = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xFFFF0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(l, bf16x2));
+}
+
+struct U4 { unsigned x, y, z, w; };
+__device__ __forceinline__ bf16x8 as_bf16x8(unsigned a, unsigned b, unsigned c, unsigned d) {
+    const U4 u = {a, b, c, d};
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 2) attn_bf16x3_kernel(const AttnP p) {
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) __bf16 Khi[KT * KLDB];
+    __shared__ __attribute__((aligned(16))) __bf16 Klo[KT * KLDB];
+    __shared__ __attribute__((aligned(16))) __bf16 Vhi[HD * VLDB];
+    __shared__ __attribute__((aligned(16))) __bf16 Vlo[HD * VLDB];
+    __shared__ const float* kptr[KT];
+    __shared__ const float* vptr[KT];
+
+    const fgt_attn_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    Prob pr;
+    {
+        int y = blockIdx.y;
+        pr.hd = y % d.heads; y /= d.heads;
+        if (d.mode == 0) {
+            pr.zj = y % d.group; y /= d.group;
+            pr.zi = y % d.group; y /= d.group;
+            pr.frame0 = y * d.t;
+        } else {
+            pr.zj = y % p.gw; y /= p.gw;
+            pr.zi = y % p.gh; y /= p.gh;
+            pr.frame0 = y;
+        }
+    }
+    const int choff = pr.hd * HD;
+
+    // ---- Q rows into registers, pre-scaled by log2(e)/sqrt(d) and split: step s holds d = 16s + 8h + (0..7)
+    const int qi = blockIdx.x * (NW * 32) + wave * 32 + l31;
+    const int qpix = local_pix(p, pr, min(qi, p.n_q - 1));
+    bf16x8 qh[8], ql[8];
+    {
+        const float* qp = p.Q + (long)qpix * d.ldq + d.qoff + choff + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(qp + 16 * s);
+            const float4 b = *reinterpret_cast<const float4*>(qp + 16 * s + 4);
+            unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+            const float sc = p.scale_log2e;
+            split2(a.x * sc, a.y * sc, h0, l0); split2(a.z * sc, a.w * sc, h1, l1);
+            split2(b.x * sc, b.y * sc, h2, l2); split2(b.z * sc, b.w * sc, h3, l3);
+            qh[s] = as_bf16x8(h0, h1, h2, h3);
+            ql[s] = as_bf16x8(l0, l1, l2, l3);
+        }
+    }
+
+    f32x16 o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int k0 = 0; k0 < p.n_k; k0 += KT) {
+        key_pointers(p, pr, choff, k0, tid, kptr, vptr);
+        __syncthreads();
+        // ---- K tile: [key][d] rows, split on the way in
+#pragma unroll
+        for (int it = 0; it < KT * (HD / 4) / NT; ++it) {
+            const int idx = tid + it * NT;
+            const int row = idx >> 5, c4 = idx & 31;
+            const float4 kv = *reinterpret_cast<const float4*>(kptr[row] + c4 * 4);
+            unsigned h0, h1, l0, l1;
+            split2(kv.x, kv.y, h0, l0); split2(kv.z, kv.w, h1, l1);
+            *reinterpret_cast<uint2*>(Khi + row * KLDB + c4 * 4) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(Klo + row * KLDB + c4 * 4) = make_uint2(l0, l1);
+        }
+        // ---- V tile transposed: item = (d, position group g = 2*ks + h); its 8 keys are key(8ks + j, h)
+#pragma unroll
+        for (int it = 0; it < HD * 4 / NT; ++it) {
+            const int idx = tid + it * NT;
+            const int dd = idx & (HD - 1), g = idx >> 7;        // HD == 128
+            const int kbase = 16 * (g >> 1) + 4 * (g & 1);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = vptr[kbase + (j & 3) + 8 * (j >> 2)][dd];
+            unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+            split2(v[0], v[1], h0, l0); split2(v[2], v[3], h1, l1); split2(v[4], v[5], h2, l2); split2(v[6], v[7], h3, l3);
+            *reinterpret_cast<uint4*>(Vhi + dd * VLDB + g * 8) = make_uint4(h0, h1, h2, h3);
+            *reinterpret_cast<uint4*>(Vlo + dd * VLDB + g * 8) = make_uint4(l0, l1, l2, l3);
+        }
+        __syncthreads();
+
+        // ---- S^T tile = K . Q^T  (already in log2 units: Q carries the scale)
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        {
+            const __bf16* kh = Khi + l31 * KLDB + 8 * lh;
+            const __bf16* kl = Klo + l31 * KLDB + 8 * lh;
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(kh + 16 * st);
+                const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(kl + 16 * st);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, qh[st], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, ql[st], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, qh[st], s, 0, 0, 0);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const float v = key < p.n_k ? s[e] : -INFINITY;
+            s[e] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float pe = exp2f(s[e] - m_new);
+            s[e] = pe;
+            psum += pe;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
+        // ---- O^T += V^T . P^T : P split from the accumulator registers (keys 8ks..8ks+7 of this lane half)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+            split2(s[8 * ks + 0], s[8 * ks + 1], h0, l0); split2(s[8 * ks + 2], s[8 * ks + 3], h1, l1);
+            split2(s[8 * ks + 4], s[8 * ks + 5], h2, l2); split2(s[8 * ks + 6], s[8 * ks + 7], h3, l3);
+            const bf16x8 p_h = as_bf16x8(h0, h1, h2, h3), p_l = as_bf16x8(l0, l1, l2, l3);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int off = (t * 32 + l31) * VLDB + (2 * ks + lh) * 8;
+                const bf16x8 v_h = *reinterpret_cast<const bf16x8*>(Vhi + off);
+                const bf16x8 v_l = *reinterpret_cast<const bf16x8*>(Vlo + off);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_l, p_h, o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h, p_l, o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h, p_h, o[t], 0, 0, 0);
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_tot;
+    if (qi < p.n_q) {
+        long orow;
+        bool keep = true;
+        if (d.mode == 0) {
+            orow = qpix;
+        } else {
+            const int fr = qpix / (d.nh * d.nw), rem = qpix - fr * (d.nh * d.nw);
+            const int y = rem / d.nw, x = rem - y * d.nw;
+            keep = y < d.h && x < d.w;
+            orow = ((long)fr * d.h + y) * d.w + x;
+        }
+        if (keep) {
+            float* op = p.O + orow * d.ldo + choff + 4 * lh;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const float4 v = make_float4(o[t][4 * e4 + 0] * inv, o[t][4 * e4 + 1] * inv,
+                                                 o[t][4 * e4 + 2] * inv, o[t][4 * e4 + 3] * inv);
+                    *reinterpret_cast<float4*>(op + t * 32 + 8 * e4) = v;
+                }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int fgt_attention(const fgt_attn_desc* dd, const float* Q, const float* K, const float* V,
@@ -226,12 +438,15 @@ extern "C" int fgt_attention(const fgt_attn_desc* dd, const float* Q, const floa
     }
     FGT_REQUIRE(problems <= 65535, "fgt_attention: too many problems (%d) for grid.y", problems);
     hipStream_t s = (hipStream_t)stream;
+    FGT_REQUIRE(d.precision == 0 || d.precision == 1, "fgt_attention: unknown precision %d", d.precision);
     if (p.n_q <= 64) {
         dim3 grid(cdiv(p.n_q, 64), problems);
-        hipLaunchKernelGGL((attn_kernel<2>), grid, dim3(128), 0, s, p);
+        if (d.precision == 0) hipLaunchKernelGGL((attn_kernel<2>), grid, dim3(128), 0, s, p);
+        else hipLaunchKernelGGL((attn_bf16x3_kernel<2>), grid, dim3(128), 0, s, p);
     } else {
         dim3 grid(cdiv(p.n_q, 128), problems);
-        hipLaunchKernelGGL((attn_kernel<4>), grid, dim3(256), 0, s, p);
+        if (d.precision == 0) hipLaunchKernelGGL((attn_kernel<4>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((attn_bf16x3_kernel<4>), grid, dim3(256), 0, s, p);
     }
     return fgt_check_launch("attn_kernel");
 }

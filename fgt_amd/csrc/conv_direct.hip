@@ -85,6 +85,84 @@ int launch_direct(const ConvP& p, int lpp_log2, hipStream_t s) {
     return fgt_check_launch("conv_direct");
 }
 
+
+// ---- LDS-tiled variant for 3x3 / stride 1 / pad 1 layers whose input map is large (FGT decoder.final: 64 -> 3 at full
+// resolution, RAFT flow head 256 -> 2).  A 256-thread block owns an 8 x 32 output tile; the 10 x 34 input halo tile is
+// staged through LDS 16 channels at a time ([pixel][16 + 4 pad] floats: conflict-free float4 reads), every thread
+// accumulates its pixel's COUT outputs with weights fetched through the scalar cache (uniform addresses).
+// Input bytes are read from HBM/L2 once per tile (halo overhead 1.33x) instead of 9x.
+constexpr int TH = 8, TW = 32, CCH = 16, PLD = CCH + 4;
+
+template <int COUT>
+__global__ void __launch_bounds__(256) conv3x3_tiled_kernel(const ConvP p) {
+    __shared__ __attribute__((aligned(16))) float tile[(TH + 2) * (TW + 2) * PLD];
+    const fgt_conv_desc& d = p.d;
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, n_img = blockIdx.z;
+    const float* __restrict__ wgt = p.w;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+    for (int c0 = 0; c0 < p.Cg; c0 += CCH) {
+        __syncthreads();
+        for (int idx = tid; idx < (TH + 2) * (TW + 2) * (CCH / 4); idx += 256) {
+            const int pix = idx >> 2, c4 = idx & 3;
+            const int py = pix / (TW + 2), px = pix - py * (TW + 2);
+            const int gy = y0 + py - 1, gx = x0 + px - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gy < (unsigned)d.H && (unsigned)gx < (unsigned)d.W) {
+                const int ci = c0 + c4 * 4;
+                const float* src; int ld, ch;
+                if (ci < p.Cg0) { src = p.x0; ld = d.ld0; ch = d.off0 + ci; } else { src = p.x1; ld = d.ld1; ch = d.off1 + ci - p.Cg0; }
+                v = *reinterpret_cast<const float4*>(src + ((long)(n_img * d.H + gy) * d.W + gx) * ld + ch);
+                if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            *reinterpret_cast<float4*>(tile + pix * PLD + c4 * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float* tp = tile + ((ty + t / 3) * (TW + 2) + tx + t % 3) * PLD;
+#pragma unroll
+            for (int c4 = 0; c4 < CCH / 4; ++c4) {
+                const float4 v = *reinterpret_cast<const float4*>(tp + c4 * 4);
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    const float* w = wgt + (long)co * d.Kpad + t * p.Cg + c0 + c4 * 4;   // wave-uniform -> scalar loads
+                    acc[co] = fmaf(v.x, w[0], fmaf(v.y, w[1], fmaf(v.z, w[2], fmaf(v.w, w[3], acc[co]))));
+                }
+            }
+        }
+    }
+    const int oy = y0 + ty, ox = x0 + tx;
+    if (oy < d.H && ox < d.W) {
+        const long m = ((long)n_img * d.H + oy) * d.W + ox;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float cs = p.cscale ? p.cscale[co] : 1.f, cb = p.cbias ? p.cbias[co] : 0.f;
+            float x = fgt_act(acc[co] * cs + cb, d.act, d.slope) * d.out_scale;
+            if (d.epi == FGT_EPI_MUL) x *= p.aux1[m * d.ld_aux1 + co];
+            else if (d.epi == FGT_EPI_ADD) x = fgt_act(x + p.aux1[m * d.ld_aux1 + co], d.act2, d.slope);
+            else if (d.epi == FGT_EPI_GRU) { const float z = p.aux1[m * d.ld_aux1 + co], hh = p.aux2[m * d.ld_aux2 + co]; x = (1.f - z) * hh + z * x; }
+            if (d.out_nchw) p.out[((long)n_img * d.Cout + co) * p.HoWo + (long)oy * d.W + ox] = x;
+            else p.out[m * d.ldo + d.ooff + co] = x;
+        }
+    }
+}
+
+template <int COUT>
+int launch_tiled(const ConvP& p, hipStream_t s) {
+    dim3 grid(cdiv(p.d.W, TW), cdiv(p.d.H, TH), p.d.N);
+    hipLaunchKernelGGL((conv3x3_tiled_kernel<COUT>), grid, dim3(256), 0, s, p);
+    return fgt_check_launch("conv3x3_tiled");
+}
+
+bool tiled_eligible(const ConvP& p) {
+    const fgt_conv_desc& d = p.d;
+    return d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.dh == 1 && d.dw == 1 && d.ph == 1 && d.pw == 1 && !d.upsample &&
+           d.pad_mode == 0 && p.Cg % CCH == 0 && d.N <= 65535 && d.H >= TH && d.W >= TW;
+}
+
 }  // namespace
 
 bool fgt_conv_direct_eligible(const ConvP& p) {
@@ -97,6 +175,14 @@ int fgt_conv_direct(const ConvP& p, hipStream_t s) {
     while ((1 << lpp_log2) < (p.Cg >> 2)) ++lpp_log2;
     const int taps = p.d.kh * p.d.kw;
     const int co = p.Cout_g;
+    if (tiled_eligible(p)) {
+        switch (co) {
+            case 1: return launch_tiled<1>(p, s);
+            case 2: return launch_tiled<2>(p, s);
+            case 3: return launch_tiled<3>(p, s);
+            default: return launch_tiled<4>(p, s);
+        }
+    }
     if (taps == 9) {
         if (co <= 2) return launch_direct<9, 2>(p, lpp_log2, s);
         return launch_direct<9, 4>(p, lpp_log2, s);

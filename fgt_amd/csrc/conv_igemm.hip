@@ -394,13 +394,12 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const float* x0, const float*
 
     int tile = d.tile;
     if (tile == 0) {
+        // static fallback (profiles/r01_run2_tune_conv_*.txt); fgt_amd.ops autotunes per shape on first use
         if (p.Cout_g <= 32) tile = FGT_TILE_128x32;
-        else if (p.Cout_g <= 64) tile = FGT_TILE_128x64;
+        else if (p.Cout_g <= 64) tile = FGT_TILE_64x64;
         else {
             const long blocks128 = (long)cdiv(M, 128) * cdiv(p.Cout_g, 128) * d.groups;
-            if (blocks128 >= 384) tile = FGT_TILE_128x128;
-            else if (blocks128 * 2 >= 256) tile = FGT_TILE_128x64;
-            else tile = FGT_TILE_64x64;
+            tile = blocks128 >= (d.precision == 0 ? 1024 : 512) ? FGT_TILE_128x128 : FGT_TILE_64x64;
         }
     }
     hipStream_t s = (hipStream_t)stream;

@@ -16,6 +16,18 @@ from ._lib import ACT, EPI, PREC, TILE, AttnDesc, ConvDesc, check
 
 # arithmetic mode of fgt_conv2d when the caller does not pass `precision=`: 'fp32' (exact) or 'bf16x3'
 DEFAULT_CONV_PRECISION = os.environ.get("FGT_CONV_PRECISION", "fp32")
+DEFAULT_ATTN_PRECISION = os.environ.get("FGT_ATTN_PRECISION", "fp32")
+
+# Per-shape tile autotuning of fgt_conv2d: the first call of a new (shape, precision) times every tile candidate with HIP
+# events and caches the fastest.  Tiles only change the work decomposition: results are bit-identical across tiles
+# (the k order of every accumulation is the same), so tuning never changes numerics.
+AUTOTUNE = os.environ.get("FGT_AUTOTUNE", "1") != "0"
+TILE_CANDIDATES = ("128x128", "64x64", "128x64", "256x128", "128x32")
+_tile_cache = {}
+
+
+def tuning_table():
+    return {repr(k): v for k, v in _tile_cache.items()}
 
 
 def _stream():
@@ -126,9 +138,36 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     d.out_scale = float(out_scale)
     d.Kpad, d.Npad, d.tile = pc.Kpad, pc.Npad, TILE[tile]
     d.precision = PREC[precision if precision is not None else DEFAULT_CONV_PRECISION]
-    check(_lib.lib().fgt_conv2d(C.byref(d), _ptr(x), _ptr(x1), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(aux1),
-                                _ptr(aux2), _ptr(out), _stream()), "fgt_conv2d")
+    args = (C.byref(d), _ptr(x), _ptr(x1), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(aux1), _ptr(aux2), _ptr(out))
+    if d.tile == 0 and AUTOTUNE and pc.Cout // pc.groups > 4:
+        key = (N, H, W, C0, C1, pc.Cout, pc.groups, pc.kh, pc.kw, sh, sw, ph, pw, dh, dw, d.upsample, d.epi, d.out_nchw, d.precision)
+        best = _tile_cache.get(key)
+        if best is None:
+            best = _tile_cache[key] = _autotune(d, args)
+        d.tile = best
+    check(_lib.lib().fgt_conv2d(*args, _stream()), "fgt_conv2d")
     return out
+
+
+def _autotune(d, args):
+    """Time each tile candidate on the current stream (1 warm + 2 timed launches) and return the fastest tile code."""
+    fn, st = _lib.lib().fgt_conv2d, _stream()
+    best, best_ms = 0, None
+    for name in TILE_CANDIDATES:
+        d.tile = TILE[name]
+        if fn(*args, st) != 0:
+            continue
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(*args, st)
+        fn(*args, st)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        if best_ms is None or ms < best_ms:
+            best, best_ms = TILE[name], ms
+    d.tile = 0
+    return best
 
 
 def linear(x, pc, **kw):
@@ -158,7 +197,7 @@ def layernorm(x0, gA, bA, x1=None, gB=None, bB=None, outA=None, outB=None, eps=1
     return (outA, outB) if gB is not None else outA
 
 
-def attention_temporal(qkv, b, t, nh, nw, heads, group, c):
+def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None):
     """Temporal zone attention reading q/k/v in place from a fused [b*t*nh*nw, 3c] projection buffer."""
     _require_dev(qkv)
     out = torch.empty(b * t * nh * nw, c, dtype=torch.float32, device=qkv.device)
@@ -169,12 +208,13 @@ def attention_temporal(qkv, b, t, nh, nw, heads, group, c):
     d.qoff, d.koff, d.voff = 0, c, 2 * c
     d.ldg_k = d.ldg_v = 0
     d.ldo = c
+    d.precision = PREC[precision if precision is not None else DEFAULT_ATTN_PRECISION]
     check(_lib.lib().fgt_attention(C.byref(d), _ptr(qkv), _ptr(qkv), _ptr(qkv), None, None, _ptr(out), _stream()),
           "fgt_attention(temporal)")
     return out
 
 
-def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global):
+def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, precision=None):
     """Window attention + shared global tokens; q/k/v are [bt*nh*nw, c] maps on the padded grid, output cropped."""
     _require_dev(q, k, v, kg, vg)
     c = q.shape[1]
@@ -186,6 +226,7 @@ def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global):
     d.qoff = d.koff = d.voff = 0
     d.ldg_k, d.ldg_v = kg.stride(0), vg.stride(0)
     d.ldo = c
+    d.precision = PREC[precision if precision is not None else DEFAULT_ATTN_PRECISION]
     check(_lib.lib().fgt_attention(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(kg), _ptr(vg), _ptr(out), _stream()),
           "fgt_attention(spatial)")
     return out

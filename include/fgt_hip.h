@@ -123,6 +123,7 @@ typedef struct fgt_attn_desc {
     int group;              /* mode 0: zones per side                                                 */
     int ws, n_global;       /* mode 1                                                                 */
     int ldq, qoff, ldk, koff, ldv, voff, ldg_k, ldg_v, ldo;
+    int precision;          /* FGT_PREC_FP32 | FGT_PREC_BF16X3 (Q, K, P, V split into hi/lo bf16, 3 MFMAs per product) */
 } fgt_attn_desc;
 
 int fgt_attention(const fgt_attn_desc* d, const float* Q, const float* K, const float* V,

@@ -100,7 +100,7 @@ def _sdpa(q, k, v):
     return torch.matmul(F.softmax(s, dim=-1), v)
 
 
-def attention_temporal(qkv, b, t, nh, nw, heads, group, c):
+def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None):
     zh, zw, d = nh // group, nw // group, c // heads
 
     def zones(y):
@@ -110,7 +110,7 @@ def attention_temporal(qkv, b, t, nh, nw, heads, group, c):
     return a.view(b, group, group, heads, t, zh, zw, d).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(b * t * nh * nw, c)
 
 
-def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global):
+def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, precision=None):
     c = q.shape[1]
     gh, gw, d = nh // ws, nw // ws, c // heads
 

@@ -31,7 +31,7 @@ def test_library_exports_every_symbol():
 def test_struct_sizes_match_header():
     # 38 ints/floats in fgt_conv_desc, 20 ints in fgt_attn_desc (4 bytes each, no padding)
     assert ctypes.sizeof(_lib.ConvDesc) == 38 * 4
-    assert ctypes.sizeof(_lib.AttnDesc) == 20 * 4
+    assert ctypes.sizeof(_lib.AttnDesc) == 21 * 4
 
 
 def test_rejects_bad_arguments_without_gpu():

@@ -99,6 +99,7 @@ def test_fgt_bf16x3_conv_precision_within_fp32_bar(dev, monkeypatch):
     (and stay ~1e-5 relative): this is the fast path bench.py can select with --precision bf16x3."""
     from fgt_amd import ops
     monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", "bf16x3")
+    monkeypatch.setattr(ops, "DEFAULT_ATTN_PRECISION", "bf16x3")
     g = load_golden("fgt_vanilla_240x432x2.npz")
     mf, fl, ms = fgt_inputs(240, 432, 2, 14)
     m, _ = _model(dev)

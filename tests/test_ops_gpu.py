@@ -310,3 +310,84 @@ def test_conv2d_bf16x3_split_precision(case, tile, dev):
     out = ops.conv2d(nhwc(x).to(dev), pc, stride=s, pad=p, dil=d, act="lrelu", tile=tile, precision="bf16x3")
     e, r = report(f"conv bf16x3 {name} tile={tile}", nchw(out.cpu()), ref)
     assert r < 5e-5
+
+
+@pytest.mark.parametrize("b,t,nh,nw", [(1, 3, 20, 36), (2, 2, 6, 8), (1, 5, 22, 36)])
+def test_attention_temporal_bf16x3(b, t, nh, nw, dev):
+    """Same contract as test_attention_temporal with Q/K/P/V split into hi/lo bf16 (3 bf16 MFMAs per product)."""
+    from fgt_amd import ops
+    heads, G, c = 4, 2, 512
+    qkv = _rand(b * t * nh * nw, 3 * c, seed=nh)
+    qkv[:, :2 * c] *= 2
+    zh, zw = nh // G, nw // G
+
+    def zones(y):
+        return y.view(b, t, G, zh, G, zw, heads, c // heads).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, G * G, heads, -1, c // heads)
+
+    a = _sdpa(zones(qkv[:, :c].double()), zones(qkv[:, c:2 * c].double()), zones(qkv[:, 2 * c:].double())).float()
+    ref = a.view(b, G, G, heads, t, zh, zw, c // heads).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(b * t * nh * nw, c)
+    out = ops.attention_temporal(qkv.to(dev), b, t, nh, nw, heads, G, c, precision="bf16x3")
+    assert report(f"attn temporal bf16x3 b{b} t{t} {nh}x{nw}", out.cpu(), ref)[1] < 1e-4
+
+
+@pytest.mark.parametrize("bt,h,w", [(2, 20, 36), (1, 22, 35)])
+def test_attention_spatial_bf16x3(bt, h, w, dev):
+    from fgt_amd import ops
+    heads, ws, gd, c = 4, 8, 4, 512
+    nh, nw = (h + ws - 1) // ws * ws, (w + ws - 1) // ws * ws
+    gh, gw = nh // ws, nw // ws
+    ng = (nh // gd) * (nw // gd)
+    q, k, v = (_rand(bt * nh * nw, c, seed=s) for s in (1, 2, 3))
+    kg, vg = _rand(bt * ng, c, seed=4), _rand(bt * ng, c, seed=5)
+
+    def windows(y):
+        return y.view(bt, gh, ws, gw, ws, c).transpose(2, 3).reshape(bt, gh * gw, ws * ws, c)
+
+    def split(y):
+        return y.reshape(bt, gh * gw, -1, heads, c // heads).permute(0, 1, 3, 2, 4)
+
+    K = torch.cat([windows(k), kg.view(bt, 1, ng, c).expand(-1, gh * gw, -1, -1)], 2)
+    V = torch.cat([windows(v), vg.view(bt, 1, ng, c).expand(-1, gh * gw, -1, -1)], 2)
+    a = _sdpa(split(windows(q)).double(), split(K).double(), split(V).double()).float()
+    a = a.transpose(2, 3).reshape(bt, gh, gw, ws, ws, c).transpose(2, 3).reshape(bt, nh, nw, c)[:, :h, :w].reshape(bt * h * w, c)
+    out = ops.attention_spatial(q.to(dev), k.to(dev), v.to(dev), kg.to(dev), vg.to(dev), bt, h, w, nh, nw, heads, ws, ng,
+                                precision="bf16x3")
+    assert report(f"attn spatial bf16x3 bt{bt} {h}x{w}", out.cpu(), a)[1] < 1e-4
+
+
+def test_attention_bf16x3_forced_rescale(dev):
+    from fgt_amd import ops
+    b, t, nh, nw, heads, G, c = 1, 4, 8, 8, 4, 2, 512
+    qkv = _rand(b * t * nh * nw, 3 * c, seed=9) * 0.3
+    qkv[-1, c:2 * c] = qkv[5, :c] * 40.0
+    zh, zw = nh // G, nw // G
+
+    def zones(y):
+        return y.view(b, t, G, zh, G, zw, heads, c // heads).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, G * G, heads, -1, c // heads)
+
+    a = _sdpa(zones(qkv[:, :c].double()), zones(qkv[:, c:2 * c].double()), zones(qkv[:, 2 * c:].double())).float()
+    ref = a.view(b, G, G, heads, t, zh, zw, c // heads).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(-1, c)
+    out = ops.attention_temporal(qkv.to(dev), b, t, nh, nw, heads, G, c, precision="bf16x3")
+    assert report("attn bf16x3 forced rescale", out.cpu(), ref)[1] < 1e-4
+
+
+@pytest.mark.parametrize("Cin,Cout,act,epi,nchw_out,two_src", [(64, 3, "tanh", None, True, False), (256, 2, None, "add", False, False),
+                                                                (48, 1, "sigmoid", None, False, True), (16, 4, "lrelu", None, False, False)])
+def test_conv3x3_lds_tiled_small_cout(Cin, Cout, act, epi, nchw_out, two_src, dev):
+    """3x3/s1/p1, Cout <= 4, Cin % 16 == 0 and a map of at least 8 x 32: the LDS-tiled direct kernel (partial edge tiles)."""
+    from fgt_amd import ops
+    N, H, W = 2, 21, 45
+    x = _rand(N, Cin, H, W, seed=1)
+    w, b = _rand(Cout, Cin, 3, 3, seed=2, scale=1.0 / math.sqrt(Cin * 9)), _rand(Cout, seed=3)
+    y = F.conv2d(x, w, b, 1, 1)
+    y = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "lrelu": lambda v: F.leaky_relu(v, 0.2), None: lambda v: v}[act](y)
+    aux = _rand(N, H, W, Cout, seed=4) if epi else None
+    if epi:
+        y = y + nchw(aux)
+    pc = ops.PackedConv(w.to(dev), b.to(dev))
+    xh = nhwc(x).to(dev)
+    kw = dict(x1=xh[..., 32:].contiguous()) if two_src else {}
+    x0 = xh[..., :32].contiguous() if two_src else xh
+    out = ops.conv2d(x0, pc, stride=1, pad=1, act=act, epi=epi, aux1=None if aux is None else aux.to(dev), out_nchw=nchw_out, **kw)
+    got = out.cpu() if nchw_out else nchw(out.cpu())
+    assert report(f"tiled 3x3 {Cin}->{Cout}", got, y)[1] < 2e-5

@@ -12,7 +12,7 @@ echo "== smoke"
 timeout 300 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit: $?" | tee -a gpurun_out/smoke.log
 tail -2 gpurun_out/smoke.log
 echo "== bench (variants)"
-for v in "--precision fp32 --no-cache" "--precision fp32" "--precision bf16x3 --no-cache" "--precision bf16x3"; do
+for v in "--precision fp32 --no-cache" "--precision bf16x3"; do
   tag=$(echo "$v" | tr -d ' -')
   timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline $v > gpurun_out/bench_$tag.log 2>&1; echo "bench $v exit: $?"
   grep '^{' gpurun_out/bench_$tag.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'],'fps', d['ms_per_step'],'ms', d.get('roofline'))"
@@ -21,8 +21,7 @@ echo "== bench (default, with cpu baseline)"
 timeout 900 python bench.py --steps 2 --warmup 1 > gpurun_out/bench.log 2>&1; echo "bench exit: $?" | tee -a gpurun_out/bench.log
 tail -3 gpurun_out/bench.log
 echo "== tune_conv"
-timeout 600 python tools/tune_conv.py --t 17 > gpurun_out/tune_conv_fp32.log 2>&1; cp gpurun_out/tune_conv.json gpurun_out/tune_conv_fp32.json; tail -45 gpurun_out/tune_conv_fp32.log
-FGT_CONV_PRECISION=bf16x3 timeout 600 python tools/tune_conv.py --t 17 > gpurun_out/tune_conv_bf16x3.log 2>&1; cp gpurun_out/tune_conv.json gpurun_out/tune_conv_bf16x3.json; tail -45 gpurun_out/tune_conv_bf16x3.log
+FGT_CONV_PRECISION=bf16x3 timeout 600 python tools/tune_conv.py --t 17 > gpurun_out/tune_conv_bf16x3.log 2>&1; cp gpurun_out/tune_conv.json gpurun_out/tune_conv_bf16x3.json; tail -40 gpurun_out/tune_conv_bf16x3.log
 if [ "${1:-}" != "quick" ]; then
   echo "== rocprofv3 kernel stats"
   rm -rf gpurun_out/prof
