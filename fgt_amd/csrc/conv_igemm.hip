@@ -17,6 +17,7 @@
 //                v_cvt_pk_bf16_f32 per pair) and each product is issued as three v_mfma_f32_32x32x16_bf16
 //                (lo*hi + hi*lo + hi*hi, fp32 accumulate): ~2^-16 relative error per product at 16/3 = 5.3x the
 //                fp32-MFMA rate.  LDS tiles are [rows][40] bf16 (80-byte rows: conflict-free ds_read_b128 operands).
+#include <stdlib.h>
 #include <vector>
 #include "common.h"
 #include "conv_params.h"
@@ -24,6 +25,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -84,6 +86,11 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
     int ci = k_cur - tap * p.Cg;
     int ky = tap / d.kw, kx = tap - ky * d.kw;
 
+    // Out-of-range gathers read a zero page instead of being predicated: the select is on the ADDRESS, never on the
+    // loaded value, so the tile fetch is straight-line code and the loads of a K-step are issued back to back
+    // (a branch or select that consumes a loaded value makes the compiler wait for every load separately).
+    const float* zp = p.zero_page;
+
     const float* wrow[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it)
@@ -94,32 +101,30 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
     auto load_tiles = [&]() {
         // A: gather
         const bool kval = k_cur < p.K;
-        const float* src; int ld, ch;
-        if (ci < p.Cg0) { src = p.x0; ld = d.ld0; ch = d.off0 + g * p.Cg0 + ci; }
-        else            { src = p.x1; ld = d.ld1; ch = d.off1 + g * p.Cg1 + (ci - p.Cg0); }
+        const bool in0 = ci < p.Cg0;
+        const float* src = in0 ? p.x0 : p.x1;
+        const int ld = in0 ? d.ld0 : d.ld1;
+        const int ch = in0 ? d.off0 + g * p.Cg0 + ci : d.off1 + g * p.Cg1 + (ci - p.Cg0);
         const int dy = ky * d.dh, dx = kx * d.dw;
         const int ush = d.upsample ? 1 : 0;
+        const float relu_floor = d.in_relu ? 0.f : -INFINITY;
+        const bool rep = d.pad_mode != 0;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             int iy = a_iy0[it] + dy, ix = a_ix0[it] + dx;
-            if (d.pad_mode) {
-                iy = min(max(iy, 0), p.Hin - 1);
-                ix = min(max(ix, 0), p.Win - 1);
-            }
+            const int cy = min(max(iy, 0), p.Hin - 1), cx = min(max(ix, 0), p.Win - 1);
+            iy = rep ? cy : iy;
+            ix = rep ? cx : ix;
             const bool ok = kval && a_nb[it] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-            // branch-free: invalid lanes read the (always mapped) first float4 of the source and discard it
-            const long off = ok ? ((long)(a_nb[it] + (iy >> ush) * d.W + (ix >> ush)) * ld + ch) : 0l;
-            float4 v = *reinterpret_cast<const float4*>(src + off);
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (d.in_relu) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
-            va[it] = v;
+            const float* addr = src + ((long)(a_nb[it] + (iy >> ush) * d.W + (ix >> ush)) * ld + ch);
+            const float4 v = *reinterpret_cast<const float4*>(ok ? addr : zp);
+            va[it] = make_float4(fmaxf(v.x, relu_floor), fmaxf(v.y, relu_floor), fmaxf(v.z, relu_floor), fmaxf(v.w, relu_floor));
         }
-        // B: packed weights, always in bounds (zero padded to Npad x Kpad)
+        // B: packed weights (zero padded to Npad x Kpad); prefetches past Kpad read the zero page
+        const bool kb_ok = k_cur < d.Kpad;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            vb[it] = *reinterpret_cast<const float4*>(wrow[it]);
+            vb[it] = *reinterpret_cast<const float4*>(kb_ok ? wrow[it] : zp);
             wrow[it] += BK;
         }
         // advance the k decomposition
@@ -178,6 +183,52 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
 
     const int l31 = lane & 31, lh = lane >> 5;
 
+    auto mfma_bf16 = [&](int buf, int ks) {
+        const __bf16* base = reinterpret_cast<const __bf16*>(smem + buf * STAGE);
+        const __bf16* Ahi = base + (wm * WTM + l31) * LDB + lh * 8;
+        const __bf16* Alo = Ahi + BM * LDB;
+        const __bf16* Bhi = base + 2 * BM * LDB + (wn * WTN + l31) * LDB + lh * 8;
+        const __bf16* Blo = Bhi + BN * LDB;
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            ah[i] = *reinterpret_cast<const bf16x8*>(Ahi + i * 32 * LDB + ks * 16);
+            al[i] = *reinterpret_cast<const bf16x8*>(Alo + i * 32 * LDB + ks * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + j * 32 * LDB + ks * 16);
+            bl[j] = *reinterpret_cast<const bf16x8*>(Blo + j * 32 * LDB + ks * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    if (PREC == 1 && p.pipe) {
+        // Software-pipelined schedule (one basic block per K-step, no branches): registers hold tile kt+1 while LDS holds
+        // tile kt.  The split + LDS store of tile kt+1 and the global gathers of tile kt+2 sit between the two halves of
+        // tile kt's MFMAs so that each wavefront overlaps its own VALU / LDS / VMEM work with its own matrix work.
+        if constexpr (PREC == 1) {
+            load_tiles();
+            store_tiles(0);
+            load_tiles();
+            __syncthreads();
+            for (int kt = 0; kt < p.nk; ++kt) {
+                const int buf = kt & 1;
+                mfma_bf16(buf, 0);
+                store_tiles(buf ^ 1);
+                load_tiles();
+                mfma_bf16(buf, 1);
+                __syncthreads();
+            }
+        }
+    } else {
     load_tiles();
     store_tiles(0);
     __syncthreads();
@@ -203,36 +254,12 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         } else {
-            const __bf16* base = reinterpret_cast<const __bf16*>(smem + buf * STAGE);
-            const __bf16* Ahi = base + (wm * WTM + l31) * LDB + lh * 8;
-            const __bf16* Alo = Ahi + BM * LDB;
-            const __bf16* Bhi = base + 2 * BM * LDB + (wn * WTN + l31) * LDB + lh * 8;
-            const __bf16* Blo = Bhi + BN * LDB;
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    ah[i] = *reinterpret_cast<const bf16x8*>(Ahi + i * 32 * LDB + ks * 16);
-                    al[i] = *reinterpret_cast<const bf16x8*>(Alo + i * 32 * LDB + ks * 16);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + j * 32 * LDB + ks * 16);
-                    bl[j] = *reinterpret_cast<const bf16x8*>(Blo + j * 32 * LDB + ks * 16);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
-            }
+            mfma_bf16(buf, 0);
+            mfma_bf16(buf, 1);
         }
         if (more) store_tiles(buf ^ 1);
         __syncthreads();
+    }
     }
 
     // ---- epilogue.  The accumulators go through LDS (the tile buffers are free now) so that the
@@ -390,6 +417,10 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const float* x0, const float*
     const long M = (long)d.N * Ho * Wo;
     FGT_REQUIRE(M < (1l << 31), "fgt_conv2d: M too large");
     p.M = (int)M; p.HoWo = Ho * Wo; p.nk = d.Kpad / BK;
+    static const int pipe_env = [] { const char* e = getenv("FGT_CONV_PIPE"); return e ? atoi(e) : 1; }();
+    p.pipe = pipe_env;
+    p.zero_page = fgt_zero_page();
+    FGT_REQUIRE(p.zero_page != nullptr, "fgt_conv2d: could not allocate the zero page");
     p.x0 = x0; p.x1 = x1 ? x1 : x0; p.w = w_packed; p.cscale = cscale; p.cbias = cbias; p.aux1 = aux1; p.aux2 = aux2; p.out = out;
 
     int tile = d.tile;

@@ -7,7 +7,12 @@ struct ConvP {
     const float *x0, *x1, *w, *cscale, *cbias, *aux1, *aux2;
     float* out;
     int M, HoWo, Cg0, Cg1, Cg, K, Cout_g, Hin, Win, nk;
+    const float* zero_page;   // 256 zero bytes in device memory: target of out-of-range gathers
+    int pipe;   // bf16x3: software-pipelined K loop (FGT_CONV_PIPE=0 selects the plain double-buffered loop)
 };
+
+// runtime.hip: one 256-byte zero-filled device allocation, created on first use (the only memory the library owns)
+const float* fgt_zero_page();
 
 // conv_direct.hip
 bool fgt_conv_direct_eligible(const ConvP& p);

@@ -13,3 +13,14 @@ void fgt_set_error(const char* fmt, ...) {
 
 extern "C" const char* fgt_last_error(void) { return g_err; }
 extern "C" int fgt_abi_version(void) { return 1; }
+
+const float* fgt_zero_page() {
+    static float* zp = nullptr;
+    if (!zp) {
+        void* q = nullptr;
+        if (hipMalloc(&q, 256) != hipSuccess) return nullptr;
+        if (hipMemset(q, 0, 256) != hipSuccess) return nullptr;
+        zp = static_cast<float*>(q);
+    }
+    return zp;
+}

@@ -21,7 +21,10 @@ echo "== bench (default, with cpu baseline)"
 timeout 900 python bench.py --steps 2 --warmup 1 > gpurun_out/bench.log 2>&1; echo "bench exit: $?" | tee -a gpurun_out/bench.log
 tail -3 gpurun_out/bench.log
 echo "== tune_conv"
-FGT_CONV_PRECISION=bf16x3 timeout 600 python tools/tune_conv.py --t 17 > gpurun_out/tune_conv_bf16x3.log 2>&1; cp gpurun_out/tune_conv.json gpurun_out/tune_conv_bf16x3.json; tail -40 gpurun_out/tune_conv_bf16x3.log
+for pipe in 0 1; do
+FGT_AUTOTUNE=0 FGT_CONV_PIPE=$pipe FGT_CONV_PRECISION=bf16x3 timeout 600 python tools/tune_conv.py --t 17 --tiles 128x128,64x64,128x64,256x128 > gpurun_out/tune_conv_bf16x3_pipe$pipe.log 2>&1; tail -32 gpurun_out/tune_conv_bf16x3_pipe$pipe.log
+done
+FGT_AUTOTUNE=0 FGT_CONV_PRECISION=fp32 timeout 600 python tools/tune_conv.py --t 17 --tiles 128x128,64x64 > gpurun_out/tune_conv_fp32.log 2>&1; tail -32 gpurun_out/tune_conv_fp32.log
 if [ "${1:-}" != "quick" ]; then
   echo "== rocprofv3 kernel stats"
   rm -rf gpurun_out/prof
