@@ -25,6 +25,22 @@ for pipe in 0 1; do
 FGT_AUTOTUNE=0 FGT_CONV_PIPE=$pipe FGT_CONV_PRECISION=bf16x3 timeout 600 python tools/tune_conv.py --t 17 --tiles 128x128,64x64,128x64,256x128 > gpurun_out/tune_conv_bf16x3_pipe$pipe.log 2>&1; tail -32 gpurun_out/tune_conv_bf16x3_pipe$pipe.log
 done
 FGT_AUTOTUNE=0 FGT_CONV_PRECISION=fp32 timeout 600 python tools/tune_conv.py --t 17 --tiles 128x128,64x64 > gpurun_out/tune_conv_fp32.log 2>&1; tail -32 gpurun_out/tune_conv_fp32.log
+echo "== PMC on one layer (enc8, bf16x3 128x128)"
+(cd /tmp && rocprofv3 -L > "$GRAFT_REPO_ROOT/gpurun_out/counters.txt" 2>&1
+ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+   tag=$(echo $set | cut -d' ' -f1)
+   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag" -o pmc -- python "$GRAFT_REPO_ROOT/tools/conv_micro.py" --layer enc8 --tile 128x128 --precision bf16x3 --reps 5 > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log" 2>&1
+   echo "pmc $tag exit $?"; tail -1 "$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log"
+ done)
+python - <<'PY'
+import csv, glob, collections
+for f in sorted(glob.glob("gpurun_out/pmc_*/**/*counter_collection.csv", recursive=True)):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        if "conv_igemm" in r.get("Kernel_Name", ""):
+            a = agg[r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+    print(f.split("/")[1], {k: round(v[1] / max(v[0], 1), 1) for k, v in agg.items()})
+PY
 if [ "${1:-}" != "quick" ]; then
   echo "== rocprofv3 kernel stats"
   rm -rf gpurun_out/prof
