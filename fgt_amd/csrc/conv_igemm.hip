@@ -62,7 +62,21 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int q = tid & 7, r = tid >> 3;
-    const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN, g = blockIdx.z;
+    // XCD-aware tile order.  Workgroup L is dispatched to XCD L % 8 (each XCD has a private 4 MiB L2).  Every XCD walks
+    // its own contiguous range of M tiles with the N tiles of one M tile adjacent in time, so the im2col re-reads
+    // (kh*kw taps x N tiles of the same input rows) hit that XCD's L2 instead of going back to HBM.  xcd_swizzle = 0
+    // keeps the plain (m fastest) order for A/B measurements.
+    int m_idx, n_idx;
+    if (p.xcd_swizzle) {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        n_idx = i % p.ntiles;
+        m_idx = xcd * p.mchunk + i / p.ntiles;
+        if (m_idx >= p.mtiles) return;
+    } else {
+        m_idx = blockIdx.x % p.mtiles;
+        n_idx = blockIdx.x / p.mtiles;
+    }
+    const int bm0 = m_idx * BM, bn0 = n_idx * BN, g = blockIdx.y;
 
     // ---- per-thread im2col row state (fixed over the K loop)
     int a_iy0[A_IT], a_ix0[A_IT];
@@ -98,27 +112,42 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
 
     float4 va[A_IT], vb[B_IT];
 
-    auto load_tiles = [&]() {
-        // A: gather
-        const bool kval = k_cur < p.K;
+    // Per-row gather bases for the current (tap, source) of this thread's k column: recomputed only when the column
+    // moves to another tap or crosses from source 0 to source 1 (every Cin_g/32 K-steps for the heavy layers), so the
+    // per-step address math is one add + one select per row.
+    const float* a_base[A_IT];
+    unsigned a_okmask = 0;
+    int seg_end = 0;
+    auto retap = [&]() {
         const bool in0 = ci < p.Cg0;
         const float* src = in0 ? p.x0 : p.x1;
         const int ld = in0 ? d.ld0 : d.ld1;
-        const int ch = in0 ? d.off0 + g * p.Cg0 + ci : d.off1 + g * p.Cg1 + (ci - p.Cg0);
+        const int chb = in0 ? d.off0 + g * p.Cg0 : d.off1 + g * p.Cg1 - p.Cg0;   // channel = chb + ci
+        seg_end = in0 ? p.Cg0 : p.Cg;
         const int dy = ky * d.dh, dx = kx * d.dw;
         const int ush = d.upsample ? 1 : 0;
-        const float relu_floor = d.in_relu ? 0.f : -INFINITY;
         const bool rep = d.pad_mode != 0;
+        a_okmask = 0;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             int iy = a_iy0[it] + dy, ix = a_ix0[it] + dx;
             const int cy = min(max(iy, 0), p.Hin - 1), cx = min(max(ix, 0), p.Win - 1);
             iy = rep ? cy : iy;
             ix = rep ? cx : ix;
-            const bool ok = kval && a_nb[it] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-            const float* addr = src + ((long)(a_nb[it] + (iy >> ush) * d.W + (ix >> ush)) * ld + ch);
-            const float4 v = *reinterpret_cast<const float4*>(ok ? addr : zp);
-            va[it] = make_float4(fmaxf(v.x, relu_floor), fmaxf(v.y, relu_floor), fmaxf(v.z, relu_floor), fmaxf(v.w, relu_floor));
+            const bool ok = a_nb[it] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            a_okmask |= (ok ? 1u : 0u) << it;
+            a_base[it] = src + ((long)(a_nb[it] + (iy >> ush) * d.W + (ix >> ush)) * ld + chb);
+        }
+    };
+    retap();
+
+    auto load_tiles = [&]() {
+        // A: gather (straight-line: the select is on the address, never on the loaded value)
+        const bool kval = k_cur < p.K;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const bool ok = kval && ((a_okmask >> it) & 1u);
+            va[it] = *reinterpret_cast<const float4*>(ok ? a_base[it] + ci : zp);
         }
         // B: packed weights (zero padded to Npad x Kpad); prefetches past Kpad read the zero page
         const bool kb_ok = k_cur < d.Kpad;
@@ -130,13 +159,21 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
         // advance the k decomposition
         k_cur += BK;
         ci += BK;
-        while (ci >= p.Cg) {
-            ci -= p.Cg;
-            if (++kx == d.kw) { kx = 0; ++ky; }
+        if (ci >= seg_end) {
+            while (ci >= p.Cg) {
+                ci -= p.Cg;
+                if (++kx == d.kw) { kx = 0; ++ky; }
+            }
+            retap();
         }
     };
 
     auto store_tiles = [&](int buf) {
+        if (d.in_relu) {   // ReLU on the gathered values (ffn_base.py:40-45), applied where they are consumed anyway
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it)
+                va[it] = make_float4(fmaxf(va[it].x, 0.f), fmaxf(va[it].y, 0.f), fmaxf(va[it].z, 0.f), fmaxf(va[it].w, 0.f));
+        }
         if constexpr (PREC == 0) {
             float* As = smem + buf * STAGE;
             float* Bs = As + BM * LDS_LD;
@@ -340,8 +377,12 @@ int launch(const ConvP& p, hipStream_t s) {
         }
         attr_set = true;
     }
-    dim3 grid(cdiv(p.M, BM), cdiv(p.Cout_g, BN), p.d.groups);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, PREC>), grid, dim3(NT), smem, s, p);
+    ConvP q = p;
+    q.mtiles = cdiv(p.M, BM);
+    q.ntiles = cdiv(p.Cout_g, BN);
+    q.mchunk = cdiv(q.mtiles, 8);
+    dim3 grid(q.xcd_swizzle ? 8 * q.mchunk * q.ntiles : q.mtiles * q.ntiles, p.d.groups);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, PREC>), grid, dim3(NT), smem, s, q);
     return fgt_check_launch("conv_igemm");
 }
 
@@ -419,6 +460,8 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const float* x0, const float*
     p.M = (int)M; p.HoWo = Ho * Wo; p.nk = d.Kpad / BK;
     static const int pipe_env = [] { const char* e = getenv("FGT_CONV_PIPE"); return e ? atoi(e) : 1; }();
     p.pipe = pipe_env;
+    static const int xcd_env = [] { const char* e = getenv("FGT_CONV_XCD"); return e ? atoi(e) : 1; }();
+    p.xcd_swizzle = xcd_env;
     p.zero_page = fgt_zero_page();
     FGT_REQUIRE(p.zero_page != nullptr, "fgt_conv2d: could not allocate the zero page");
     p.x0 = x0; p.x1 = x1 ? x1 : x0; p.w = w_packed; p.cscale = cscale; p.cbias = cbias; p.aux1 = aux1; p.aux2 = aux2; p.out = out;

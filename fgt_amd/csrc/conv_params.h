@@ -8,6 +8,7 @@ struct ConvP {
     float* out;
     int M, HoWo, Cg0, Cg1, Cg, K, Cout_g, Hin, Win, nk;
     const float* zero_page;   // 256 zero bytes in device memory: target of out-of-range gathers
+    int mtiles, ntiles, mchunk, xcd_swizzle;   // tile grid and XCD-aware ordering (set by the launcher)
     int pipe;   // bf16x3: software-pipelined K loop (FGT_CONV_PIPE=0 selects the plain double-buffered loop)
 };
 

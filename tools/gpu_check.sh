@@ -11,20 +11,16 @@ grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -3
 echo "== smoke"
 timeout 300 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit: $?" | tee -a gpurun_out/smoke.log
 tail -2 gpurun_out/smoke.log
-echo "== bench (variants)"
-for v in "--precision fp32 --no-cache" "--precision bf16x3"; do
-  tag=$(echo "$v" | tr -d ' -')
-  timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline $v > gpurun_out/bench_$tag.log 2>&1; echo "bench $v exit: $?"
-  grep '^{' gpurun_out/bench_$tag.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'],'fps', d['ms_per_step'],'ms', d.get('roofline'))"
-done
 echo "== bench (default, with cpu baseline)"
-timeout 900 python bench.py --steps 2 --warmup 1 > gpurun_out/bench.log 2>&1; echo "bench exit: $?" | tee -a gpurun_out/bench.log
-tail -3 gpurun_out/bench.log
-echo "== tune_conv"
-for pipe in 0 1; do
-FGT_AUTOTUNE=0 FGT_CONV_PIPE=$pipe FGT_CONV_PRECISION=bf16x3 timeout 600 python tools/tune_conv.py --t 17 --tiles 128x128,64x64,128x64,256x128 > gpurun_out/tune_conv_bf16x3_pipe$pipe.log 2>&1; tail -32 gpurun_out/tune_conv_bf16x3_pipe$pipe.log
+timeout 900 python bench.py --steps 3 --warmup 1 > gpurun_out/bench.log 2>&1; echo "bench exit: $?" | tee -a gpurun_out/bench.log
+grep '^{' gpurun_out/bench.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'],'fps', d['ms_per_step'],'ms', d.get('roofline'), d.get('cpu_baseline',{}).get('value'))"
+echo "== bench fp32 exact, no cache (reference-equivalent work)"
+timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --precision fp32 --no-cache > gpurun_out/bench_fp32_nocache.log 2>&1
+grep '^{' gpurun_out/bench_fp32_nocache.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'],'fps', d['ms_per_step'],'ms', d.get('roofline'))"
+echo "== tune_conv (XCD swizzle off / on)"
+for x in 0 1; do
+FGT_AUTOTUNE=0 FGT_CONV_XCD=$x FGT_CONV_PRECISION=bf16x3 timeout 600 python tools/tune_conv.py --t 17 --tiles 128x128,64x64,256x128 > gpurun_out/tune_conv_bf16x3_xcd$x.log 2>&1; tail -30 gpurun_out/tune_conv_bf16x3_xcd$x.log | cut -c1-120
 done
-FGT_AUTOTUNE=0 FGT_CONV_PRECISION=fp32 timeout 600 python tools/tune_conv.py --t 17 --tiles 128x128,64x64 > gpurun_out/tune_conv_fp32.log 2>&1; tail -32 gpurun_out/tune_conv_fp32.log
 echo "== PMC on one layer (enc8, bf16x3 128x128)"
 (cd /tmp && rocprofv3 -L > "$GRAFT_REPO_ROOT/gpurun_out/counters.txt" 2>&1
  for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
