@@ -33,7 +33,12 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDS_LD = 33;
 
-constexpr int LDB = 40;  // bf16 elements per LDS row in bf16x3 mode (32 + 8 pad = 80 bytes)
+constexpr int LDB = 32;  // bf16 elements per LDS row in bf16x3 mode: 64-byte rows, no padding.
+// The four 16-byte slots of a row are XOR-swizzled with (row >> 2) & 3: the 16 rows of a ds_read_b128 lane group then
+// cover all 16 slots of the 256-byte bank line (conflict free) and the 8-byte stores of two adjacent rows never share a
+// bank either.  (The 80-byte padded layout it replaces had 2-way store conflicts: SQ_LDS_BANK_CONFLICT = 33 % of
+// SQ_LDS_IDX_ACTIVE in profiles/r01_run4_pmc_*.json.)
+__device__ __forceinline__ int swz(int row, int slot) { return (slot ^ ((row >> 2) & 3)) * 8; }
 
 // hi/lo split of a float4 run: returns packed bf16 {hi0,hi1},{hi2,hi3} and {lo0,lo1},{lo2,lo3}
 __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
@@ -105,10 +110,15 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
     // (a branch or select that consumes a loaded value makes the compiler wait for every load separately).
     const float* zp = p.zero_page;
 
+    // fp32: float4 run q of row r.  bf16x3: the weights arrive pre-split ([2][groups][Npad][Kpad] bf16: hi plane, lo
+    // plane); thread q < 4 fetches 8 hi values (16 bytes) of its row, q >= 4 the matching 8 lo values: no conversion.
     const float* wrow[B_IT];
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it)
-        wrow[it] = p.w + ((long)g * d.Npad + bn0 + r + it * RPP) * d.Kpad + q * 4;
+    for (int it = 0; it < B_IT; ++it) {
+        const long rowi = (long)g * d.Npad + bn0 + r + it * RPP;
+        if constexpr (PREC == 0) wrow[it] = p.w + rowi * d.Kpad + q * 4;
+        else wrow[it] = p.w + ((q >> 2) * (long)d.groups * d.Npad * d.Kpad + rowi * d.Kpad) / 2 + (q & 3) * 4;   // in floats (2 bf16 each)
+    }
 
     float4 va[A_IT], vb[B_IT];
 
@@ -154,7 +164,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             vb[it] = *reinterpret_cast<const float4*>(kb_ok ? wrow[it] : zp);
-            wrow[it] += BK;
+            wrow[it] += PREC == 0 ? BK : BK / 2;
         }
         // advance the k decomposition
         k_cur += BK;
@@ -195,17 +205,16 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
             for (int it = 0; it < A_IT; ++it) {
                 uint2 hi, lo;
                 split4(va[it], hi, lo);
-                const int o = (r + it * RPP) * LDB + q * 4;
+                const int row = r + it * RPP;
+                const int o = row * LDB + swz(row, q >> 1) + (q & 1) * 4;
                 *reinterpret_cast<uint2*>(Ahi + o) = hi;
                 *reinterpret_cast<uint2*>(Alo + o) = lo;
             }
 #pragma unroll
-            for (int it = 0; it < B_IT; ++it) {
-                uint2 hi, lo;
-                split4(vb[it], hi, lo);
-                const int o = (r + it * RPP) * LDB + q * 4;
-                *reinterpret_cast<uint2*>(Bhi + o) = hi;
-                *reinterpret_cast<uint2*>(Blo + o) = lo;
+            for (int it = 0; it < B_IT; ++it) {      // already bf16: 16 bytes straight into the hi (q < 4) or lo plane
+                const int row = r + it * RPP;
+                __bf16* dst = (q < 4 ? Bhi : Blo) + row * LDB + swz(row, q & 3);
+                *reinterpret_cast<float4*>(dst) = vb[it];
             }
         }
     };
@@ -222,29 +231,36 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
 
     auto mfma_bf16 = [&](int buf, int ks) {
         const __bf16* base = reinterpret_cast<const __bf16*>(smem + buf * STAGE);
-        const __bf16* Ahi = base + (wm * WTM + l31) * LDB + lh * 8;
+        // operand rows: wave-tile base (multiple of 32) + l31, so (row >> 2) & 3 == (l31 >> 2) & 3 for every fragment
+        const int so = swz(l31, ks * 2 + lh);
+        const __bf16* Ahi = base + (wm * WTM + l31) * LDB + so;
         const __bf16* Alo = Ahi + BM * LDB;
-        const __bf16* Bhi = base + 2 * BM * LDB + (wn * WTN + l31) * LDB + lh * 8;
+        const __bf16* Bhi = base + 2 * BM * LDB + (wn * WTN + l31) * LDB + so;
         const __bf16* Blo = Bhi + BN * LDB;
         bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            ah[i] = *reinterpret_cast<const bf16x8*>(Ahi + i * 32 * LDB + ks * 16);
-            al[i] = *reinterpret_cast<const bf16x8*>(Alo + i * 32 * LDB + ks * 16);
+            ah[i] = *reinterpret_cast<const bf16x8*>(Ahi + i * 32 * LDB);
+            al[i] = *reinterpret_cast<const bf16x8*>(Alo + i * 32 * LDB);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + j * 32 * LDB + ks * 16);
-            bl[j] = *reinterpret_cast<const bf16x8*>(Blo + j * 32 * LDB + ks * 16);
+            bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + j * 32 * LDB);
+            bl[j] = *reinterpret_cast<const bf16x8*>(Blo + j * 32 * LDB);
         }
+        // the three partial products of one accumulator are spread out: consecutive MFMAs never share an accumulator
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
     };
 
     if (PREC == 1 && p.pipe) {
@@ -478,7 +494,7 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const float* x0, const float*
     }
     hipStream_t s = (hipStream_t)stream;
     ProfRec rec{};
-    const bool direct = d.tile == 0 && fgt_conv_direct_eligible(p);
+    const bool direct = d.tile == 0 && d.precision == 0 && fgt_conv_direct_eligible(p);
     const bool prof = g_prof_on && !direct;   // the roofline block is about the MFMA kernel only
     if (prof) {
         rec.a = get_event(); rec.b = get_event();

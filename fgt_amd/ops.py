@@ -96,8 +96,18 @@ class PackedConv:
         tmp[..., :Cg] = wp
         packed[:, :Cout_g, :K] = tmp.reshape(groups, Cout_g, K)
         self.w = packed.contiguous()
+        self._w_split = None
         self.bias = None if bias is None else bias.detach().float().contiguous()
         self.scale = None if scale is None else scale.detach().float().contiguous()
+
+
+def _split_weights(pc):
+    """[2, groups, Npad, Kpad] bf16: hi = bf16_rne(w), lo = bf16_rne(w - hi) — the bf16x3 kernel's weight image."""
+    if pc._w_split is None:
+        hi = pc.w.to(torch.bfloat16)
+        lo = (pc.w - hi.float()).to(torch.bfloat16)
+        pc._w_split = torch.stack([hi, lo], 0).contiguous()
+    return pc._w_split
 
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
@@ -138,7 +148,10 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     d.out_scale = float(out_scale)
     d.Kpad, d.Npad, d.tile = pc.Kpad, pc.Npad, TILE[tile]
     d.precision = PREC[precision if precision is not None else DEFAULT_CONV_PRECISION]
-    args = (C.byref(d), _ptr(x), _ptr(x1), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(aux1), _ptr(aux2), _ptr(out))
+    if pc.Cout // pc.groups <= 4 and d.tile == 0:
+        d.precision = 0                      # Cout <= 4 layers run the fp32 VALU direct-conv kernels
+    wbuf = pc.w if d.precision == 0 else _split_weights(pc)
+    args = (C.byref(d), _ptr(x), _ptr(x1), _ptr(wbuf), _ptr(pc.scale), _ptr(pc.bias), _ptr(aux1), _ptr(aux2), _ptr(out))
     if d.tile == 0 and AUTOTUNE and pc.Cout // pc.groups > 4:
         key = (N, H, W, C0, C1, pc.Cout, pc.groups, pc.kh, pc.kw, sh, sw, ph, pw, dh, dw, d.upsample, d.epi, d.out_nchw, d.precision)
         best = _tile_cache.get(key)

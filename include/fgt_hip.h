@@ -80,7 +80,10 @@ typedef struct fgt_conv_desc {
     float out_scale;        /* multiplies the value after act (before epi); 1.0f = off                */
     int Kpad, Npad;         /* packed-weight geometry: w is [groups, Npad, Kpad], k = (ky*kw+kx)*Cg+ci */
     int tile;               /* 0 = auto; otherwise a FGT_TILE_* override (tuning / tests)             */
-    int precision;          /* FGT_PREC_FP32 (exact fp32 MFMA) | FGT_PREC_BF16X3 (hi/lo bf16 split, 3 MFMAs)  */
+    int precision;          /* FGT_PREC_FP32 (exact fp32 MFMA) | FGT_PREC_BF16X3 (hi/lo bf16 split, 3 MFMAs).
+                             * With FGT_PREC_BF16X3 `w_packed` must be the PRE-SPLIT bf16 image of the packed weights:
+                             * [2][groups][Npad][Kpad] bf16, plane 0 = hi = bf16_rne(w), plane 1 = lo = bf16_rne(w - hi)
+                             * (same byte count as the fp32 image).  Activations are split inside the kernel.      */
 } fgt_conv_desc;
 
 #define FGT_PREC_FP32 0
