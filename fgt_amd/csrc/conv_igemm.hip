@@ -214,7 +214,10 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
             for (int it = 0; it < B_IT; ++it) {      // already bf16: 16 bytes straight into the hi (q < 4) or lo plane
                 const int row = r + it * RPP;
                 __bf16* dst = (q < 4 ? Bhi : Blo) + row * LDB + swz(row, q & 3);
-                *reinterpret_cast<float4*>(dst) = vb[it];
+                // (built component-wise: a whole-struct float4 copy through this pointer keeps vb[] in scratch memory)
+                const float4 t = vb[it];
+                *reinterpret_cast<uint4*>(dst) = make_uint4(__builtin_bit_cast(unsigned, t.x), __builtin_bit_cast(unsigned, t.y),
+                                                            __builtin_bit_cast(unsigned, t.z), __builtin_bit_cast(unsigned, t.w));
             }
         }
     };
