@@ -52,8 +52,8 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
                     __builtin_bit_cast(unsigned, __builtin_convertvector(lb, bf16x2)));
 }
 
-template <int BM, int BN, int WM, int WN, int PREC>
-__global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP p) {
+template <int BM, int BN, int WM, int WN, int PREC, int MINW>
+__global__ void __launch_bounds__(WM* WN * 64, MINW) conv_igemm_kernel(const ConvP p) {
     constexpr int NT = WM * WN * 64;
     constexpr int RPP = NT / 8;  // tile rows covered per pass of the loader
     constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
@@ -382,13 +382,13 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(const ConvP 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int PREC>
+template <int BM, int BN, int WM, int WN, int PREC, int MINW = 2>
 int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr size_t smem = 2ul * (PREC == 0 ? (BM + BN) * LDS_LD : (BM + BN) * LDB) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, PREC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, PREC, MINW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
             fgt_set_error("hipFuncSetAttribute(conv_igemm %dx%d): %s", BM, BN, hipGetErrorString(e));
@@ -401,7 +401,7 @@ int launch(const ConvP& p, hipStream_t s) {
     q.ntiles = cdiv(p.Cout_g, BN);
     q.mchunk = cdiv(q.mtiles, 8);
     dim3 grid(q.xcd_swizzle ? 8 * q.mchunk * q.ntiles : q.mtiles * q.ntiles, p.d.groups);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, PREC>), grid, dim3(NT), smem, s, q);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, PREC, MINW>), grid, dim3(NT), smem, s, q);
     return fgt_check_launch("conv_igemm");
 }
 
@@ -413,6 +413,8 @@ int launch_tile(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_64x64: return launch<64, 64, 2, 2, PREC>(p, s);
         case FGT_TILE_128x32: return launch<128, 32, 4, 1, PREC>(p, s);
         case FGT_TILE_256x128: return launch<256, 128, 4, 2, PREC>(p, s);
+        case FGT_TILE_128x128x8: return launch<128, 128, 2, 4, PREC, 4>(p, s);   // 8 wavefronts of 64x32, <= 128 VGPRs: 4 waves/SIMD
+        case FGT_TILE_256x128x16: return launch<256, 128, 4, 4, PREC, 4>(p, s); // 16 wavefronts of 64x32
         default: fgt_set_error("fgt_conv2d: unknown tile %d", tile); return FGT_EINVAL;
     }
 }

@@ -94,6 +94,8 @@ typedef struct fgt_conv_desc {
 #define FGT_TILE_64x64 3
 #define FGT_TILE_128x32 4
 #define FGT_TILE_256x128 5
+#define FGT_TILE_128x128x8 6   /* 128x128 tile on 8 wavefronts (64x32 each) */
+#define FGT_TILE_256x128x16 7  /* 256x128 tile on 16 wavefronts */
 
 int fgt_conv2d(const fgt_conv_desc* d, const float* x0, const float* x1, const float* w_packed,
                const float* cscale /* [Cout] or NULL */, const float* cbias /* [Cout] or NULL */,

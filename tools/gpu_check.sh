@@ -18,7 +18,7 @@ echo "== bench fp32 exact, no cache (reference-equivalent work)"
 timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --precision fp32 --no-cache > gpurun_out/bench_fp32_nocache.log 2>&1
 grep '^{' gpurun_out/bench_fp32_nocache.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'],'fps', d['ms_per_step'],'ms', d.get('roofline'))"
 echo "== tune_conv"
-FGT_AUTOTUNE=0 FGT_CONV_PRECISION=bf16x3 timeout 600 python tools/tune_conv.py --t 17 --tiles 128x128,64x64,256x128,128x64 > gpurun_out/tune_conv_bf16x3.log 2>&1; tail -30 gpurun_out/tune_conv_bf16x3.log | cut -c1-130
+FGT_AUTOTUNE=0 FGT_CONV_PRECISION=bf16x3 timeout 600 python tools/tune_conv.py --t 17 --tiles 128x128,64x64,256x128,128x128x8,256x128x16 > gpurun_out/tune_conv_bf16x3.log 2>&1; tail -30 gpurun_out/tune_conv_bf16x3.log | cut -c1-130
 echo "== PMC on one layer (enc8, bf16x3 128x128)"
 (cd /tmp && rocprofv3 -L > "$GRAFT_REPO_ROOT/gpurun_out/counters.txt" 2>&1
  for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
