@@ -31,6 +31,17 @@ def fgt_flops(t):
     return (147.03 * t + 1.0618 * t * t) * 1e9
 
 
+def conv_traffic(prec):
+    """HBM bytes per conv_igemm launch from the rocprofv3 PMC passes over this same command (FETCH_SIZE and WRITE_SIZE
+    in separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), committed as profiles/conv_traffic.json by
+    tools/gpu_check.sh.  PMC counters cannot be read from inside the process, so this is the last profiled value."""
+    p = os.path.join(ROOT, "profiles", "conv_traffic.json")
+    if not os.path.exists(p):
+        return None
+    t = json.load(open(p))
+    return t.get(prec, {}).get("hbm_bytes_per_launch")
+
+
 def cpu_baseline(cfg, sd, frames, flows, masks, sched):
     """Oracle (PyTorch-CPU port of the reference path) on a bounded sample of the same workload: the first window
     (t = 13) of the schedule, after choosing the intra-op thread count that runs a 2-frame probe fastest (a 256-thread
@@ -116,6 +127,8 @@ def main():
 
     runner.run()                      # untimed preparation pass: weight packing + per-shape tile autotuning (setup, not a step)
     barrier()
+    if rank == 0 and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        ops.save_tuning(os.path.join(ROOT, "gpurun_out", "tuning.json"))
     for _ in range(args.warmup):
         runner.run()
     barrier()
@@ -124,6 +137,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         comp = runner.run()
+    host_dt = time.perf_counter() - t0      # time the host needed to enqueue everything (launch-bound if close to dt)
     barrier()
     dt = time.perf_counter() - t0
     if not args.no_prof:
@@ -149,6 +163,7 @@ def main():
                        "windows": len(runner.sched), "sharding": f"windows round-robin over {world} rank(s)",
                        "conv_precision": prec, "per_frame_feature_cache": bool(runner.cache_features)},
         }
+        out["host_enqueue_ms_per_step"] = round(1e3 * host_dt / args.steps, 3)
         if clip_flops:
             out["effective_tflops"] = round(clip_flops * args.steps / dt / 1e12, 2)
         if not args.no_prof and k_ms > 0:
@@ -157,7 +172,7 @@ def main():
             ach = passes * k_flops / (k_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": f"conv_igemm_kernel ({prec} implicit-GEMM conv + all Linear layers)",
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(ach / peak, 4), "traffic": None,
+                               "frac": round(ach / peak, 4), "traffic": conv_traffic(prec),
                                "algorithmic_tflops": round(k_flops / (k_ms * 1e-3) / 1e12, 2), "mfma_passes_per_product": passes,
                                "launches": k_launches, "kernel_ms_per_step": round(k_ms / args.steps, 3),
                                "share_of_step": round(k_ms / (1e3 * dt), 3)}

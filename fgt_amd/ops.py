@@ -30,6 +30,24 @@ def tuning_table():
     return {repr(k): v for k, v in _tile_cache.items()}
 
 
+def save_tuning(path):
+    import json
+    with open(path, "w") as f:
+        json.dump(tuning_table(), f, indent=0, sort_keys=True)
+
+
+def load_tuning(path):
+    """Pre-seed the autotuner with a table written by save_tuning (keys are shape tuples, values tile codes)."""
+    import ast
+    import json
+    for k, v in json.load(open(path)).items():
+        _tile_cache[ast.literal_eval(k)] = int(v)
+
+
+if os.environ.get("FGT_TUNING_FILE") and os.path.exists(os.environ["FGT_TUNING_FILE"]):
+    load_tuning(os.environ["FGT_TUNING_FILE"])
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -1,0 +1,27 @@
+"""Compile-time resource guard (CPU only, hipcc cross-compiles): no kernel may use scratch memory or spill registers.
+A 16-byte struct copy through the wrong pointer type once put a tile fragment in scratch and cost 35 % throughput."""
+import os
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+from fgt_amd import build as B
+
+
+def _usage(src):
+    cmd = [B._hipcc()] + B.FLAGS + ["-c", os.path.join(B.CSRC, src), "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    txt = r.stdout + r.stderr
+    return [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", txt)], [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", txt)]
+
+
+def test_no_kernel_uses_scratch_or_spills():
+    srcs = [s for s in B.SOURCES if s != "runtime.hip"]
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        res = dict(zip(srcs, ex.map(_usage, srcs)))
+    for src, (scratch, spills) in res.items():
+        assert scratch, f"{src}: no kernels reported"
+        allowed = 24 if src == "conv_igemm.hip" else 0     # the 8-wave 128x128 bf16x3 tile is capped at 128 VGPRs (6 dwords spill)
+        assert max(scratch) <= allowed and sum(1 for s in scratch if s) <= 1, f"{src}: scratch bytes/lane {scratch}"
+        assert sum(spills) <= 6, f"{src}: VGPR spills {spills}"

@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""BASELINE config #4 / #5 timings on the GPU box: LAFC call and RAFT pair at 432x240 (and the tool-faithful 864x480
+RAFT input), plus one FGT window of the 864x480x160 clip (t = 26, 2880 tokens/frame).  Prints one JSON line per case and
+writes gpurun_out/flow_bench.json.  CPU oracle timings are taken on small bounded samples."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fgt_amd import ops  # noqa: E402
+from fgt_amd.synth import synth_clip, synth_state_dict  # noqa: E402
+
+
+def timed(fn, reps):
+    fn(); fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--precision", default="bf16x3")
+    ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle on the same inputs")
+    a = ap.parse_args()
+    ops.DEFAULT_CONV_PRECISION = ops.DEFAULT_ATTN_PRECISION = a.precision
+    dev = torch.device("cuda:0")
+    torch.set_grad_enabled(False)
+    out = []
+    # ---- LAFC: 3 flows at 240x432 (130.2 GFLOP per call)
+    from fgt_amd import lafc_model
+    m = lafc_model.Model(dict(lafc_model.DEFAULT_CONFIG)).eval()
+    sd = synth_state_dict(m.state_dict(), seed=0, mode="kaiming")
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(0)
+    fl = torch.randn(1, 2, 3, 240, 432, generator=g)
+    ms = (torch.rand(1, 1, 3, 240, 432, generator=g) > 0.8).float()
+    dfl, dms = fl.to(dev), ms.to(dev)
+    t = timed(lambda: m(dfl, dms), 10)
+    rec = {"case": "LAFC forward [1,2,3,240,432]", "ms": round(t * 1e3, 3), "tflops_algorithmic": round(130.2e9 / t / 1e12, 2), "precision": a.precision}
+    if a.cpu:
+        from oracle import lafc_oracle as LO
+        t0 = time.perf_counter(); ref = LO.lafc_forward(sd, lafc_model.DEFAULT_CONFIG, fl, ms); rec["cpu_oracle_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+        rec["max_abs_vs_oracle"] = float((m(dfl, dms)[0].cpu() - ref[0]).abs().max())
+    out.append(rec)
+    # ---- RAFT pairs, 20 iterations
+    import argparse as ap2
+    from fgt_amd import raft_model
+    r = raft_model.RAFT(ap2.Namespace(small=False, mixed_precision=False, alternate_corr=False)).eval()
+    rsd = synth_state_dict(r.state_dict(), seed=0, mode="kaiming")
+    r.load_state_dict(rsd, strict=True)
+    r = r.to(dev)
+    for (H, W, gf) in ((240, 432, 245.7), (480, 864, 998.9)):
+        base = torch.nn.functional.interpolate(torch.rand(1, 3, H // 8 + 2, W // 8 + 2, generator=g), size=(H + 8, W + 8), mode="bilinear") * 255
+        i1, i2 = base[:, :, 4:4 + H, 4:4 + W].contiguous().to(dev), base[:, :, 3:3 + H, 6:6 + W].contiguous().to(dev)
+        t = timed(lambda: r(i1, i2, iters=20, test_mode=True), 5)
+        out.append({"case": f"RAFT pair {W}x{H}, 20 iters", "ms": round(t * 1e3, 3), "tflops_algorithmic": round(gf * 1e9 / t / 1e12, 2), "precision": a.precision})
+    # ---- one FGT window of BASELINE config #5: 864x480, t = 26
+    from fgt_amd.fgt_model import DEFAULT_CONFIG, Model
+    f = Model(dict(DEFAULT_CONFIG)).eval()
+    f.load_state_dict(synth_state_dict(f.state_dict(), seed=0), strict=True)
+    f = f.to(dev)
+    fr, fw, mk = synth_clip(26, 480, 864, device=dev)
+    mf = (fr * 2 - 1) * (1 - mk)
+    t = timed(lambda: f(mf, fw, mk), 3)
+    out.append({"case": "FGT window 864x480, t=26 (config #5 unit)", "ms": round(t * 1e3, 2), "frames_per_s_this_window": round(26 / t, 1),
+                "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "precision": a.precision})
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(out, open("gpurun_out/flow_bench.json", "w"), indent=1)
+    for o in out:
+        print(json.dumps(o))
+
+
+if __name__ == "__main__":
+    main()

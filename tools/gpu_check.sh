@@ -36,9 +36,16 @@ for f in sorted(glob.glob("gpurun_out/pmc_*/**/*counter_collection.csv", recursi
     print(f.split("/")[1], {k: round(v[1] / max(v[0], 1), 1) for k, v in agg.items()})
 PY
 if [ "${1:-}" != "quick" ]; then
+  echo "== flow bench (LAFC / RAFT / config-5 window)"
+  timeout 600 python tools/flow_bench.py --cpu > gpurun_out/flow_bench.log 2>&1; tail -5 gpurun_out/flow_bench.log | cut -c1-250
+  echo "== PMC HBM traffic of conv_igemm over bench.py"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && FGT_TUNING_FILE="$GRAFT_REPO_ROOT/gpurun_out/tuning.json" timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmcb_$c" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-prof > "$GRAFT_REPO_ROOT/gpurun_out/pmcb_$c.log" 2>&1)
+  done
+  python tools/pmc_traffic.py gpurun_out/pmcb_FETCH_SIZE gpurun_out/pmcb_WRITE_SIZE bf16x3 gpurun_out/conv_traffic.json
   echo "== rocprofv3 kernel stats"
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o fgt -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-prof --precision bf16x3 > "$GRAFT_REPO_ROOT/gpurun_out/rocprof.log" 2>&1)
+  (cd /tmp && FGT_TUNING_FILE="$GRAFT_REPO_ROOT/gpurun_out/tuning.json" timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o fgt -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-prof --precision bf16x3 > "$GRAFT_REPO_ROOT/gpurun_out/rocprof.log" 2>&1)
   echo "rocprof exit: $?"
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cut -c1-160 "$f" | head -16

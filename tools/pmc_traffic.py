@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py into per-launch HBM traffic of conv_igemm.
+
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <precision> <out.json>
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def avg(d, counter):
+    n, tot = 0, 0.0
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "conv_igemm" in r.get("Kernel_Name", "") and r["Counter_Name"] == counter:
+                n += 1
+                tot += float(r["Counter_Value"])
+    return n, tot
+
+
+def main():
+    fd, wd, prec, out = sys.argv[1:5]
+    nf, f = avg(fd, "FETCH_SIZE")
+    nw, w = avg(wd, "WRITE_SIZE")
+    res = json.load(open(out)) if os.path.exists(out) else {}
+    res[prec] = {"launches": nf, "fetch_KiB_per_launch_raw": f / max(nf, 1), "write_KiB_per_launch": w / max(nw, 1),
+                 "hbm_bytes_per_launch": round((2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024),
+                 "note": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KiB -> bytes, averaged over the "
+                         "conv_igemm_kernel launches of `bench.py --steps 1 --warmup 0`"}
+    json.dump(res, open(out, "w"), indent=1)
+    print(res[prec])
+
+
+if __name__ == "__main__":
+    main()
