@@ -96,12 +96,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # FGT_BENCH_SHARE_GPU=1 + FGT_BENCH_BACKEND=gloo: rehearse the N-rank sharded path on a single-GPU box (all ranks on
+    # cuda:0, collectives staged through the host).  The driver's multi-GPU runs use the defaults: one GPU per rank, RCCL.
+    share = os.environ.get("FGT_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("FGT_BENCH_BACKEND", "nccl")
+    local = 0 if share else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.set_grad_enabled(False)
 
     from fgt_amd import ops
@@ -143,7 +151,7 @@ def main():
     if not args.no_prof:
         ops.prof_enable(False)
         k_ms, k_flops, k_launches = ops.prof_collect()
-    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = tt.item()
@@ -180,6 +188,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, sd, frames, flows, masks, runner.sched)
         # sanity on the produced clip (finite, in range) so a broken run cannot report a number silently
         c = comp.float()
+        out["output_checksum"] = round(float(c.double().mean()), 6)      # identical for every N (same clip, exact sharding)
         out["output_sane"] = bool(torch.isfinite(c).all() and c.min().item() >= 0 and c.max().item() <= 255)
         print(json.dumps(out))
         assert out["output_sane"], "composited clip has NaN/inf or out-of-range values"

@@ -41,6 +41,19 @@ def shard_windows(n_windows, rank, world):
     return list(range(rank, n_windows, world))
 
 
+def all_gather(out, buf, group=None):
+    """all_gather_into_tensor; RCCL works on device buffers directly.  The gloo backend (CPU tests, and the 2-ranks-on-one-GPU
+    rehearsal of the sharded path on a single-GPU box) cannot gather device tensors, so it is staged through host memory."""
+    import torch.distributed as dist
+    if buf.is_cuda and dist.get_backend(group) != "nccl":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, buf.cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, buf, group=group)
+    return out
+
+
 def compose_torch(out, nb, frames01, masks, comp, visited):
     """Reference compose/blend restated with torch ops (CPU path used only by the CPU tests)."""
     filled = ((out + 1) / 2).permute(0, 2, 3, 1) * 255
@@ -112,7 +125,7 @@ class ClipRunner:
             buf = torch.zeros(per, mine.shape[1], dtype=mine.dtype, device=mine.device)
             buf[: mine.shape[0]] = mine
             flat = torch.empty(self.world * per, mine.shape[1], dtype=mine.dtype, device=mine.device)
-            dist.all_gather_into_tensor(flat, buf, group=self.group)       # the "boundary feature" all-gather (RCCL / gloo)
+            all_gather(flat, buf, self.group)                              # the "boundary feature" all-gather (RCCL / gloo)
             flat = flat[: self.n]
         Hf, Wf = self.H // 4, self.W // 4
         n_tok = th * tw
@@ -160,7 +173,7 @@ class ClipRunner:
             o = outs[wi]
             buf[slot, : o.shape[0]] = o
         gathered = torch.empty(self.world * per_rank, self.max_nb, 3, self.H, self.W, dtype=torch.float32, device=self.dev)
-        dist.all_gather_into_tensor(gathered, buf, group=self.group)
+        all_gather(gathered, buf, self.group)
         full = {}
         for r in range(self.world):
             for slot, wi in enumerate(shard_windows(len(self.sched), r, self.world)):

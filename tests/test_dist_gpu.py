@@ -1,0 +1,53 @@
+"""Rehearsal of the multi-rank FGT stage on ONE MI355X: two ranks share cuda:0 (gloo, collectives staged through the
+host), each runs the HIP model on its shard of frames / windows; the result must equal the single-rank clip.
+(RCCL itself cannot be exercised on a 1-GPU box: the collective calls are the same `all_gather_into_tensor`.)"""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+N, H, W = 14, 64, 96
+
+
+def _clip_and_model():
+    from fgt_amd.fgt_model import DEFAULT_CONFIG, Model
+    from fgt_amd.synth import synth_clip, synth_state_dict
+    torch.set_grad_enabled(False)
+    dev = torch.device("cuda:0")
+    m = Model(dict(DEFAULT_CONFIG)).eval()
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=0), strict=True)
+    fr, fl, ms = synth_clip(N, H, W, seed=5, device=dev)
+    return m.to(dev), fr, fl, ms
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fgt_amd.scheduler import ClipRunner
+    m, fr, fl, ms = _clip_and_model()
+    comp = ClipRunner(m, fr, fl, ms, rank=rank, world=world).run()
+    q.put((rank, comp.cpu()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_single_rank():
+    from fgt_amd.scheduler import ClipRunner
+    world, port = 2, 33500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=600) for _ in range(world))
+    [p.join(timeout=120) for p in procs]
+    m, fr, fl, ms = _clip_and_model()
+    single = ClipRunner(m, fr, fl, ms).run().cpu()
+    uncached = ClipRunner(m, fr, fl, ms, cache_features=False).run().cpu()
+    assert torch.equal(res[0], res[1])
+    for name, other in (("2 ranks", res[0]), ("no feature cache", uncached)):
+        d = (other - single).abs()
+        print(f"[parity] clip {name} vs single rank: max diff {d.max().item()} (uint8 steps), differing px {(d > 0).float().mean().item():.2e}")
+        assert d.max().item() <= 1.0 and (d > 0).float().mean().item() < 1e-3
