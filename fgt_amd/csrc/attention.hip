@@ -12,6 +12,7 @@
 //
 // The zone / window / head gathers of the reference (attention_base.py:61-69, attention_flow.py:76-108)
 // are folded into the row addressing: Q, K, V are read in place from the projection GEMM outputs.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -231,7 +232,7 @@ __device__ __forceinline__ bf16x8 as_bf16x8(unsigned a, unsigned b, unsigned c, 
     return __builtin_bit_cast(bf16x8, u);
 }
 
-template <int NW>
+template <int NW, bool PF>
 __global__ void __launch_bounds__(NW * 64, 2) attn_bf16x3_kernel(const AttnP p) {
     constexpr int NT = NW * 64;
     __shared__ __attribute__((aligned(16))) __bf16 Khi[KT * KLDB];
@@ -287,35 +288,67 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_bf16x3_kernel(const AttnP p) 
         for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    for (int k0 = 0; k0 < p.n_k; k0 += KT) {
-        key_pointers(p, pr, choff, k0, tid, kptr, vptr);
-        __syncthreads();
-        // ---- K tile: [key][d] rows, split on the way in
+    // Register prefetch: the raw fp32 K/V values of tile i+1 are fetched while tile i is being multiplied, so the
+    // global-load latency (57 % of the wave time was s_waitcnt/barrier in the non-prefetching version) overlaps the MFMAs.
+    constexpr int K_IT = KT * (HD / 4) / NT, V_IT = HD * 4 / NT;
+    float4 kreg[K_IT];
+    float vreg[V_IT][8];
+    auto gload = [&]() {
 #pragma unroll
-        for (int it = 0; it < KT * (HD / 4) / NT; ++it) {
+        for (int it = 0; it < K_IT; ++it) {
+            const int idx = tid + it * NT;
+            kreg[it] = *reinterpret_cast<const float4*>(kptr[idx >> 5] + (idx & 31) * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < V_IT; ++it) {
+            const int idx = tid + it * NT;
+            const int dd = idx & (HD - 1), g = idx >> 7;        // HD == 128; g = 2*ks + h
+            const int kbase = 16 * (g >> 1) + 4 * (g & 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vreg[it][j] = vptr[kbase + (j & 3) + 8 * (j >> 2)][dd];
+        }
+    };
+    auto lstore = [&]() {
+        // K tile: [key][d] rows; V tile transposed [d][pos], pos = (2*ks + h)*8 + j  <->  key(8ks + j, h)
+#pragma unroll
+        for (int it = 0; it < K_IT; ++it) {
             const int idx = tid + it * NT;
             const int row = idx >> 5, c4 = idx & 31;
-            const float4 kv = *reinterpret_cast<const float4*>(kptr[row] + c4 * 4);
             unsigned h0, h1, l0, l1;
-            split2(kv.x, kv.y, h0, l0); split2(kv.z, kv.w, h1, l1);
+            split2(kreg[it].x, kreg[it].y, h0, l0); split2(kreg[it].z, kreg[it].w, h1, l1);
             *reinterpret_cast<uint2*>(Khi + row * KLDB + c4 * 4) = make_uint2(h0, h1);
             *reinterpret_cast<uint2*>(Klo + row * KLDB + c4 * 4) = make_uint2(l0, l1);
         }
-        // ---- V tile transposed: item = (d, position group g = 2*ks + h); its 8 keys are key(8ks + j, h)
 #pragma unroll
-        for (int it = 0; it < HD * 4 / NT; ++it) {
+        for (int it = 0; it < V_IT; ++it) {
             const int idx = tid + it * NT;
-            const int dd = idx & (HD - 1), g = idx >> 7;        // HD == 128
-            const int kbase = 16 * (g >> 1) + 4 * (g & 1);
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = vptr[kbase + (j & 3) + 8 * (j >> 2)][dd];
+            const int dd = idx & (HD - 1), g = idx >> 7;
+            const float* v = vreg[it];
             unsigned h0, h1, h2, h3, l0, l1, l2, l3;
             split2(v[0], v[1], h0, l0); split2(v[2], v[3], h1, l1); split2(v[4], v[5], h2, l2); split2(v[6], v[7], h3, l3);
             *reinterpret_cast<uint4*>(Vhi + dd * VLDB + g * 8) = make_uint4(h0, h1, h2, h3);
             *reinterpret_cast<uint4*>(Vlo + dd * VLDB + g * 8) = make_uint4(l0, l1, l2, l3);
         }
+    };
+
+    if constexpr (PF) {
+        key_pointers(p, pr, choff, 0, tid, kptr, vptr);
         __syncthreads();
+        gload();
+    }
+    for (int k0 = 0; k0 < p.n_k; k0 += KT) {
+        if constexpr (PF) {
+            lstore();                                                 // tile k0: registers -> LDS (waits for its loads)
+            key_pointers(p, pr, choff, k0 + KT, tid, kptr, vptr);     // rows of the next tile (clamped past the end)
+            __syncthreads();
+            gload();                                                  // next tile in flight during the MFMAs below
+        } else {                                                      // short key lists (spatial windows): no prefetch registers
+            key_pointers(p, pr, choff, k0, tid, kptr, vptr);
+            __syncthreads();
+            gload();
+            lstore();
+            __syncthreads();
+        }
 
         // ---- S^T tile = K . Q^T  (already in log2 units: Q carries the scale)
         f32x16 s;
@@ -374,6 +407,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_bf16x3_kernel(const AttnP p) 
                 o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h, p_h, o[t], 0, 0, 0);
             }
         }
+        if constexpr (PF) __syncthreads();                            // tile consumed: LDS may be overwritten
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -401,6 +435,11 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_bf16x3_kernel(const AttnP p) 
                 }
         }
     }
+}
+
+bool attn_nw8() {
+    static const int v = [] { const char* e = getenv("FGT_ATTN_NW8"); return e ? atoi(e) : 0; }();
+    return v != 0;
 }
 
 }  // namespace
@@ -442,11 +481,14 @@ extern "C" int fgt_attention(const fgt_attn_desc* dd, const float* Q, const floa
     if (p.n_q <= 64) {
         dim3 grid(cdiv(p.n_q, 64), problems);
         if (d.precision == 0) hipLaunchKernelGGL((attn_kernel<2>), grid, dim3(128), 0, s, p);
-        else hipLaunchKernelGGL((attn_bf16x3_kernel<2>), grid, dim3(128), 0, s, p);
+        else hipLaunchKernelGGL((attn_bf16x3_kernel<2, false>), grid, dim3(128), 0, s, p);
     } else {
         dim3 grid(cdiv(p.n_q, 128), problems);
         if (d.precision == 0) hipLaunchKernelGGL((attn_kernel<4>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((attn_bf16x3_kernel<4>), grid, dim3(256), 0, s, p);
+        else if (attn_nw8()) {
+            dim3 grid8(cdiv(p.n_q, 256), problems);
+            hipLaunchKernelGGL((attn_bf16x3_kernel<8, true>), grid8, dim3(512), 0, s, p);
+        } else hipLaunchKernelGGL((attn_bf16x3_kernel<4, true>), grid, dim3(256), 0, s, p);
     }
     return fgt_check_launch("attn_kernel");
 }

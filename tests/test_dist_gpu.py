@@ -29,7 +29,7 @@ def _worker(rank, world, port, q):
     from fgt_amd.scheduler import ClipRunner
     m, fr, fl, ms = _clip_and_model()
     comp = ClipRunner(m, fr, fl, ms, rank=rank, world=world).run()
-    q.put((rank, comp.cpu()))
+    q.put((rank, comp.cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -41,7 +41,7 @@ def test_two_ranks_on_one_gpu_match_single_rank():
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
-    res = dict(q.get(timeout=600) for _ in range(world))
+    res = {r: torch.from_numpy(a) for r, a in (q.get(timeout=600) for _ in range(world))}
     [p.join(timeout=120) for p in procs]
     m, fr, fl, ms = _clip_and_model()
     single = ClipRunner(m, fr, fl, ms).run().cpu()

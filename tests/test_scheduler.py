@@ -55,7 +55,7 @@ def _worker(rank, world, port, n, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     fr, fl, ms = clip(n)
     got = ClipRunner(None, fr, fl, ms, forward=cheap_forward, rank=rank, world=world).run()
-    q.put((rank, got))
+    q.put((rank, got.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,7 +67,7 @@ def test_window_sharding_two_ranks_gloo(n):
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     [p.start() for p in procs]
-    res = dict(q.get(timeout=120) for _ in range(world))
+    res = {r: torch.from_numpy(a) for r, a in (q.get(timeout=120) for _ in range(world))}
     [p.join(timeout=60) for p in procs]
     fr, fl, ms = clip(n)
     ref = O.fgt_clip(None, None, fr, fl, ms, forward=cheap_forward)

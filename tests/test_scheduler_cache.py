@@ -49,7 +49,7 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     m, sd, fr, fl, ms = _setup()
-    q.put((rank, ClipRunner(m, fr, fl, ms, rank=rank, world=world, cache_features=True).run()))
+    q.put((rank, ClipRunner(m, fr, fl, ms, rank=rank, world=world, cache_features=True).run().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,7 +60,7 @@ def test_frame_sharded_encode_and_window_sharding_two_ranks():
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
-    res = dict(q.get(timeout=300) for _ in range(world))
+    res = {r: torch.from_numpy(a) for r, a in (q.get(timeout=300) for _ in range(world))}
     [p.join(timeout=60) for p in procs]
     real_ops, real_pc = fgt_model.ops, fgt_model.PackedConv
     try:
