@@ -89,6 +89,8 @@ def main():
                     help="arithmetic of the conv/GEMM and attention kernels: exact fp32 MFMA, or fp32 operands split into hi/lo "
                          "bf16 with 3 bf16 MFMAs per product and fp32 accumulation (FGT max |diff| vs reference 1.6e-6, bar 1e-3)")
     ap.add_argument("--no-cache", action="store_true", help="recompute the per-frame encoders in every window like the reference")
+    ap.add_argument("--graphs", action="store_true", help="replay each window's launch sequence as a hipGraph (the roofline block is "
+                                                          "then measured on one extra eager step after the timed region)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,7 +127,7 @@ def main():
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
     frames, flows, masks = synth_clip(args.frames, args.height, args.width, seed=1234, device=dev)
-    runner = ClipRunner(model, frames, flows, masks, rank=rank, world=world, cache_features=not args.no_cache)
+    runner = ClipRunner(model, frames, flows, masks, rank=rank, world=world, cache_features=not args.no_cache, use_graphs=args.graphs)
 
     def barrier():
         torch.cuda.synchronize()
@@ -149,8 +151,16 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if not args.no_prof:
+        if args.graphs:     # graph replays bypass the per-launch events: measure the same kernels on one eager step
+            ops.prof_collect()
+            runner.use_graphs = False
+            runner.run()
+            torch.cuda.synchronize()
+            runner.use_graphs = True
         ops.prof_enable(False)
         k_ms, k_flops, k_launches = ops.prof_collect()
+        if args.graphs:
+            k_ms, k_flops, k_launches = k_ms * args.steps, k_flops * args.steps, k_launches * args.steps
     tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -169,7 +179,7 @@ def main():
             "config": {"workload": f"full FGT forward, random (N(0,0.02)) weights, {args.width}x{args.height}x{args.frames} clip, "
                                    f"reference window schedule (neighbor_stride 5, step 10; sum t = {sum(len(a) + len(b) for a, b in runner.sched)})",
                        "windows": len(runner.sched), "sharding": f"windows round-robin over {world} rank(s)",
-                       "conv_precision": prec, "per_frame_feature_cache": bool(runner.cache_features)},
+                       "conv_precision": prec, "per_frame_feature_cache": bool(runner.cache_features), "hip_graphs": bool(args.graphs)},
         }
         out["host_enqueue_ms_per_step"] = round(1e3 * host_dt / args.steps, 3)
         if clip_flops:

@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_bf16x3_kernel(const AttnP p) 
 }
 
 bool attn_nw8() {
-    static const int v = [] { const char* e = getenv("FGT_ATTN_NW8"); return e ? atoi(e) : 0; }();
+    static const int v = [] { const char* e = getenv("FGT_ATTN_NW8"); return e ? atoi(e) : 1; }();
     return v != 0;
 }
 
@@ -485,7 +485,7 @@ extern "C" int fgt_attention(const fgt_attn_desc* dd, const float* Q, const floa
     } else {
         dim3 grid(cdiv(p.n_q, 128), problems);
         if (d.precision == 0) hipLaunchKernelGGL((attn_kernel<4>), grid, dim3(256), 0, s, p);
-        else if (attn_nw8()) {
+        else if (attn_nw8() && p.n_q >= 2048) {   // long zones: 8 wavefronts share each K/V tile (345 vs 375 us at t = 17)
             dim3 grid8(cdiv(p.n_q, 256), problems);
             hipLaunchKernelGGL((attn_bf16x3_kernel<8, true>), grid8, dim3(512), 0, s, p);
         } else hipLaunchKernelGGL((attn_bf16x3_kernel<4, true>), grid, dim3(256), 0, s, p);

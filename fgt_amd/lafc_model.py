@@ -7,6 +7,8 @@ The T frames of a clip window are a batch of channels-last images: a (1,k,k) Con
 T images, a (3,1,1) Conv3d is the same kernel run with "height" = T and "width" = H*W (kernel 3x1), so the whole P3D
 net runs on fgt_conv2d with fused LeakyReLU / residual / nearest-x2 / skip-concat (two-source) epilogues.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -86,6 +88,8 @@ class P3DNet(nn.Module):
         self.decoder = nn.ModuleList([Deconv2d(nf * 4, nf, 3, g, b), Block2d(nf, nf // 2, 3, g, b), Block2d(nf // 2, 2, 3, g, b)])
         self.edgeDetector = EdgeParams(g)
         self._packed, self._key = None, None
+        self.use_graph = os.environ.get("FGT_GRAPHS", "0") == "1"
+        self._graphs = None
 
     # ---- packing
     def _pk(self, blk, temporal=False):
@@ -143,6 +147,11 @@ class P3DNet(nn.Module):
 
     def forward(self, flows, masks, edges=None):
         with torch.no_grad():
+            if self.use_graph and edges is None and flows.is_cuda:
+                from .graph import GraphCache
+                if self._graphs is None:
+                    self._graphs = GraphCache(lambda a, b: self._forward(a, b, None))
+                return tuple(o.clone() for o in self._graphs(flows.float(), masks.float()))
             return self._forward(flows, masks, edges)
 
     def _forward(self, flows, masks, edges):

@@ -407,8 +407,17 @@ def compose_blend(out_nchw, ids, first, frames01, masks, comp):
     return comp
 
 
+_prof_on = False
+
+
 def prof_enable(on):
+    global _prof_on
+    _prof_on = bool(on)
     _lib.lib().fgt_prof_enable(int(on))
+
+
+def prof_is_enabled():
+    return _prof_on
 
 
 def prof_collect():

@@ -9,6 +9,8 @@ Feature / context encoders, the all-pairs correlation GEMM, the motion encoder, 
 the gate blend fused into conv epilogues, `cat([h, x])` read as two sources), flow/mask heads: fgt_conv2d.  Instance
 norm, correlation pyramid pooling, the 4-level 9x9 bilinear lookup and convex up-sampling: dedicated HBM-bound kernels.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -117,6 +119,8 @@ class RAFT(nn.Module):
         self.cnet = EncoderParams(256, "batch")
         self.update_block = UpdateBlockParams(self.corr_levels * (2 * self.corr_radius + 1) ** 2)
         self._packed, self._key = None, None
+        self.use_graph = os.environ.get("FGT_GRAPHS", "0") == "1"
+        self._graphs = {}
 
     # ------------------------------------------------------------------ packing
     @staticmethod
@@ -170,6 +174,14 @@ class RAFT(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=False):
         with torch.no_grad():
+            if self.use_graph and flow_init is None and image1.is_cuda:
+                # ~40 launches per GRU iteration: replay the whole pair as one hipGraph (fgt_amd/graph.py)
+                from .graph import GraphCache
+                key = (iters, bool(test_mode))
+                if key not in self._graphs:
+                    self._graphs[key] = GraphCache(lambda a, b: self._forward(a, b, iters, None, test_mode))
+                out = self._graphs[key](image1.float(), image2.float())
+                return tuple(o.clone() for o in out) if isinstance(out, tuple) else [o.clone() for o in out]
             return self._forward(image1, image2, iters, flow_init, test_mode)
 
     def _forward(self, image1, image2, iters, flow_init, test_mode):

@@ -67,7 +67,7 @@ def compose_torch(out, nb, frames01, masks, comp, visited):
 
 class ClipRunner:
     def __init__(self, model, frames01, flows_normed, masks, neighbor_stride=5, ref_length=10, num_ref=-1,
-                 rank=0, world=1, forward=None, group=None, cache_features=None, encode_chunk=20):
+                 rank=0, world=1, forward=None, group=None, cache_features=None, encode_chunk=20, use_graphs=None):
         self.model = model
         self.frames01, self.flows, self.masks = frames01, flows_normed, masks
         self.n = frames01.shape[1]
@@ -96,6 +96,9 @@ class ClipRunner:
         can_cache = forward is None and hasattr(net, "encode_frames")
         self.cache_features = can_cache if cache_features is None else (cache_features and can_cache)
         self.encode_chunk = encode_chunk
+        # hipGraph replay of the per-window launch sequence (one graph per window length t), only with the feature cache
+        self.use_graphs = (self.on_gpu and self.cache_features) if use_graphs is None else (use_graphs and self.on_gpu and self.cache_features)
+        self._graphs = None
 
     def run_window(self, wi):
         ids = self._ids[wi]
@@ -138,12 +141,30 @@ class ClipRunner:
         enc, tok, ftok, th, tw = feats
         ids = self._ids[wi]
         t = ids.numel()
-        out = self.model.net.transform_decode(enc[ids].contiguous(), tok[ids].reshape(t * th * tw, -1),
-                                              ftok[ids].reshape(t * th * tw, -1), 1, t, th, tw)
-        return out[: len(self.sched[wi][0])]
+        e, x, f = enc[ids].contiguous(), tok[ids].reshape(t * th * tw, -1), ftok[ids].reshape(t * th * tw, -1)
+        nb = len(self.sched[wi][0])
+        if self.use_graphs:
+            if self._graphs is None:
+                from .graph import GraphCache
+                net = self.model.net
+                self._graphs = GraphCache(lambda e_, x_, f_: net.transform_decode(e_, x_, f_, 1, e_.shape[0], th, tw))
+            out = self._graphs(e, x, f)[:nb]
+            return out.clone() if self.world > 1 else out     # the static output buffer is reused by the next window of this length
+        return self.model.net.transform_decode(e, x, f, 1, t, th, tw)[:nb]
 
     def run(self):
         """One pass over the clip.  Returns comp [N,H,W,3] fp32 (0..255 scale, before the final astype(uint8))."""
+        comp = torch.empty(self.n, self.H, self.W, 3, dtype=torch.float32, device=self.dev)
+        if self.on_gpu and self.world == 1:
+            # single rank: windows run in ascending order, so each one is composed as soon as it is produced
+            # (its output buffer may be a graph-static buffer that the next window of the same length overwrites)
+            f01, mk = self.frames01[0].contiguous(), self.masks[0].contiguous()
+            with torch.no_grad():
+                feats = self.encode_clip() if self.cache_features else None
+                for wi in range(len(self.sched)):
+                    out = self.run_window_cached(wi, feats) if self.cache_features else self.run_window(wi)
+                    ops.compose_blend(out, self._nb[wi], self._first[wi], f01, mk, comp)
+            return comp
         if self.cache_features:
             with torch.no_grad():
                 feats = self.encode_clip()
@@ -152,7 +173,6 @@ class ClipRunner:
             outs = {wi: self.run_window(wi) for wi in self.mine}
         if self.world > 1:
             outs = self._exchange(outs)
-        comp = torch.empty(self.n, self.H, self.W, 3, dtype=torch.float32, device=self.dev)
         if self.on_gpu:
             f01 = self.frames01[0].contiguous()
             mk = self.masks[0].contiguous()
