@@ -1,0 +1,33 @@
+"""Clip-level RAFT driver (tool/video_inpainting.py:233-288, `calculate_flow`) restructured for the MI355X — SURVEY §8f rank 2.
+
+The reference calls RAFT once per adjacent pair and direction: 2(N-1) calls of batch 1, every frame is pushed through the
+feature encoder up to 4 times and through the context encoder twice, and at 432x240 a pair is only 1620 query pixels
+(13 M-tiles of work per conv: the GPU is mostly idle).  Here
+  * fnet / cnet run ONCE per frame (InstanceNorm is per sample and BatchNorm is in eval mode, so this is exact),
+  * pairs are processed `batch` at a time (forward and backward pairs in the same batch), which fills the machine.
+Outputs are the reference's per-pair `flow_up` fields in its order.
+"""
+import torch
+
+
+def compute_flows(raft, frames, iters=20, batch=8, enc_batch=16):
+    """frames [N,3,H,W] in 0..255 (H, W multiples of 8) -> (forward [N-1,2,H,W], backward [N-1,2,H,W]).
+    forward[i] = RAFT(frame i, frame i+1), backward[i] = RAFT(frame i+1, frame i)  (tool/video_inpainting.py:246-263)."""
+    N = frames.shape[0]
+    with torch.no_grad():
+        fm, cm = [], []
+        for s in range(0, N, enc_batch):
+            packed = raft.pack_images(frames[s:s + enc_batch])
+            fm.append(raft.encode_features(packed))
+            cm.append(raft.encode_context(packed))
+        fmap, cmap = torch.cat(fm, 0), torch.cat(cm, 0)
+        i1 = list(range(0, N - 1)) + list(range(1, N))          # forward pairs then backward pairs
+        i2 = list(range(1, N)) + list(range(0, N - 1))
+        ups = []
+        for s in range(0, len(i1), batch):
+            a = torch.tensor(i1[s:s + batch], device=frames.device)
+            b = torch.tensor(i2[s:s + batch], device=frames.device)
+            _, up = raft.iterate(fmap[a], fmap[b], cmap[a], iters=iters, test_mode=True)
+            ups.append(up)
+        up = torch.cat(ups, 0)
+        return up[: N - 1], up[N - 1:]

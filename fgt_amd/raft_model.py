@@ -184,30 +184,47 @@ class RAFT(nn.Module):
                 return tuple(o.clone() for o in out) if isinstance(out, tuple) else [o.clone() for o in out]
             return self._forward(image1, image2, iters, flow_init, test_mode)
 
-    def _forward(self, image1, image2, iters, flow_init, test_mode):
-        P = self.packed()
-        B, _, H, W = image1.shape
+    def pack_images(self, images):
+        """[B,3,H,W] in 0..255 -> channels-last 2*(x/255)-1 with a zero 4th channel (raft.py:90-94)."""
+        B, _, H, W = images.shape
         if H % 8 or W % 8:
             raise ValueError("RAFT needs H, W divisible by 8 (use InputPadder as the reference does)")
-        dev = image1.device
-        h8, w8 = H // 8, W // 8
-        # 2 * (x / 255) - 1, packed channels-last with a zero 4th channel (raft.py:90-94)
-        imgs = torch.empty(2 * B, H, W, 4, dtype=torch.float32, device=dev)
-        ops.nchw_to_nhwc(image1.float(), imgs[:B], coff=0, zero_to=4, scale=2.0 / 255.0, shift=-1.0)
-        ops.nchw_to_nhwc(image2.float(), imgs[B:], coff=0, zero_to=4, scale=2.0 / 255.0, shift=-1.0)
-        fmap = self._encode(imgs, P["fnet"], instance=True)                        # [2B, h8, w8, 256]
+        out = torch.empty(B, H, W, 4, dtype=torch.float32, device=images.device)
+        ops.nchw_to_nhwc(images.float(), out, coff=0, zero_to=4, scale=2.0 / 255.0, shift=-1.0)
+        return out
+
+    def encode_features(self, packed):
+        """fnet (InstanceNorm: per-sample, so any batching of frames is exact) -> [B, H/8, W/8, 256]."""
+        return self._encode(packed, self.packed()["fnet"], instance=True)
+
+    def encode_context(self, packed):
+        """cnet (BatchNorm in eval mode) -> [B, H/8, W/8, 256] (tanh/relu split applied by iterate)."""
+        return self._encode(packed, self.packed()["cnet"], instance=False)
+
+    def _forward(self, image1, image2, iters, flow_init, test_mode):
+        B = image1.shape[0]
+        imgs = torch.cat([self.pack_images(image1), self.pack_images(image2)], 0)
+        fmap = self.encode_features(imgs)                                          # [2B, h8, w8, 256]
+        cmap = self.encode_context(imgs[:B])                                       # [B, h8, w8, 256]
+        return self.iterate(fmap[:B], fmap[B:], cmap, iters, flow_init, test_mode)
+
+    def iterate(self, fmap1, fmap2, cmap, iters=12, flow_init=None, test_mode=True):
+        """Correlation volume + pyramid, then the GRU refinement loop (raft.py:102-143) from precomputed features."""
+        P = self.packed()
+        B, h8, w8, _ = fmap1.shape
+        dev = fmap1.device
         # all-pairs correlation volume (corr.py:52-60) as a GEMM against fmap2, then the avg-pool pyramid
         n = h8 * w8
         vol = torch.empty(B * n, n, dtype=torch.float32, device=dev)
         for b in range(B):
-            pc = PackedConv(fmap[B + b].reshape(n, 256), None)
-            ops.linear(fmap[b].reshape(n, 256), pc, out=vol[b * n:(b + 1) * n], out_scale=1.0 / 16.0)
+            pc = PackedConv(fmap2[b].reshape(n, 256), None)
+            ops.linear(fmap1[b].reshape(n, 256), pc, out=vol[b * n:(b + 1) * n], out_scale=1.0 / 16.0)
         pyr = [vol]
         hh, ww = h8, w8
         for _ in range(self.corr_levels - 1):
             pyr.append(ops.avgpool2(pyr[-1], B * n, hh, ww))
             hh, ww = hh // 2, ww // 2
-        cmap = self._encode(imgs[:B], P["cnet"], instance=False)                   # [B, h8, w8, 256]
+        cmap = cmap.contiguous()
         net = ops.axpby(cmap.view(B * n, 256)[:, :128], act="tanh")                # raft.py:112-115
         xbuf = torch.empty(B * n, 256, dtype=torch.float32, device=dev)            # [inp | motion(126) | flow(2)]
         ops.axpby(cmap.view(B * n, 256)[:, 128:], act="relu", out=xbuf[:, :128])

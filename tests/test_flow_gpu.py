@@ -111,3 +111,19 @@ def test_raft_helper_kernels(dev):
     ref = F.relu(F.relu(F.instance_norm(x)) + res)
     out = ops.instnorm(x.permute(0, 2, 3, 1).contiguous().to(dev), act="relu", res=res.permute(0, 2, 3, 1).contiguous().to(dev), act2="relu")
     assert report("instnorm", out.permute(0, 3, 1, 2), ref)[0] < 1e-4
+
+
+def test_flow_pipeline_batched_pairs_match_per_pair_calls_gpu(dev):
+    from fgt_amd import flow_pipeline
+    m = raft_model.RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).eval()
+    m.load_state_dict(_sd("raft_state_keys.json"), strict=True)
+    m = m.to(dev)
+    g = load_golden("raft_128x160_it6.npz")
+    frames = torch.cat([g["image1"], g["image2"], g["image1"].flip(-1), g["image2"].flip(-2)], 0).to(dev)
+    fw, bw = flow_pipeline.compute_flows(m, frames, iters=6, batch=4, enc_batch=3)
+    assert report("flow pipeline fwd[0] vs reference golden", fw[0:1], g["flow_up"])[1] < 1e-3
+    for i in range(3):
+        a = m(frames[i:i + 1], frames[i + 1:i + 2], iters=6, test_mode=True)[1]
+        b = m(frames[i + 1:i + 2], frames[i:i + 1], iters=6, test_mode=True)[1]
+        assert report(f"flow pipeline fwd[{i}] vs per-pair call", fw[i:i + 1], a)[1] < 1e-4
+        assert report(f"flow pipeline bwd[{i}] vs per-pair call", bw[i:i + 1], b)[1] < 1e-4

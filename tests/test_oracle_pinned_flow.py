@@ -83,3 +83,17 @@ def test_flow_oracles_match_live_reference():
     iw, fb = RL.warp_fns()
     img, f = torch.randn(1, 3, 20, 28, generator=g), torch.randn(1, 2, 20, 28, generator=g) * 2
     assert max_err(iw(img, f), RO.image_warp(img, f)) == 0
+
+
+def test_flow_pipeline_batched_pairs_match_per_pair_calls(fake):
+    """fgt_amd.flow_pipeline.compute_flows (per-frame encoder cache + batched pairs) == per-pair RAFT calls in the
+    reference's order (tool/video_inpainting.py:246-263), on the CPU kernel spec."""
+    from fgt_amd import flow_pipeline
+    m = raft_model.RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).eval()
+    m.load_state_dict(_sd("raft_state_keys.json"), strict=True)
+    g = load_golden("raft_128x160_it6.npz")
+    frames = torch.cat([g["image1"], g["image2"], g["image1"].flip(-1)], 0)
+    fw, bw = flow_pipeline.compute_flows(m, frames, iters=3, batch=3, enc_batch=2)
+    for i in range(2):
+        assert rel_err(fw[i:i + 1], m(frames[i:i + 1], frames[i + 1:i + 2], iters=3, test_mode=True)[1]) < 1e-5
+        assert rel_err(bw[i:i + 1], m(frames[i + 1:i + 2], frames[i:i + 1], iters=3, test_mode=True)[1]) < 1e-5

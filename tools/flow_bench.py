@@ -63,6 +63,14 @@ def main():
         i1, i2 = base[:, :, 4:4 + H, 4:4 + W].contiguous().to(dev), base[:, :, 3:3 + H, 6:6 + W].contiguous().to(dev)
         t = timed(lambda: r(i1, i2, iters=20, test_mode=True), 5)
         out.append({"case": f"RAFT pair {W}x{H}, 20 iters", "ms": round(t * 1e3, 3), "tflops_algorithmic": round(gf * 1e9 / t / 1e12, 2), "precision": a.precision})
+    # ---- clip-level RAFT: per-frame encoder cache + batched pairs (fgt_amd/flow_pipeline.py), 16 frames = 30 pairs
+    from fgt_amd import flow_pipeline
+    for (H, W, gf) in ((240, 432, 245.7), (480, 864, 998.9)):
+        frames = torch.nn.functional.interpolate(torch.rand(16, 3, H // 8, W // 8, generator=g), size=(H, W), mode="bilinear").to(dev) * 255
+        for bsz in (1, 8):
+            t = timed(lambda: flow_pipeline.compute_flows(r, frames, iters=20, batch=bsz), 2)
+            out.append({"case": f"RAFT clip pipeline {W}x{H}, 16 frames (30 pairs), pair batch {bsz}", "ms_per_pair": round(t * 1e3 / 30, 3),
+                        "tflops_algorithmic_vs_reference_count": round(30 * gf * 1e9 / t / 1e12, 2), "precision": a.precision})
     # ---- one FGT window of BASELINE config #5: 864x480, t = 26
     from fgt_amd.fgt_model import DEFAULT_CONFIG, Model
     f = Model(dict(DEFAULT_CONFIG)).eval()
