@@ -31,3 +31,36 @@ def compute_flows(raft, frames, iters=20, batch=8, enc_batch=16):
             ups.append(up)
         up = torch.cat(ups, 0)
         return up[: N - 1], up[N - 1:]
+
+
+def indices_gen(pivot, interval, frames, t):
+    """tool/video_inpainting.py:90-100: reflect-indexed temporal neighbourhood of `pivot`."""
+    out = []
+    for i in range(-(frames // 2), frames // 2 + 1):
+        idx = pivot + interval * i
+        if idx < 0:
+            idx = abs(idx)
+        if idx > t - 1:
+            idx = 2 * (t - 1) - idx
+        out.append(idx)
+    return out
+
+
+def complete_flows(lafc, flows, masks, diffused, num_flows=3, interval=3, batch=8):
+    """The LAFC loop of tool/video_inpainting.py:367-384 with `batch` pivots per LAFC call.
+    flows, diffused [1,2,t,H,W]; masks [1,1,t,H,W] (already sliced for the direction, :350-353).  Returns [t,2,H,W]:
+    completed flow inside the mask, the known flow outside (`output * pivot_mask + pivot_flow * (1 - pivot_mask)`)."""
+    t = diffused.shape[2]
+    pivot = num_flows // 2
+    idx = torch.tensor([indices_gen(i, interval, num_flows, t) for i in range(t)], device=flows.device)    # [t, num_flows]
+    out = []
+    with torch.no_grad():
+        for s in range(0, t, batch):
+            ii = idx[s:s + batch]                                            # [b, num_flows]
+            inp = diffused[0][:, ii].permute(1, 0, 2, 3, 4)                   # [b, 2, num_flows, H, W]
+            cm = masks[0][:, ii].permute(1, 0, 2, 3, 4)                       # [b, 1, num_flows, H, W]
+            flow = lafc(inp.contiguous(), cm.contiguous())[0]                 # [b, 2, H, W]
+            pm = cm[:, :, pivot]
+            pf = flows[0][:, ii[:, pivot]].permute(1, 0, 2, 3)
+            out.append(flow * pm + pf * (1 - pm))
+    return torch.cat(out, 0)

@@ -97,3 +97,24 @@ def test_flow_pipeline_batched_pairs_match_per_pair_calls(fake):
     for i in range(2):
         assert rel_err(fw[i:i + 1], m(frames[i:i + 1], frames[i + 1:i + 2], iters=3, test_mode=True)[1]) < 1e-5
         assert rel_err(bw[i:i + 1], m(frames[i + 1:i + 2], frames[i:i + 1], iters=3, test_mode=True)[1]) < 1e-5
+
+
+def test_complete_flows_batched_matches_reference_loop(fake):
+    """fgt_amd.flow_pipeline.complete_flows == the per-pivot loop of tool/video_inpainting.py:367-384 (run with the oracle)."""
+    from fgt_amd import flow_pipeline
+    cfg = lafc_model.DEFAULT_CONFIG
+    sd = _sd("lafc_vanilla_state_keys.json")
+    m = lafc_model.Model(dict(cfg)).eval()
+    m.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(4)
+    t, H, W = 7, 32, 48
+    flows = torch.randn(1, 2, t, H, W, generator=g)
+    masks = (torch.rand(1, 1, t, H, W, generator=g) > 0.6).float()
+    diffused = flows * (1 - masks)
+    got = flow_pipeline.complete_flows(m, flows, masks, diffused, batch=3)
+    for i in range(t):
+        ind = LO.indices_gen(i, 3, 3, t)
+        assert ind == flow_pipeline.indices_gen(i, 3, 3, t)
+        o = LO.lafc_forward(sd, cfg, diffused[:, :, ind], masks[:, :, ind])[0]
+        ref = o * masks[:, :, ind][:, :, 1] + flows[:, :, ind][:, :, 1] * (1 - masks[:, :, ind][:, :, 1])
+        assert rel_err(got[i:i + 1], ref) < 2e-5

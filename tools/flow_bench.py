@@ -71,6 +71,13 @@ def main():
             t = timed(lambda: flow_pipeline.compute_flows(r, frames, iters=20, batch=bsz), 2)
             out.append({"case": f"RAFT clip pipeline {W}x{H}, 16 frames (30 pairs), pair batch {bsz}", "ms_per_pair": round(t * 1e3 / 30, 3),
                         "tflops_algorithmic_vs_reference_count": round(30 * gf * 1e9 / t / 1e12, 2), "precision": a.precision})
+    # ---- clip-level LAFC: batched pivots (fgt_amd/flow_pipeline.complete_flows), 32 flows at 240x432
+    flows32 = torch.randn(1, 2, 32, 240, 432, generator=g).to(dev)
+    masks32 = (torch.rand(1, 1, 32, 240, 432, generator=g) > 0.8).float().to(dev)
+    for bsz in (1, 8):
+        t = timed(lambda: flow_pipeline.complete_flows(m, flows32, masks32, flows32 * (1 - masks32), batch=bsz), 2)
+        out.append({"case": f"LAFC clip pipeline 432x240, 32 flows, pivot batch {bsz}", "ms_per_flow": round(t * 1e3 / 32, 3),
+                    "tflops_algorithmic": round(32 * 130.2e9 / t / 1e12, 2), "precision": a.precision})
     # ---- one FGT window of BASELINE config #5: 864x480, t = 26
     from fgt_amd.fgt_model import DEFAULT_CONFIG, Model
     f = Model(dict(DEFAULT_CONFIG)).eval()
