@@ -415,6 +415,7 @@ int launch_tile(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_256x128: return launch<256, 128, 4, 2, PREC>(p, s);
         case FGT_TILE_128x128x8: return launch<128, 128, 2, 4, PREC, 4>(p, s);   // 8 wavefronts of 64x32, <= 128 VGPRs: 4 waves/SIMD
         case FGT_TILE_256x128x16: return launch<256, 128, 4, 4, PREC, 4>(p, s); // 16 wavefronts of 64x32
+        case FGT_TILE_256x64x8: return launch<256, 64, 4, 2, PREC, 2>(p, s);     // Cout = 64 layers: 8 wavefronts of 64x32
         default: fgt_set_error("fgt_conv2d: unknown tile %d", tile); return FGT_EINVAL;
     }
 }

@@ -391,8 +391,10 @@ class FGT(nn.Module):
         th, tw = tok.shape[1], tok.shape[2]
         return enc, tok.view(bt * th * tw, -1), ftok.view(bt * th * tw, -1), th, tw
 
-    def transform_decode(self, enc, x, f, b, t, th, tw):
-        """model.py:272-283 given per-frame features."""
+    def transform_decode(self, enc, x, f, b, t, th, tw, n_out=None):
+        """model.py:272-283 given per-frame features.  `n_out` (b == 1 only): soft composition + decoder run for the first
+        n_out frames only — the tool discards the decoded reference frames (tool/video_inpainting.py:727: only
+        `range(len(neighbor_ids))` is read) and both stages are per-frame, so the kept frames are unchanged."""
         P = self.packed()
         cfg = self.cfg
         bt = b * t
@@ -404,6 +406,10 @@ class FGT(nn.Module):
         for pt, ps in P["blocks"]:
             x = self._temporal(x, pt, b, t, th, tw, Hf, Wf)
             x = self._spatial(x, f, ps, bt, th, tw, Hf, Wf)
+        if n_out is not None and n_out < bt:
+            assert b == 1, "n_out needs a single clip (frames of one batch element are contiguous)"
+            bt = n_out
+            x, enc = x[: bt * th * tw], enc[:bt]
         Y = ops.linear(x, P["v2p"])
         feat = ops.fold(Y, bt, th, tw, P["v2p_c"], cfg["k"][0], cfg["s"][0], cfg["p"][0], Hf, Wf, normalize=False, res=enc)
         D = P["dec"]

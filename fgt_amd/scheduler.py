@@ -147,10 +147,11 @@ class ClipRunner:
             if self._graphs is None:
                 from .graph import GraphCache
                 net = self.model.net
-                self._graphs = GraphCache(lambda e_, x_, f_: net.transform_decode(e_, x_, f_, 1, e_.shape[0], th, tw))
-            out = self._graphs(e, x, f)[:nb]
+                # the neighbour count travels as the SHAPE of a dummy tensor: graphs are cached per input-shape signature
+                self._graphs = GraphCache(lambda e_, x_, f_, n_: net.transform_decode(e_, x_, f_, 1, e_.shape[0], th, tw, n_out=n_.shape[0]))
+            out = self._graphs(e, x, f, torch.empty(nb, device=self.dev))[:nb]
             return out.clone() if self.world > 1 else out     # the static output buffer is reused by the next window of this length
-        return self.model.net.transform_decode(e, x, f, 1, t, th, tw)[:nb]
+        return self.model.net.transform_decode(e, x, f, 1, t, th, tw, n_out=nb)
 
     def run(self):
         """One pass over the clip.  Returns comp [N,H,W,3] fp32 (0..255 scale, before the final astype(uint8))."""
