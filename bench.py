@@ -42,7 +42,7 @@ def conv_traffic(prec):
     return t.get(prec, {}).get("hbm_bytes_per_launch")
 
 
-def cpu_baseline(cfg, sd, frames, flows, masks, sched):
+def cpu_baseline(cfg, sd, frames, flows, masks, sched, model=None):
     """Oracle (PyTorch-CPU port of the reference path) on a bounded sample of the same workload: the first window
     (t = 13) of the schedule, after choosing the intra-op thread count that runs a 2-frame probe fastest (a 256-thread
     pool on a 256-core host is ~8x slower than 32 threads for these conv sizes)."""
@@ -64,11 +64,19 @@ def cpu_baseline(cfg, sd, frames, flows, masks, sched):
             best, best_dt = th, dt
     torch.set_num_threads(best)
     t0 = time.perf_counter()
-    O.fgt_forward(sd, cfg, mf, fl, m)
+    ref = O.fgt_forward(sd, cfg, mf, fl, m)
     dt = time.perf_counter() - t0
     total = sum(fgt_flops(len(a) + len(b)) for a, b in sched)
     est_clip_s = dt * total / fgt_flops(len(ids))
-    return {"value": round(frames.shape[1] / est_clip_s, 4), "unit": "frames/s", "cores": best, "host_cores": ncpu,
+    parity = None
+    if model is not None:      # "PSNR vs ref" of the metric: the same window through the HIP path vs the oracle's output
+        dev = frames.device
+        got = model(mf.to(dev), fl.to(dev), m.to(dev)).cpu()
+        u8 = lambda x: ((x + 1) / 2 * 255).clamp(0, 255).to(torch.uint8).float()
+        parity = {"window": 0, "frames": len(ids), "max_abs_diff": float((got - ref).abs().max()),
+                  "ref_max_abs": float(ref.abs().max()), "psnr_db_uint8": round(O.psnr(u8(got), u8(ref)), 2),
+                  "note": "HIP path (bench precision) vs CPU oracle on window 0; PSNR per FGT/metrics/psnr.py:5-9 on clip((x+1)/2*255) uint8 frames (100 = identical)"}
+    return parity, {"value": round(frames.shape[1] / est_clip_s, 4), "unit": "frames/s", "cores": best, "host_cores": ncpu,
             "kind": "port",
             "sample": f"oracle fgt_forward on window 0 (t={len(ids)}) at {frames.shape[-1]}x{frames.shape[-2]} in {dt:.2f} s with {best} threads "
                       f"(fastest of a 2-frame probe); clip time extrapolated by F(t)=147.03t+1.0618t^2 GFLOP over the "
@@ -195,7 +203,7 @@ def main():
                                "launches": k_launches, "kernel_ms_per_step": round(k_ms / args.steps, 3),
                                "share_of_step": round(k_ms / (1e3 * dt), 3)}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, frames, flows, masks, runner.sched)
+            out["parity_vs_cpu_oracle"], out["cpu_baseline"] = cpu_baseline(cfg, sd, frames, flows, masks, runner.sched, model)
         # sanity on the produced clip (finite, in range) so a broken run cannot report a number silently
         c = comp.float()
         out["output_checksum"] = round(float(c.double().mean()), 6)      # identical for every N (same clip, exact sharding)
