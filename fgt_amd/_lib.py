@@ -22,7 +22,8 @@ class ConvDesc(C.Structure):
                [("slope", C.c_float)] + \
                [(n, C.c_int) for n in ("epi", "act2", "ld_aux1", "ld_aux2")] + \
                [("out_scale", C.c_float)] + \
-               [(n, C.c_int) for n in ("Kpad", "Npad", "tile", "precision")]
+               [(n, C.c_int) for n in ("Kpad", "Npad", "tile", "precision", "in_split", "out_split", "ldo_s", "ooff_s")] + \
+               [(n, C.c_longlong) for n in ("ps0", "ps1", "pso")]
 
 
 class AttnDesc(C.Structure):
@@ -39,7 +40,8 @@ _F = C.c_float
 SIGNATURES = {
     "fgt_last_error": [],
     "fgt_abi_version": [],
-    "fgt_conv2d": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "fgt_conv2d": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "fgt_split": [_P, _L, _I, _I, _P, _I, C.c_longlong, _I, _P],
     "fgt_layernorm": [_P, _I, _I, _P, _I, _I, _L, _F, _P, _P, _P, _I, _P, _P, _P, _I, _P],
     "fgt_attention": [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P],
     "fgt_dw_pool": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfgt_hip.so")
-SOURCES = ["runtime.hip", "conv_igemm.hip", "conv_direct.hip", "attention.hip", "pointwise.hip", "flow_ops.hip"]
+SOURCES = ["runtime.hip", "conv_igemm.hip", "conv_split.hip", "conv_direct.hip", "attention.hip", "pointwise.hip", "flow_ops.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
@@ -30,7 +30,7 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(HERE, "..", "include", "fgt_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(CSRC, "conv_tile.h"), os.path.join(HERE, "..", "include", "fgt_hip.h")]
     hipcc = _hipcc()
     jobs = []
     objs = []

@@ -38,3 +38,18 @@ __device__ __forceinline__ float fgt_act(float v, int act, float slope) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// hi/lo split of a float4 run: packed bf16 {hi0,hi1},{hi2,hi3} and {lo0,lo1},{lo2,lo3} with hi = bf16_rne(x),
+// lo = bf16_rne(x - hi) (one v_cvt_pk_bf16_f32 per pair).  THE definition of the split format: every producer uses it.
+typedef __bf16 fgt_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float fgt_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fgt_split4(const float4 v, uint2& hi, uint2& lo) {
+    const fgt_f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+    const unsigned ha = __builtin_bit_cast(unsigned, __builtin_convertvector(a, fgt_bf16x2));
+    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(b, fgt_bf16x2));
+    const fgt_f32x2 la = {v.x - __builtin_bit_cast(float, ha << 16), v.y - __builtin_bit_cast(float, ha & 0xFFFF0000u)};
+    const fgt_f32x2 lb = {v.z - __builtin_bit_cast(float, hb << 16), v.w - __builtin_bit_cast(float, hb & 0xFFFF0000u)};
+    hi = make_uint2(ha, hb);
+    lo = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(la, fgt_bf16x2)),
+                    __builtin_bit_cast(unsigned, __builtin_convertvector(lb, fgt_bf16x2)));
+}

@@ -22,35 +22,9 @@
 #include "common.h"
 #include "conv_params.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#include "conv_tile.h"
 
 namespace {
-
-
-constexpr int BK = 32;
-constexpr int LDS_LD = 33;
-
-constexpr int LDB = 32;  // bf16 elements per LDS row in bf16x3 mode: 64-byte rows, no padding.
-// The four 16-byte slots of a row are XOR-swizzled with (row >> 2) & 3: the 16 rows of a ds_read_b128 lane group then
-// cover all 16 slots of the 256-byte bank line (conflict free) and the 8-byte stores of two adjacent rows never share a
-// bank either.  (The 80-byte padded layout it replaces had 2-way store conflicts: SQ_LDS_BANK_CONFLICT = 33 % of
-// SQ_LDS_IDX_ACTIVE in profiles/r01_run4_pmc_*.json.)
-__device__ __forceinline__ int swz(int row, int slot) { return (slot ^ ((row >> 2) & 3)) * 8; }
-
-// hi/lo split of a float4 run: returns packed bf16 {hi0,hi1},{hi2,hi3} and {lo0,lo1},{lo2,lo3}
-__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
-    const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
-    const unsigned ha = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));
-    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2));
-    const f32x2 la = {v.x - __builtin_bit_cast(float, ha << 16), v.y - __builtin_bit_cast(float, ha & 0xFFFF0000u)};
-    const f32x2 lb = {v.z - __builtin_bit_cast(float, hb << 16), v.w - __builtin_bit_cast(float, hb & 0xFFFF0000u)};
-    hi = make_uint2(ha, hb);
-    lo = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(la, bf16x2)),
-                    __builtin_bit_cast(unsigned, __builtin_convertvector(lb, bf16x2)));
-}
 
 template <int BM, int BN, int WM, int WN, int PREC, int MINW>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_igemm_kernel(const ConvP p) {
@@ -67,20 +41,8 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_igemm_kernel(const Con
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int q = tid & 7, r = tid >> 3;
-    // XCD-aware tile order.  Workgroup L is dispatched to XCD L % 8 (each XCD has a private 4 MiB L2).  Every XCD walks
-    // its own contiguous range of M tiles with the N tiles of one M tile adjacent in time, so the im2col re-reads
-    // (kh*kw taps x N tiles of the same input rows) hit that XCD's L2 instead of going back to HBM.  xcd_swizzle = 0
-    // keeps the plain (m fastest) order for A/B measurements.
     int m_idx, n_idx;
-    if (p.xcd_swizzle) {
-        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-        n_idx = i % p.ntiles;
-        m_idx = xcd * p.mchunk + i / p.ntiles;
-        if (m_idx >= p.mtiles) return;
-    } else {
-        m_idx = blockIdx.x % p.mtiles;
-        n_idx = blockIdx.x / p.mtiles;
-    }
+    if (!conv_tile_index(p, m_idx, n_idx)) return;
     const int bm0 = m_idx * BM, bn0 = n_idx * BN, g = blockIdx.y;
 
     // ---- per-thread im2col row state (fixed over the K loop)
@@ -318,68 +280,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_igemm_kernel(const Con
     }
     }
 
-    // ---- epilogue.  The accumulators go through LDS (the tile buffers are free now) so that the
-    // global side is a compact, coalesced float4 loop shared by every epilogue flavour.
-    // C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-    constexpr int EP_PASSES = (BM * BN > 2 * STAGE) ? ((BM * BN > 4 * STAGE) ? 4 : 2) : 1;
-    constexpr int EP_BM = BM / EP_PASSES;
-    constexpr int WM_PER_PASS = WM / EP_PASSES;
-    static_assert(EP_BM * BN <= 2 * STAGE && WM % EP_PASSES == 0, "epilogue staging does not fit in the tile buffers");
-    float* Cs = smem;
-    const bool vec_ok = (p.Cout_g % 4 == 0) && !d.out_nchw && (d.ldo % 4 == 0) && (d.ooff % 4 == 0) &&
-                        (d.epi == FGT_EPI_NONE || d.ld_aux1 % 4 == 0) && (d.epi != FGT_EPI_GRU || d.ld_aux2 % 4 == 0);
-#pragma unroll
-    for (int ps = 0; ps < EP_PASSES; ++ps) {
-        if (ps > 0) __syncthreads();
-        if (wm / WM_PER_PASS == ps) {
-            const int wml = wm % WM_PER_PASS;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        Cs[(wml * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * BN + wn * WTN + j * 32 + l31] = acc[i][j][e];
-        }
-        __syncthreads();
-        const int mbase = bm0 + ps * EP_BM;
-        for (int idx = tid; idx < EP_BM * (BN / 4); idx += NT) {
-            const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
-            const int m = mbase + row;
-            const int n = bn0 + c4 * 4;
-            if (m >= p.M || n >= p.Cout_g) continue;
-            const float4 cv = *reinterpret_cast<const float4*>(Cs + row * BN + c4 * 4);
-            float v[4] = {cv.x, cv.y, cv.z, cv.w};
-            const int co = g * p.Cout_g + n;
-            const int nvalid = min(4, p.Cout_g - n);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (u < nvalid) {
-                    const float cs = p.cscale ? p.cscale[co + u] : 1.f;
-                    const float cb = p.cbias ? p.cbias[co + u] : 0.f;
-                    float x = fgt_act(v[u] * cs + cb, d.act, d.slope) * d.out_scale;
-                    if (d.epi == FGT_EPI_MUL) {
-                        x *= p.aux1[(long)m * d.ld_aux1 + co + u];
-                    } else if (d.epi == FGT_EPI_ADD) {
-                        x = fgt_act(x + p.aux1[(long)m * d.ld_aux1 + co + u], d.act2, d.slope);
-                    } else if (d.epi == FGT_EPI_GRU) {
-                        const float z = p.aux1[(long)m * d.ld_aux1 + co + u];
-                        const float hh = p.aux2[(long)m * d.ld_aux2 + co + u];
-                        x = (1.f - z) * hh + z * x;
-                    }
-                    v[u] = x;
-                }
-            }
-            if (vec_ok) {
-                *reinterpret_cast<float4*>(p.out + (long)m * d.ldo + d.ooff + co) = make_float4(v[0], v[1], v[2], v[3]);
-            } else if (d.out_nchw) {
-                const int n_img = m / p.HoWo, rem = m - n_img * p.HoWo;
-                for (int u = 0; u < nvalid; ++u) p.out[((long)n_img * d.Cout + co + u) * p.HoWo + rem] = v[u];
-            } else {
-                for (int u = 0; u < nvalid; ++u) p.out[(long)m * d.ldo + d.ooff + co + u] = v[u];
-            }
-        }
-    }
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
 }
 
 template <int BM, int BN, int WM, int WN, int PREC, int MINW = 2>
@@ -451,10 +352,12 @@ extern "C" int fgt_prof_collect(double* total_ms, double* total_flops, long* lau
     return FGT_OK;
 }
 
-extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const float* x0, const float* x1, const float* w_packed,
+extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* x1v, const float* w_packed,
                           const float* cscale, const float* cbias, const float* aux1, const float* aux2,
-                          float* out, void* stream) {
-    FGT_REQUIRE(dd && x0 && w_packed && out, "fgt_conv2d: null pointer");
+                          float* out, void* out_s, void* stream) {
+    FGT_REQUIRE(dd && x0v && w_packed, "fgt_conv2d: null pointer");
+    const float* x0 = static_cast<const float*>(x0v);
+    const float* x1 = static_cast<const float*>(x1v);
     ConvP p;
     p.d = *dd;
     const fgt_conv_desc& d = p.d;
@@ -462,9 +365,26 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const float* x0, const float*
     FGT_REQUIRE(d.C0 > 0 && d.C0 % d.groups == 0 && d.C1 % d.groups == 0 && d.Cout % d.groups == 0,
                 "fgt_conv2d: channels (%d,%d,%d) not divisible by groups %d", d.C0, d.C1, d.Cout, d.groups);
     p.Cg0 = d.C0 / d.groups; p.Cg1 = d.C1 / d.groups; p.Cg = p.Cg0 + p.Cg1; p.Cout_g = d.Cout / d.groups;
-    FGT_REQUIRE(p.Cg0 % 4 == 0 && p.Cg1 % 4 == 0, "fgt_conv2d: per-group channels (%d,%d) must be multiples of 4 (pad the tensor)", p.Cg0, p.Cg1);
-    FGT_REQUIRE(d.ld0 % 4 == 0 && d.off0 % 4 == 0 && (d.C1 == 0 || (x1 && d.ld1 % 4 == 0 && d.off1 % 4 == 0)),
-                "fgt_conv2d: source strides/offsets must be multiples of 4 floats");
+    const int gran = d.in_split ? 8 : 4;    // elements per 16-byte gather
+    FGT_REQUIRE(d.in_split == 0 || d.in_split == 1, "fgt_conv2d: in_split must be 0 or 1");
+    FGT_REQUIRE(p.Cg0 % gran == 0 && p.Cg1 % gran == 0, "fgt_conv2d: per-group channels (%d,%d) must be multiples of %d (pad the tensor)", p.Cg0, p.Cg1, gran);
+    FGT_REQUIRE(d.ld0 % gran == 0 && d.off0 % gran == 0 && (d.C1 == 0 || (x1 && d.ld1 % gran == 0 && d.off1 % gran == 0)),
+                "fgt_conv2d: source strides/offsets must be multiples of %d elements", gran);
+    if (d.in_split) {
+        FGT_REQUIRE(d.precision == FGT_PREC_BF16X3, "fgt_conv2d: split inputs need FGT_PREC_BF16X3");
+        FGT_REQUIRE(d.in_relu == 0, "fgt_conv2d: in_relu cannot be applied to split inputs (the producer applies it)");
+        FGT_REQUIRE(d.ps0 % 8 == 0 && d.ps0 > 0 && (d.C1 == 0 || (d.ps1 % 8 == 0 && d.ps1 > 0)), "fgt_conv2d: plane strides must be positive multiples of 8");
+    }
+    FGT_REQUIRE(d.out_split >= 0 && d.out_split <= 2, "fgt_conv2d: out_split must be 0, 1 or 2");
+    FGT_REQUIRE(d.out_split == 1 || out != nullptr, "fgt_conv2d: null output");
+    if (d.out_split) {
+        FGT_REQUIRE(out_s != nullptr && ((uintptr_t)out_s & 7) == 0, "fgt_conv2d: out_split needs an 8-byte aligned out_s");
+        FGT_REQUIRE(p.Cout_g % 4 == 0 && !d.out_nchw && d.ldo_s % 4 == 0 && d.ooff_s % 4 == 0 && d.pso % 4 == 0 && d.pso > 0,
+                    "fgt_conv2d: out_split needs Cout/groups, ldo_s, ooff_s, pso multiples of 4 and NHWC output");
+        FGT_REQUIRE(d.out_split == 1 || (d.ldo % 4 == 0 && d.ooff % 4 == 0), "fgt_conv2d: out_split = 2 needs ldo, ooff multiples of 4");
+        FGT_REQUIRE(d.epi == FGT_EPI_NONE || d.ld_aux1 % 4 == 0, "fgt_conv2d: out_split needs ld_aux1 % 4 == 0");
+        FGT_REQUIRE(d.epi != FGT_EPI_GRU || d.ld_aux2 % 4 == 0, "fgt_conv2d: out_split needs ld_aux2 % 4 == 0");
+    }
     FGT_REQUIRE(((uintptr_t)x0 & 15) == 0 && ((uintptr_t)x1 & 15) == 0 && ((uintptr_t)w_packed & 15) == 0,
                 "fgt_conv2d: pointers must be 16-byte aligned");
     FGT_REQUIRE(d.kh > 0 && d.kw > 0 && d.sh > 0 && d.sw > 0 && d.dh > 0 && d.dw > 0 && d.ph >= 0 && d.pw >= 0, "fgt_conv2d: bad kernel geometry");
@@ -487,6 +407,7 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const float* x0, const float*
     p.zero_page = fgt_zero_page();
     FGT_REQUIRE(p.zero_page != nullptr, "fgt_conv2d: could not allocate the zero page");
     p.x0 = x0; p.x1 = x1 ? x1 : x0; p.w = w_packed; p.cscale = cscale; p.cbias = cbias; p.aux1 = aux1; p.aux2 = aux2; p.out = out;
+    p.out_s = static_cast<__bf16*>(out_s); p.pso = d.pso; p.ps0 = d.ps0; p.ps1 = d.C1 ? d.ps1 : d.ps0;
 
     int tile = d.tile;
     if (tile == 0) {
@@ -500,7 +421,7 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const float* x0, const float*
     }
     hipStream_t s = (hipStream_t)stream;
     ProfRec rec{};
-    const bool direct = d.tile == 0 && d.precision == 0 && fgt_conv_direct_eligible(p);
+    const bool direct = d.tile == 0 && d.precision == 0 && d.out_split == 0 && fgt_conv_direct_eligible(p);
     const bool prof = g_prof_on && !direct;   // the roofline block is about the MFMA kernel only
     if (prof) {
         rec.a = get_event(); rec.b = get_event();
@@ -510,6 +431,7 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const float* x0, const float*
     FGT_REQUIRE(d.precision == 0 || d.precision == 1, "fgt_conv2d: unknown precision %d", d.precision);
     int rc;
     if (direct) rc = fgt_conv_direct(p, s);   // Cout <= 4: VALU direct conv (fp32)
+    else if (d.in_split) rc = fgt_conv_split_launch(tile, p, s);
     else rc = d.precision == 0 ? launch_tile<0>(tile, p, s) : launch_tile<1>(tile, p, s);
     if (prof) {
         hipEventRecord(rec.b, s);

@@ -6,6 +6,8 @@ struct ConvP {
     fgt_conv_desc d;
     const float *x0, *x1, *w, *cscale, *cbias, *aux1, *aux2;
     float* out;
+    __bf16* out_s;            // split output (desc.out_split), plane stride pso
+    long pso, ps0, ps1;       // plane strides in bf16 elements
     int M, HoWo, Cg0, Cg1, Cg, K, Cout_g, Hin, Win, nk;
     const float* zero_page;   // 256 zero bytes in device memory: target of out-of-range gathers
     int mtiles, ntiles, mchunk, xcd_swizzle;   // tile grid and XCD-aware ordering (set by the launcher)
@@ -14,6 +16,9 @@ struct ConvP {
 
 // runtime.hip: one 256-byte zero-filled device allocation, created on first use (the only memory the library owns)
 const float* fgt_zero_page();
+
+// conv_split.hip: bf16x3 with pre-split inputs moved global -> LDS by LDS-DMA
+int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s);
 
 // conv_direct.hip
 bool fgt_conv_direct_eligible(const ConvP& p);

@@ -1,0 +1,254 @@
+// bf16x3 implicit-GEMM convolution / GEMM with PRE-SPLIT operands, fed by LDS-DMA (gfx950).
+//
+// Same math as conv_igemm.hip's FGT_PREC_BF16X3 path (hi/lo bf16 operands, three v_mfma_f32_32x32x16_bf16 per product in the
+// same order, fp32 accumulate: results are bit-identical), different data movement.  The activations arrive already split
+// (desc.in_split: two bf16 planes, written once by their producer), the weights are pre-split at pack time, so a K-step's
+// tiles are plain 16-byte copies.  Every wavefront moves them global -> LDS with global_load_lds_dwordx4: no staging
+// registers, no conversion VALU work, no ds_write pass, and (for a 3x3 conv with 4 N tiles) a value that used to be split 36
+// times is split once.  What the register-staged kernel spends on the loader (16 staging VGPRs + ~40 VALU per K-step per
+// wavefront at the 128-VGPR occupancy step) goes to holding both k-halves' MFMA fragments at once instead.
+//
+// LDS image of one stage (identical to conv_igemm.hip): [A_hi | A_lo | B_hi | B_lo], rows of 32 bf16 (64 bytes), the four
+// 16-byte slots of row r XOR-swizzled with (r >> 2) & 3.  An LDS-DMA instruction writes lane l's 16 bytes at
+// M0 + 16*l, i.e. one instruction fills 16 consecutive rows of one plane (row = l >> 2, slot = l & 3); the swizzle is applied
+// on the SOURCE side: lane l fetches the k-chunk (l & 3) ^ ((l >> 4) & 3) of its row.  Out-of-image taps and the K tail read
+// the library's zero page (select on the address).
+//
+// Pipeline: two LDS stages; tile kt+1's DMAs are issued at the top of step kt and land while the 12-24 MFMAs of the step
+// run; `s_waitcnt vmcnt(0)` + one barrier per K-step publishes them (the reads of a stage happen strictly after the
+// barrier that follows the wait, as the LDS-DMA ordering rule requires).
+#include "conv_tile.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN, int MINW, bool PIN>
+__global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const ConvP p) {
+    constexpr int NW = WM * WN;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    constexpr int STAGE = (BM + BN) * LDB;              // floats per stage (= (BM+BN) * 64 bf16 = hi + lo planes)
+    constexpr int GA = BM / 16, GB = BN / 16;           // 16-row DMA groups per plane
+    constexpr int A_IT = GA / NW;                       // A groups per wavefront
+    constexpr int B_IT = (GB + NW - 1) / NW;            // B groups per wavefront (the last may be absent)
+    static_assert(GA % NW == 0 && A_IT >= 1 && TM >= 1 && TN >= 1, "tile / wavefront geometry");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const fgt_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int m_idx, n_idx;
+    if (!conv_tile_index(p, m_idx, n_idx)) return;
+    const int bm0 = m_idx * BM, bn0 = n_idx * BN, g = blockIdx.y;
+
+    const __bf16* const x0 = reinterpret_cast<const __bf16*>(p.x0);
+    const __bf16* const x1 = reinterpret_cast<const __bf16*>(p.x1);
+    const __bf16* const zp = reinterpret_cast<const __bf16*>(p.zero_page);
+    // (copied out of the kernel-argument struct: a select between two struct fields would otherwise be compiled as a
+    //  select between their ADDRESSES followed by a vector load from the argument segment, i.e. a vmcnt(0) in the loop)
+    const int ld0 = d.ld0, ld1 = d.ld1;
+    const int chb0 = d.off0 + g * p.Cg0, chb1 = d.off1 + g * p.Cg1 - p.Cg0;
+    const long ps0 = p.ps0, ps1 = p.ps1;
+    const int Cg0 = p.Cg0, Cg = p.Cg;
+
+    // ---- this lane's DMA rows: row (lane >> 2) of each of its 16-row groups, k-chunk kc of every K-step
+    const int lrow = lane >> 2;
+    const int kc = (lane & 3) ^ ((lane >> 4) & 3);      // swizzle on the source side (all groups start at multiples of 16 rows)
+    int a_iy0[A_IT], a_ix0[A_IT], a_nb[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int m = bm0 + (wave + it * NW) * 16 + lrow;
+        if (m < p.M) {
+            const int n_img = m / p.HoWo, rem = m - n_img * p.HoWo;
+            const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
+            a_iy0[it] = oy * d.sh - d.ph;
+            a_ix0[it] = ox * d.sw - d.pw;
+            a_nb[it] = n_img * d.H * d.W;
+        } else {
+            a_iy0[it] = 0; a_ix0[it] = 0; a_nb[it] = -1;
+        }
+    }
+    int k_cur = kc * 8;
+    int tap = k_cur / p.Cg;
+    int ci = k_cur - tap * p.Cg;
+    int ky = tap / d.kw, kx = tap - ky * d.kw;
+
+    // per-row gather bases for the current (tap, source); recomputed only when the chunk moves to another tap / source
+    const __bf16* a_base[A_IT];
+    unsigned a_okmask = 0;
+    int seg_end = 0;
+    long a_ps = 0;
+    auto retap = [&]() {
+        const bool in0 = ci < Cg0;
+        const __bf16* src = in0 ? x0 : x1;
+        const int ld = in0 ? ld0 : ld1;
+        const int chb = in0 ? chb0 : chb1;   // channel = chb + ci
+        a_ps = in0 ? ps0 : ps1;
+        seg_end = in0 ? Cg0 : Cg;
+        const int dy = ky * d.dh, dx = kx * d.dw;
+        const int ush = d.upsample ? 1 : 0;
+        const bool rep = d.pad_mode != 0;
+        a_okmask = 0;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int iy = a_iy0[it] + dy, ix = a_ix0[it] + dx;
+            const int cy = min(max(iy, 0), p.Hin - 1), cx = min(max(ix, 0), p.Win - 1);
+            iy = rep ? cy : iy;
+            ix = rep ? cx : ix;
+            const bool ok = a_nb[it] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            a_okmask |= (ok ? 1u : 0u) << it;
+            a_base[it] = src + ((long)(a_nb[it] + (iy >> ush) * d.W + (ix >> ush)) * ld + chb);
+        }
+    };
+    retap();
+
+    // weights: [2][groups][Npad][Kpad] bf16
+    const __bf16* wrow[B_IT];
+    const long w_ps = (long)d.groups * d.Npad * d.Kpad;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+        wrow[it] = reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + bn0 + (wave + it * NW) * 16 + lrow) * d.Kpad + kc * 8;
+
+    char* const lds = reinterpret_cast<char*>(smem);
+    constexpr int STAGE_B = STAGE * 4;
+    auto issue_tile = [&](int buf) {
+        char* st = lds + buf * STAGE_B;
+        const bool kval = k_cur < p.K;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const bool ok = kval && ((a_okmask >> it) & 1u);
+            const __bf16* src = a_base[it] + ci;
+            char* dst = st + (wave + it * NW) * 1024;
+            glds16(ok ? src : zp, dst);                          // A_hi rows
+            glds16(ok ? src + a_ps : zp, dst + BM * 64);         // A_lo rows
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            if (GB % NW == 0 || wave + it * NW < GB) {           // wave-uniform
+                char* dst = st + 2 * BM * 64 + (wave + it * NW) * 1024;
+                glds16(wrow[it], dst);                           // B_hi
+                glds16(wrow[it] + w_ps, dst + BN * 64);          // B_lo
+            }
+            wrow[it] += BK;
+        }
+        k_cur += BK;
+        ci += BK;
+        if (ci >= seg_end) {
+            while (ci >= Cg) {
+                ci -= Cg;
+                if (++kx == d.kw) { kx = 0; ++ky; }
+            }
+            retap();
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    issue_tile(0);
+    __syncthreads();            // (emits s_waitcnt vmcnt(0): the DMAs are LDS writes in flight)
+    for (int kt = 0; kt < p.nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < p.nk) issue_tile(buf ^ 1);
+        const __bf16* base = reinterpret_cast<const __bf16*>(smem + buf * STAGE);
+        // operand rows: wave-tile base (multiple of 32) + l31, so (row >> 2) & 3 == (l31 >> 2) & 3 for every fragment
+        bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int so = swz(l31, ks * 2 + lh);
+            const __bf16* Ahi = base + (wm * WTM + l31) * LDB + so;
+            const __bf16* Bhi = base + 2 * BM * LDB + (wn * WTN + l31) * LDB + so;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[ks][i] = *reinterpret_cast<const bf16x8*>(Ahi + i * 32 * LDB);
+                al[ks][i] = *reinterpret_cast<const bf16x8*>(Ahi + BM * LDB + i * 32 * LDB);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[ks][j] = *reinterpret_cast<const bf16x8*>(Bhi + j * 32 * LDB);
+                bl[ks][j] = *reinterpret_cast<const bf16x8*>(Bhi + BN * LDB + j * 32 * LDB);
+            }
+        }
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);   // keep all fragment reads of the step ahead of its MFMAs
+        // same product order as conv_igemm.hip (lo*hi, hi*lo, hi*hi per k-half): bit-identical accumulators
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+        }
+        // (the barrier and its vmcnt(0) must stay BEHIND the MFMAs: hoisted above them, the DMA latency of tile kt+1 is exposed
+        //  in front of this wavefront's matrix work instead of running underneath it)
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
+}
+
+template <int BM, int BN, int WM, int WN, int MINW, bool PIN>
+int launch_pin(const ConvP& p, hipStream_t s) {
+    constexpr int NT = WM * WN * 64;
+    constexpr size_t smem = 2ul * (BM + BN) * LDB * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, PIN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            fgt_set_error("hipFuncSetAttribute(conv_split %dx%d): %s", BM, BN, hipGetErrorString(e));
+            return FGT_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    ConvP q = p;
+    q.mtiles = cdiv(p.M, BM);
+    q.ntiles = cdiv(p.Cout_g, BN);
+    q.mchunk = cdiv(q.mtiles, 8);
+    dim3 grid(q.xcd_swizzle ? 8 * q.mchunk * q.ntiles : q.mtiles * q.ntiles, p.d.groups);
+    hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, MINW, PIN>), grid, dim3(NT), smem, s, q);
+    return fgt_check_launch("conv_split");
+}
+
+template <int BM, int BN, int WM, int WN, int MINW = 2>
+int launch(const ConvP& p, hipStream_t s) {
+    // p.pipe (FGT_CONV_PIPE, default 1): 1 = fragment reads pinned ahead of the MFMAs, 0 = the compiler's own interleave
+    return p.pipe ? launch_pin<BM, BN, WM, WN, MINW, true>(p, s) : launch_pin<BM, BN, WM, WN, MINW, false>(p, s);
+}
+
+}  // namespace
+
+int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s) {
+    switch (tile) {
+        case FGT_TILE_128x128: return launch<128, 128, 2, 2>(p, s);
+        case FGT_TILE_128x64: return launch<128, 64, 2, 2>(p, s);
+        case FGT_TILE_64x64: return launch<64, 64, 2, 2>(p, s);
+        case FGT_TILE_128x32: return launch<128, 32, 4, 1>(p, s);
+        case FGT_TILE_256x128: return launch<256, 128, 4, 2>(p, s);
+        case FGT_TILE_128x128x8: return launch<128, 128, 2, 4, 4>(p, s);
+        case FGT_TILE_256x128x16: return launch<256, 128, 4, 4, 4>(p, s);
+        case FGT_TILE_256x64x8: return launch<256, 64, 4, 2, 2>(p, s);
+        default: fgt_set_error("fgt_conv2d: unknown tile %d", tile); return FGT_EINVAL;
+    }
+}

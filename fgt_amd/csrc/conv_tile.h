@@ -1,0 +1,125 @@
+// Pieces shared by the implicit-GEMM kernels (conv_igemm.hip: register-staged fp32 inputs; conv_split.hip: pre-split bf16
+// inputs through LDS-DMA): LDS tile geometry, the hi/lo split, the XCD-aware tile order and the fused epilogue.
+#pragma once
+#include "common.h"
+#include "conv_params.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDS_LD = 33;
+
+constexpr int LDB = 32;  // bf16 elements per LDS row in bf16x3 mode: 64-byte rows, no padding.
+// The four 16-byte slots of a row are XOR-swizzled with (row >> 2) & 3: the 16 rows of a ds_read_b128 lane group then
+// cover all 16 slots of the 256-byte bank line (conflict free) and the 8-byte stores of two adjacent rows never share a
+// bank either.  (The 80-byte padded layout it replaces had 2-way store conflicts: SQ_LDS_BANK_CONFLICT = 33 % of
+// SQ_LDS_IDX_ACTIVE in profiles/r01_run4_pmc_*.json.)
+__device__ __forceinline__ int swz(int row, int slot) { return (slot ^ ((row >> 2) & 3)) * 8; }
+
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) { fgt_split4(v, hi, lo); }
+
+// XCD-aware tile order.  Workgroup L is dispatched to XCD L % 8 (each XCD has a private 4 MiB L2).  Every XCD walks
+// its own contiguous range of M tiles with the N tiles of one M tile adjacent in time, so the im2col re-reads
+// (kh*kw taps x N tiles of the same input rows) hit that XCD's L2 instead of going back to HBM.  xcd_swizzle = 0
+// keeps the plain (m fastest) order for A/B measurements.  Returns false for the padding blocks of the last chunk.
+__device__ __forceinline__ bool conv_tile_index(const ConvP& p, int& m_idx, int& n_idx) {
+    if (p.xcd_swizzle) {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        n_idx = i % p.ntiles;
+        m_idx = xcd * p.mchunk + i / p.ntiles;
+        return m_idx < p.mtiles;
+    }
+    m_idx = blockIdx.x % p.mtiles;
+    n_idx = blockIdx.x / p.mtiles;
+    return true;
+}
+
+// ---- epilogue.  The accumulators go through LDS (the tile buffers are free now) so that the global side is a compact,
+// coalesced float4 loop shared by every epilogue flavour: bias / per-channel scale, activation, mul / add / GRU combine,
+// then the fp32 store (NHWC slice or NCHW) and / or the pre-split bf16 store (desc.out_split) the next conv's LDS-DMA
+// loader consumes.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+// STAGE = floats per LDS stage; the caller guarantees 2 stages are allocated and no longer in use.
+template <int BM, int BN, int WM, int WN, int STAGE, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], float* smem, int bm0, int bn0, int g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    static_assert(TM == WTM / 32 && TN == WTN / 32, "accumulator shape");
+    constexpr int EP_PASSES = (BM * BN > 2 * STAGE) ? ((BM * BN > 4 * STAGE) ? 4 : 2) : 1;
+    constexpr int EP_BM = BM / EP_PASSES;
+    constexpr int WM_PER_PASS = WM / EP_PASSES;
+    static_assert(EP_BM * BN <= 2 * STAGE && WM % EP_PASSES == 0, "epilogue staging does not fit in the tile buffers");
+    const fgt_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    float* Cs = smem;
+    const bool vec_ok = (p.Cout_g % 4 == 0) && !d.out_nchw && (d.ldo % 4 == 0) && (d.ooff % 4 == 0) &&
+                        (d.epi == FGT_EPI_NONE || d.ld_aux1 % 4 == 0) && (d.epi != FGT_EPI_GRU || d.ld_aux2 % 4 == 0);
+    const bool want_f32 = d.out_split != 1, want_split = d.out_split != 0;
+#pragma unroll
+    for (int ps = 0; ps < EP_PASSES; ++ps) {
+        if (ps > 0) __syncthreads();
+        if (wm / WM_PER_PASS == ps) {
+            const int wml = wm % WM_PER_PASS;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        Cs[(wml * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * BN + wn * WTN + j * 32 + l31] = acc[i][j][e];
+        }
+        __syncthreads();
+        const int mbase = bm0 + ps * EP_BM;
+        for (int idx = tid; idx < EP_BM * (BN / 4); idx += NT) {
+            const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
+            const int m = mbase + row;
+            const int n = bn0 + c4 * 4;
+            if (m >= p.M || n >= p.Cout_g) continue;
+            const float4 cv = *reinterpret_cast<const float4*>(Cs + row * BN + c4 * 4);
+            float v[4] = {cv.x, cv.y, cv.z, cv.w};
+            const int co = g * p.Cout_g + n;
+            const int nvalid = min(4, p.Cout_g - n);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u < nvalid) {
+                    const float cs = p.cscale ? p.cscale[co + u] : 1.f;
+                    const float cb = p.cbias ? p.cbias[co + u] : 0.f;
+                    float x = fgt_act(v[u] * cs + cb, d.act, d.slope) * d.out_scale;
+                    if (d.epi == FGT_EPI_MUL) {
+                        x *= p.aux1[(long)m * d.ld_aux1 + co + u];
+                    } else if (d.epi == FGT_EPI_ADD) {
+                        x = fgt_act(x + p.aux1[(long)m * d.ld_aux1 + co + u], d.act2, d.slope);
+                    } else if (d.epi == FGT_EPI_GRU) {
+                        const float z = p.aux1[(long)m * d.ld_aux1 + co + u];
+                        const float hh = p.aux2[(long)m * d.ld_aux2 + co + u];
+                        x = (1.f - z) * hh + z * x;
+                    }
+                    v[u] = x;
+                }
+            }
+            if (vec_ok) {
+                if (want_f32) *reinterpret_cast<float4*>(p.out + (long)m * d.ldo + d.ooff + co) = make_float4(v[0], v[1], v[2], v[3]);
+                if (want_split) {       // validated by the host: vec_ok holds whenever out_split is set
+                    uint2 hi, lo;
+                    split4(make_float4(v[0], v[1], v[2], v[3]), hi, lo);
+                    __bf16* o = p.out_s + (long)m * d.ldo_s + d.ooff_s + co;
+                    *reinterpret_cast<uint2*>(o) = hi;
+                    *reinterpret_cast<uint2*>(o + p.pso) = lo;
+                }
+            } else if (d.out_nchw) {
+                const int n_img = m / p.HoWo, rem = m - n_img * p.HoWo;
+                for (int u = 0; u < nvalid; ++u) p.out[((long)n_img * d.Cout + co + u) * p.HoWo + rem] = v[u];
+            } else {
+                for (int u = 0; u < nvalid; ++u) p.out[(long)m * d.ldo + d.ooff + co + u] = v[u];
+            }
+        }
+    }
+}
+
+}  // namespace

@@ -231,6 +231,21 @@ inline int grid_for(long total, int block = 256) {
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
 }
 
+
+// fp32 -> split tensor (hi = bf16_rne(x), lo = bf16_rne(x - hi)); one float4 per thread
+__global__ void split_kernel(const float* __restrict__ x, long rows, int C4, int ldx, __bf16* __restrict__ out, int ld_s, long ps, int relu) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * C4) return;
+    const long r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    uint2 hi, lo;
+    fgt_split4(v, hi, lo);
+    __bf16* o = out + r * ld_s + c;
+    *reinterpret_cast<uint2*>(o) = hi;
+    *reinterpret_cast<uint2*>(o + ps) = lo;
+}
 }  // namespace
 
 extern "C" int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, long rows, float eps,
@@ -312,4 +327,13 @@ extern "C" int fgt_compose_blend(const float* out_nchw, const int* ids, const in
     hipLaunchKernelGGL(compose_kernel, dim3(grid_for((long)n * H * W)), dim3(256), 0, (hipStream_t)stream, out_nchw, ids, first, n,
                        frames01, masks, H, W, comp);
     return fgt_check_launch("compose_blend");
+}
+
+extern "C" int fgt_split(const float* x, long rows, int C, int ldx, void* out_s, int ld_s, long long ps, int relu, void* stream) {
+    FGT_REQUIRE(x && out_s && rows > 0 && C > 0, "fgt_split: bad arguments");
+    FGT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ld_s % 4 == 0 && ps % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out_s & 7) == 0,
+                "fgt_split: C, strides must be multiples of 4 and pointers aligned");
+    hipLaunchKernelGGL(split_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, rows, C / 4, ldx,
+                       static_cast<__bf16*>(out_s), ld_s, (long)ps, relu);
+    return fgt_check_launch("split");
 }

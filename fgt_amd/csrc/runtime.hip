@@ -12,7 +12,7 @@ void fgt_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* fgt_last_error(void) { return g_err; }
-extern "C" int fgt_abi_version(void) { return 1; }
+extern "C" int fgt_abi_version(void) { return 2; }
 
 const float* fgt_zero_page() {
     static float* zp = nullptr;

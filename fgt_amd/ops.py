@@ -62,7 +62,59 @@ def _require_dev(*ts):
             if not t.is_cuda:
                 raise RuntimeError("fgt_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
             if t.dtype != torch.float32:
-                raise RuntimeError(f"fgt_amd ops compute in fp32, got {t.dtype}")
+                raise RuntimeError(f"fgt_amd ops compute in fp32, got {t.dtype} (split bf16 operands travel as ops.Split)")
+
+
+class Split:
+    """A "split" activation tensor (include/fgt_hip.h, fgt_conv_desc.in_split): `data` is bf16 [2, *shape]; data[0] = hi =
+    bf16_rne(x), data[1] = lo = bf16_rne(x - hi) of the fp32 tensor `shape` it stands for.  Produced once by the kernel that
+    computes x (conv epilogue, layernorm, fold, attention, or ops.split), consumed by fgt_conv2d's LDS-DMA loader."""
+
+    def __init__(self, data):
+        assert data.dtype == torch.bfloat16 and data.shape[0] == 2 and data.is_cuda
+        self.data = data
+
+    @staticmethod
+    def empty(shape, device):
+        return Split(torch.empty((2,) + tuple(shape), dtype=torch.bfloat16, device=device))
+
+    @property
+    def shape(self):
+        return self.data.shape[1:]
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @property
+    def hi(self):
+        return self.data[0]
+
+    @property
+    def ps(self):
+        return self.data.stride(0)
+
+    def view(self, *shape):
+        return Split(self.data.view(2, *shape))
+
+    def __getitem__(self, idx):            # leading-dimension slices (rows / frames)
+        return Split(self.data[:, idx])
+
+    def float(self):
+        """hi + lo as fp32 (tests / debugging: 16 mantissa bits of the original)."""
+        return self.data[0].float() + self.data[1].float()
+
+
+def split(x, relu=False, out=None):
+    """fp32 [rows, C] / [N,H,W,C] -> Split (fgt_split)."""
+    _require_dev(x)
+    x4, N, H, W, Cc, ld = _as_map(x)
+    if out is None:
+        out = Split.empty(x.shape, x.device)
+    o4, oN, oH, oW, oC, ldo = _as_map(out.hi)
+    assert (oN * oH * oW, oC) == (N * H * W, Cc)
+    check(_lib.lib().fgt_split(_ptr(x4), N * H * W, Cc, ld, _ptr(out.data), ldo, out.ps, int(relu), _stream()), "fgt_split")
+    return out
 
 
 def _as_map(x):
@@ -129,9 +181,18 @@ def _split_weights(pc):
 
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
-           epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None):
-    """fgt_conv2d.  x (and optional x1) are channels-last maps; returns/outputs a channels-last map (or NCHW)."""
-    _require_dev(x, x1, aux1, aux2, out)
+           epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None,
+           out_split=None, out_s=None):
+    """fgt_conv2d.  x (and optional x1) are channels-last maps (fp32 tensors, or `Split`s for the LDS-DMA bf16x3 path);
+    returns/outputs a channels-last map (or NCHW).  out_split: None -> fp32 result; "only" -> a Split; "both" -> (fp32, Split)."""
+    in_split = isinstance(x, Split)
+    if in_split:
+        assert x1 is None or isinstance(x1, Split), "conv2d: both sources must be split"
+        xs, x1s = x, x1
+        x, x1 = xs.hi, (None if x1s is None else x1s.hi)
+    else:
+        _require_dev(x, x1)
+    _require_dev(aux1, aux2, out)
     x, N, H, W, C0, ld0 = _as_map(x)
     C1, ld1 = 0, 0
     if x1 is not None:
@@ -144,12 +205,13 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     Hin, Win = H * (2 if upsample else 1), W * (2 if upsample else 1)
     Ho = (Hin + 2 * ph - dh * (pc.kh - 1) - 1) // sh + 1
     Wo = (Win + 2 * pw - dw * (pc.kw - 1) - 1) // sw + 1
-    if out is None:
+    osp = {None: 0, False: 0, "only": 1, "both": 2}[out_split]
+    if out is None and osp != 1:
         out = torch.empty((N, pc.Cout, Ho, Wo) if out_nchw else (N, Ho, Wo, pc.Cout), dtype=torch.float32, device=x.device)
+    ldo = 0
     if out_nchw:
         assert out.is_contiguous() and tuple(out.shape) == (N, pc.Cout, Ho, Wo)
-        ldo = 0
-    else:
+    elif out is not None:
         o4, oN, oH, oW, oC, ldo = _as_map(out)
         assert (oN * oH * oW, oC) == (N * Ho * Wo, pc.Cout), f"conv2d: out shape {tuple(out.shape)} != {(N, Ho, Wo, pc.Cout)}"
     d = ConvDesc()
@@ -166,18 +228,32 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     d.out_scale = float(out_scale)
     d.Kpad, d.Npad, d.tile = pc.Kpad, pc.Npad, TILE[tile]
     d.precision = PREC[precision if precision is not None else DEFAULT_CONV_PRECISION]
-    if pc.Cout // pc.groups <= 4 and d.tile == 0:
+    if pc.Cout // pc.groups <= 4 and d.tile == 0 and not in_split and not osp:
         d.precision = 0                      # Cout <= 4 layers run the fp32 VALU direct-conv kernels
+    d.in_split = int(in_split)
+    if in_split:
+        if d.precision != PREC["bf16x3"]:
+            raise RuntimeError("conv2d: Split inputs need precision='bf16x3'")
+        d.ps0, d.ps1 = xs.ps, (0 if x1s is None else x1s.ps)
+    d.out_split = osp
+    if osp:
+        if out_s is None:
+            out_s = Split.empty((N, Ho, Wo, pc.Cout), x.device)
+        s4, sN, sH, sW, sC, ldo_s = _as_map(out_s.hi)
+        assert (sN * sH * sW, sC) == (N * Ho * Wo, pc.Cout), f"conv2d: out_s shape {tuple(out_s.shape)}"
+        d.ldo_s, d.ooff_s, d.pso = ldo_s, 0, out_s.ps
     wbuf = pc.w if d.precision == 0 else _split_weights(pc)
-    args = (C.byref(d), _ptr(x), _ptr(x1), _ptr(wbuf), _ptr(pc.scale), _ptr(pc.bias), _ptr(aux1), _ptr(aux2), _ptr(out))
+    args = (C.byref(d), _ptr(x), _ptr(x1), _ptr(wbuf), _ptr(pc.scale), _ptr(pc.bias), _ptr(aux1), _ptr(aux2), _ptr(out),
+            _ptr(None if out_s is None else out_s.data))
     if d.tile == 0 and AUTOTUNE and pc.Cout // pc.groups > 4:
-        key = (N, H, W, C0, C1, pc.Cout, pc.groups, pc.kh, pc.kw, sh, sw, ph, pw, dh, dw, d.upsample, d.epi, d.out_nchw, d.precision)
+        key = (N, H, W, C0, C1, pc.Cout, pc.groups, pc.kh, pc.kw, sh, sw, ph, pw, dh, dw, d.upsample, d.epi, d.out_nchw, d.precision,
+               d.in_split, d.out_split)
         best = _tile_cache.get(key)
         if best is None:
             best = _tile_cache[key] = _autotune(d, args)
         d.tile = best
     check(_lib.lib().fgt_conv2d(*args, _stream()), "fgt_conv2d")
-    return out
+    return {0: out, 1: out_s, 2: (out, out_s)}[osp]
 
 
 def _autotune(d, args):
@@ -202,15 +278,18 @@ def _autotune(d, args):
 
 
 def linear(x, pc, **kw):
-    """Linear on a [rows, C] token matrix (a 1x1 conv over a 1 x rows image)."""
+    """Linear on a [rows, C] token matrix (a 1x1 conv over a 1 x rows image).  x / x1 may be Splits; out_split as conv2d."""
     rows = x.shape[0]
     out = kw.pop("out", None)
-    if out is None:
+    osp = kw.get("out_split")
+    if out is None and osp != "only":
         out = torch.empty(rows, pc.Cout, dtype=torch.float32, device=x.device)
-    x1 = kw.pop("x1", None)
-    conv2d(x.unsqueeze(0).unsqueeze(0), pc, x1=None if x1 is None else x1.unsqueeze(0).unsqueeze(0),
-           out=out.unsqueeze(0).unsqueeze(0), **kw)
-    return out
+    out_s = kw.pop("out_s", None)
+    if osp and out_s is None:
+        out_s = Split.empty((rows, pc.Cout), x.device)
+    as_img = lambda t: None if t is None else (t.view(1, 1, *t.shape) if isinstance(t, Split) else t.unsqueeze(0).unsqueeze(0))
+    conv2d(as_img(x), pc, x1=as_img(kw.pop("x1", None)), out=as_img(out), out_s=as_img(out_s), **kw)
+    return {None: out, False: out, "only": out_s, "both": (out, out_s)}[osp]
 
 
 def layernorm(x0, gA, bA, x1=None, gB=None, bB=None, outA=None, outB=None, eps=1e-5):

@@ -83,7 +83,18 @@ typedef struct fgt_conv_desc {
     int precision;          /* FGT_PREC_FP32 (exact fp32 MFMA) | FGT_PREC_BF16X3 (hi/lo bf16 split, 3 MFMAs).
                              * With FGT_PREC_BF16X3 `w_packed` must be the PRE-SPLIT bf16 image of the packed weights:
                              * [2][groups][Npad][Kpad] bf16, plane 0 = hi = bf16_rne(w), plane 1 = lo = bf16_rne(w - hi)
-                             * (same byte count as the fp32 image).  Activations are split inside the kernel.      */
+                             * (same byte count as the fp32 image).                                                  */
+    /* "Split" activation tensors (FGT_PREC_BF16X3 only): two bf16 planes with the layout of the fp32 tensor they stand for,
+     * hi = bf16_rne(x) at the pointer and lo = bf16_rne(x - hi) `ps` ELEMENTS further (same bytes as fp32).  A producer
+     * splits each value once (conv epilogue, fgt_layernorm, fgt_fold, fgt_attention, fgt_split); a consumer conv then moves
+     * its im2col tiles global -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4) and does no conversion at all.        */
+    int in_split;           /* 0: x0/x1 are fp32 (split inside the kernel, per tile)
+                             * 1: x0/x1 point to split tensors; ld/off in bf16 elements; needs Cin/groups, ld, off % 8 == 0,
+                             *    in_relu == 0 (the producer applies it)                                                 */
+    int out_split;          /* 0: fp32 `out` only | 1: split `out_s` only | 2: both (needs Cout/groups, ldo_s, ooff_s % 4 == 0,
+                             *    out_nchw == 0)                                                                         */
+    int ldo_s, ooff_s;      /* row stride / first channel of out_s (bf16 elements)                                       */
+    long long ps0, ps1, pso;/* plane strides (bf16 elements) of x0, x1, out_s                                            */
 } fgt_conv_desc;
 
 #define FGT_PREC_FP32 0
@@ -98,9 +109,14 @@ typedef struct fgt_conv_desc {
 #define FGT_TILE_256x128x16 7  /* 256x128 tile on 16 wavefronts */
 #define FGT_TILE_256x64x8 8    /* 256x64 tile on 8 wavefronts (Cout = 64 layers) */
 
-int fgt_conv2d(const fgt_conv_desc* d, const float* x0, const float* x1, const float* w_packed,
+int fgt_conv2d(const fgt_conv_desc* d, const void* x0, const void* x1, const float* w_packed,
                const float* cscale /* [Cout] or NULL */, const float* cbias /* [Cout] or NULL */,
-               const float* aux1, const float* aux2, float* out, void* stream);
+               const float* aux1, const float* aux2, float* out /* NULL with out_split == 1 */,
+               void* out_s /* split output or NULL */, void* stream);
+
+/* fp32 [rows, C] (row stride ldx floats) -> split tensor (hi plane at out_s, lo plane `ps` bf16 elements further, row stride
+ * ld_s); relu = 1 applies max(x, 0) first.  For activations whose producer is not one of the fused ones.  C % 4 == 0. */
+int fgt_split(const float* x, long rows, int C, int ldx, void* out_s, int ld_s, long long ps, int relu, void* stream);
 
 /* Row LayerNorm over the concatenation [x0 | x1] (C1 = 0: single source), eps inside rsqrt.
  * Writes up to two outputs with different affine parameters from one pass over the row:

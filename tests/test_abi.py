@@ -25,19 +25,19 @@ def test_library_exports_every_symbol():
     h = ctypes.CDLL(_lib.LIB_PATH)
     for s in declared_symbols():
         assert hasattr(h, s), f"{s} not exported"
-    assert _lib.lib().fgt_abi_version() == 1
+    assert _lib.lib().fgt_abi_version() == 2
 
 
 def test_struct_sizes_match_header():
-    # 38 ints/floats in fgt_conv_desc, 20 ints in fgt_attn_desc (4 bytes each, no padding)
-    assert ctypes.sizeof(_lib.ConvDesc) == 38 * 4
+    # 42 ints/floats + 3 long long in fgt_conv_desc (42 * 4 = 168: no padding before the 8-byte fields), 21 ints in fgt_attn_desc
+    assert ctypes.sizeof(_lib.ConvDesc) == 42 * 4 + 3 * 8
     assert ctypes.sizeof(_lib.AttnDesc) == 21 * 4
 
 
 def test_rejects_bad_arguments_without_gpu():
     # argument validation happens before any HIP call: callable on a CPU-only box
     d = _lib.ConvDesc()
-    rc = _lib.lib().fgt_conv2d(ctypes.byref(d), None, None, None, None, None, None, None, None, None)
+    rc = _lib.lib().fgt_conv2d(ctypes.byref(d), None, None, None, None, None, None, None, None, None, None)
     assert rc == -1
     assert b"null" in _lib.lib().fgt_last_error()
 

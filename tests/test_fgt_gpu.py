@@ -110,3 +110,15 @@ def test_fgt_bf16x3_conv_precision_within_fp32_bar(dev, monkeypatch):
     out = m(g2["masked_frames"].to(dev), g2["flows"].to(dev), g2["masks"].to(dev))
     e, r = report("48x80x3 bf16x3", out, g2["out"])
     assert e < ABS_TOL and r < 2e-3
+
+
+@pytest.mark.parametrize("H,W,t", [(256, 432, 2), (480, 864, 2)])
+def test_fgt_inference_grids_match_oracle(H, W, t, dev):
+    """Token grids other than the trained 20x36: the tool's default 256x432 (22x36 tokens, spatial padding to 24x40) and
+    BASELINE config #5's 864x480 (40x72 tokens, 45 windows, 180 global tokens) — the reference's `inference` branches."""
+    m, sd = _model(dev)
+    mf, fl, ms = fgt_inputs(H, W, t, 31)
+    ref = O.fgt_forward(sd, DEFAULT_CONFIG, mf, fl, ms)
+    out = m(mf.to(dev), fl.to(dev), ms.to(dev))
+    e, r = report(f"fgt {W}x{H}x{t} fp32", out, ref)
+    assert e < ABS_TOL and r < REL_TOL

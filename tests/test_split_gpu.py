@@ -1,0 +1,148 @@
+"""Pre-split operand path (fgt_conv_desc.in_split / out_split, fgt_split, LDS-DMA conv kernel) on a real MI355X.
+
+The split path is the bf16x3 arithmetic with different data movement, so its gate is BIT equality with the register-staged
+bf16x3 kernel on the same inputs (same hi/lo values, same MFMA order), which is itself held to the fp32 reference in
+test_ops_gpu.py::test_conv2d_bf16x3_split_precision."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import report
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+TILES = ["128x128", "128x64", "64x64", "128x32", "256x128", "128x128x8", "256x128x16", "256x64x8"]
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def test_split_format(dev):
+    """fgt_split: hi = bf16_rne(x), lo = bf16_rne(x - hi); relu flag; strided source."""
+    from fgt_amd import ops
+    x = _rand(333, 72, seed=1, scale=3.0)
+    x[0, :4] = torch.tensor([0.0, -0.0, 1e-30, 65504.0])
+    s = ops.split(x.to(dev))
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    assert torch.equal(s.data[0].cpu(), hi) and torch.equal(s.data[1].cpu(), lo)
+    assert (s.float().cpu() - x).abs().max() <= x.abs().max() * 2.0 ** -16
+    xr = x.clamp_min(0)
+    sr = ops.split(x.to(dev), relu=True)
+    assert torch.equal(sr.data[0].cpu(), xr.to(torch.bfloat16))
+    wide = _rand(50, 96, seed=2).to(dev)
+    sv = ops.split(wide[:, 16:48])                     # channel slice of a wider buffer
+    assert torch.equal(sv.data[0].cpu(), wide[:, 16:48].cpu().to(torch.bfloat16))
+
+
+SPLIT_CASES = [
+    # name, N, H, W, Cin, Cout, k, stride, pad, dil, groups
+    ("3x3_s1", 2, 20, 28, 64, 128, 3, 1, 1, 1, 1),
+    ("3x3_s2", 2, 24, 40, 64, 64, 3, 2, 1, 1, 1),
+    ("3x3_cout_odd", 1, 17, 23, 32, 126, 3, 1, 1, 1, 1),
+    ("7x7_s3_p3_cin40", 2, 24, 36, 40, 96, 7, 3, 3, 1, 1),      # K = 1960: K tail inside the last step
+    ("3x3_dil8_cin48", 1, 30, 27, 48, 48, 3, 1, 8, 8, 1),
+    ("1x1_linear", 1, 1, 700, 512, 1960, 1, 1, 0, 1, 1),
+    ("1x1_k8", 1, 1, 130, 8, 40, 1, 1, 0, 1, 1),                  # a single 8-channel chunk
+    ("g4", 1, 15, 27, 64, 96, 3, 1, 1, 1, 4),
+    ("1x5", 1, 20, 30, 64, 64, (1, 5), 1, (0, 2), 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES, ids=[c[0] for c in SPLIT_CASES])
+@pytest.mark.parametrize("tile", TILES)
+def test_conv_split_inputs_bit_equal_to_bf16x3(case, tile, dev):
+    from fgt_amd import ops
+    name, N, H, W, Cin, Cout, k, s, p, d, g = case
+    kh, kw = (k, k) if isinstance(k, int) else k
+    x = _rand(N, H, W, Cin, seed=1).to(dev)
+    w = _rand(Cout, Cin // g, kh, kw, seed=2, scale=1.0 / math.sqrt(Cin // g * kh * kw))
+    b = _rand(Cout, seed=3)
+    pc = ops.PackedConv(w.to(dev), b.to(dev), groups=g)
+    ref = ops.conv2d(x, pc, stride=s, pad=p, dil=d, act="lrelu", tile="128x128", precision="bf16x3")
+    got = ops.conv2d(ops.split(x), pc, stride=s, pad=p, dil=d, act="lrelu", tile=tile, precision="bf16x3")
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref), f"{name} tile={tile}: max diff {(got - ref).abs().max().item():.3e}"
+    if tile == "128x128":      # and the pair is held to fp32 torch
+        t = F.leaky_relu(F.conv2d(x.cpu().permute(0, 3, 1, 2), w, b, s, p, d, g), 0.2).permute(0, 2, 3, 1)
+        e, r = report(f"split conv {name}", got.cpu(), t)
+        assert r < 2e-5
+
+
+def test_conv_split_two_source_grouped_upsample_replicate(dev):
+    """Encoder-style group-interleaved concat of two split sources; nearest-x2 upsample; replicate padding."""
+    from fgt_amd import ops
+    N, H, W, g = 2, 15, 27, 8
+    x0, o = _rand(N, H, W, 256, seed=1).to(dev), _rand(N, H, W, 384, seed=2).to(dev)
+    w, b = _rand(256, 640 // g, 3, 3, seed=3, scale=0.05), _rand(256, seed=4)
+    pc = ops.PackedConv(w.to(dev), b.to(dev), groups=g)
+    ref = ops.conv2d(x0, pc, x1=o, stride=1, pad=1, act="lrelu", precision="bf16x3")
+    for tile in ("auto", "64x64", "128x128x8"):
+        got = ops.conv2d(ops.split(x0), pc, x1=ops.split(o), stride=1, pad=1, act="lrelu", precision="bf16x3", tile=tile)
+        assert torch.equal(got, ref), tile
+    x = _rand(1, 12, 20, 32, seed=5).to(dev)
+    w2, b2 = _rand(48, 32, 3, 3, seed=6, scale=0.1), _rand(48, seed=7)
+    pc2 = ops.PackedConv(w2.to(dev), b2.to(dev))
+    for kw in (dict(upsample=True, pad=1), dict(pad=2, pad_mode="replicate", dil=2)):
+        ref = ops.conv2d(x, pc2, precision="bf16x3", **kw)
+        got = ops.conv2d(ops.split(x), pc2, precision="bf16x3", **kw)
+        assert torch.equal(got, ref), kw
+
+
+def test_conv_split_channel_slices_and_row_slices(dev):
+    """Split sources that are slices of wider / longer buffers (ld > C, leading-dim slices)."""
+    from fgt_amd import ops
+    rows = 900
+    wide = _rand(rows + 40, 96, seed=1).to(dev)
+    ws = ops.split(wide)
+    w, b = _rand(72, 64, seed=2, scale=0.1), _rand(72, seed=3)
+    pc = ops.PackedConv(w.to(dev), b.to(dev))
+    ref = ops.linear(wide[8:8 + rows, 16:80], pc, precision="bf16x3")
+    sl = ops.Split(ws.data[:, 8:8 + rows, 16:80])
+    got = ops.linear(sl, pc, precision="bf16x3")
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("mode", ["only", "both"])
+def test_conv_out_split_epilogue(mode, dev):
+    """out_split: the epilogue's split planes equal fgt_split of the fp32 result; with epilogue combine + activation."""
+    from fgt_amd import ops
+    x = _rand(2, 18, 26, 64, seed=1).to(dev)
+    w, b = _rand(128, 64, 3, 3, seed=2, scale=0.05), _rand(128, seed=3)
+    aux = _rand(2, 18, 26, 128, seed=4).to(dev)
+    pc = ops.PackedConv(w.to(dev), b.to(dev))
+    for xin in (x, ops.split(x)):
+        for tile in ("128x128", "128x128x8", "64x64"):
+            ref = ops.conv2d(x, pc, pad=1, act="lrelu", epi="add", aux1=aux, precision="bf16x3", tile="128x128")
+            r = ops.conv2d(xin, pc, pad=1, act="lrelu", epi="add", aux1=aux, precision="bf16x3", tile=tile, out_split=mode)
+            o32, osp = (None, r) if mode == "only" else r
+            want = ops.split(ref)
+            assert torch.equal(osp.data, want.data)
+            if o32 is not None:
+                assert torch.equal(o32, ref)
+    # a chain conv -> conv entirely in split form equals the fp32-tensor chain
+    w2, b2 = _rand(64, 128, 3, 3, seed=5, scale=0.05), _rand(64, seed=6)
+    pc2 = ops.PackedConv(w2.to(dev), b2.to(dev))
+    a = ops.conv2d(ops.conv2d(x, pc, pad=1, act="lrelu", precision="bf16x3"), pc2, pad=1, stride=2, precision="bf16x3")
+    s1 = ops.conv2d(ops.split(x), pc, pad=1, act="lrelu", precision="bf16x3", out_split="only")
+    bsp = ops.conv2d(s1, pc2, pad=1, stride=2, precision="bf16x3")
+    assert torch.equal(a, bsp)
+
+
+def test_split_rejections(dev):
+    from fgt_amd import ops
+    x = _rand(1, 8, 8, 36, seed=1).to(dev)            # 36 channels: not a multiple of 8
+    pc = ops.PackedConv(_rand(16, 36, 3, 3, seed=2).to(dev), None)
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        ops.conv2d(ops.split(x), pc, pad=1, precision="bf16x3", tile="64x64")
+    x = _rand(1, 8, 8, 32, seed=1).to(dev)
+    pc = ops.PackedConv(_rand(16, 32, 3, 3, seed=2).to(dev), None)
+    with pytest.raises(RuntimeError, match="bf16x3"):
+        ops.conv2d(ops.split(x), pc, pad=1, precision="fp32")
+    with pytest.raises(RuntimeError, match="in_relu"):
+        ops.conv2d(ops.split(x), pc, pad=1, precision="bf16x3", in_relu=True, tile="64x64")

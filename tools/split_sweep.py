@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Register-staged bf16x3 conv (fp32 inputs) vs the LDS-DMA kernel on pre-split inputs, per layer shape and tile.
+
+    python tools/split_sweep.py [--reps 10]        (FGT_CONV_PIPE=0 selects the unpinned schedule of the split kernel)
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fgt_amd import ops  # noqa: E402
+
+LAYERS = {  # name: (N, H, W, C0, C1, Cout, groups, k, stride, pad)
+    "enc8  256->384 3x3": (17, 60, 108, 256, 0, 384, 1, 3, 1, 1),
+    "enc10 640->512 g2": (17, 60, 108, 256, 384, 512, 2, 3, 1, 1),
+    "enc12 640->256 g8": (17, 60, 108, 256, 384, 256, 8, 3, 1, 1),
+    "enc4  64->128 s2": (17, 120, 216, 64, 0, 128, 1, 3, 2, 1),
+    "dec   128->128 120x216": (17, 120, 216, 128, 0, 128, 1, 3, 1, 1),
+    "dec   64->64 240x432/2": (8, 240, 432, 64, 0, 64, 1, 3, 1, 1),
+    "p2v   128->512 7x7s3": (17, 60, 108, 128, 0, 512, 1, 7, 3, 3),
+    "ffn1  512->1960": (1, 1, 12240, 512, 0, 1960, 1, 1, 1, 0),
+    "ffn2  40->512 7x7s3": (17, 60, 108, 40, 0, 512, 1, 7, 3, 3),
+    "qkv   512->1536": (1, 1, 12240, 512, 0, 1536, 1, 1, 1, 0),
+    "proj  512->512": (1, 1, 12240, 512, 0, 512, 1, 1, 1, 0),
+    "k     768->512": (1, 1, 17340, 768, 0, 512, 1, 1, 1, 0),
+}
+TILES = ["128x128", "64x64", "128x64", "256x128", "128x128x8", "256x128x16", "256x64x8"]
+
+
+def bench(fn, reps):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--layers", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    print(f"{'layer':26s} {'GFLOP':>7s} | " + " ".join(f"{t:>17s}" for t in TILES) + "   (TFLOP/s algorithmic: fp32-in / split-in)")
+    for name, (N, H, W, C0, C1, Cout, g, k, s, p) in LAYERS.items():
+        if a.layers and not any(x in name for x in a.layers.split(",")):
+            continue
+        x = torch.randn(N, H, W, C0, device=dev)
+        x1 = torch.randn(N, H, W, C1, device=dev) if C1 else None
+        w = torch.randn(Cout, (C0 + C1) // g, k, k, device=dev) * 0.02
+        pc = ops.PackedConv(w, torch.zeros(Cout, device=dev), groups=g)
+        xs, x1s = ops.split(x), (ops.split(x1) if C1 else None)
+        out = ops.conv2d(x, pc, x1=x1, stride=s, pad=p, act="lrelu", tile="128x128", precision="bf16x3")
+        fl = 2.0 * (out.numel() // Cout) * (Cout // g) * pc.K * g
+        cells = []
+        for t in TILES:
+            o1, o2 = torch.empty_like(out), torch.empty_like(out)
+            ms_a = bench(lambda: ops.conv2d(x, pc, x1=x1, stride=s, pad=p, act="lrelu", tile=t, precision="bf16x3", out=o1), a.reps)
+            ms_b = bench(lambda: ops.conv2d(xs, pc, x1=x1s, stride=s, pad=p, act="lrelu", tile=t, precision="bf16x3", out=o2), a.reps)
+            eq = "" if torch.equal(o1, o2) and torch.equal(o1, out) else "!"
+            cells.append(f"{fl / ms_a / 1e9:7.1f}/{fl / ms_b / 1e9:7.1f}{eq:1s} ")
+        print(f"{name:26s} {fl / 1e9:7.1f} | " + " ".join(cells), flush=True)
+        del x, x1, xs, x1s, out
+
+
+if __name__ == "__main__":
+    main()
