@@ -234,18 +234,20 @@ inline int grid_for(long total, int block = 256) {
 
 // fp32 -> split tensor (hi = bf16_rne(x), lo = bf16_rne(x - hi)); one float4 per thread
 __global__ void split_kernel(const float* __restrict__ x, long rows, int C4, int ldx, __bf16* __restrict__ out, int ld_s, long ps, int relu) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * C4) return;
-    const long r = i / C4;
-    const int c = (int)(i - r * C4) * 4;
-    float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
-    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-    uint2 hi, lo;
-    fgt_split4(v, hi, lo);
-    __bf16* o = out + r * ld_s + c;
-    *reinterpret_cast<uint2*>(o) = hi;
-    *reinterpret_cast<uint2*>(o + ps) = lo;
+    const long total = rows * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C4;
+        const int c = (int)(i - r * C4) * 4;
+        float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        uint2 hi, lo;
+        fgt_split4(v, hi, lo);
+        __bf16* o = out + r * ld_s + c;
+        *reinterpret_cast<uint2*>(o) = hi;
+        *reinterpret_cast<uint2*>(o + ps) = lo;
+    }
 }
+
 }  // namespace
 
 extern "C" int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, long rows, float eps,

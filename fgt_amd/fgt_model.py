@@ -280,12 +280,19 @@ class FGT(nn.Module):
         return P
 
     # ---- conv block helper (vanilla / gated) ---------------------------------------------------
-    def _block(self, x, packed, act="lrelu", **kw):
+    @staticmethod
+    def _split_chain():
+        """bf16x3 mode: conv -> conv chains hand their activations over pre-split (ops.Split): the producer's epilogue splits
+        each value once and the consumer's loader is a plain LDS-DMA copy (csrc/conv_split.hip).  Same arithmetic as feeding
+        fp32 tensors to the bf16x3 kernel, bit for bit."""
+        return ops.DEFAULT_CONV_PRECISION == "bf16x3"
+
+    def _block(self, x, packed, act="lrelu", out_split=None, **kw):
         f, g = packed
         if g is None:
-            return ops.conv2d(x, f, act=act, **kw)
+            return ops.conv2d(x, f, act=act, out_split=out_split, **kw)
         gate = ops.conv2d(x, g, act="sigmoid", **kw)                      # network_blocks_2d.py:86-91
-        return ops.conv2d(x, f, act=act, epi="mul", aux1=gate, **kw)
+        return ops.conv2d(x, f, act=act, epi="mul", aux1=gate, out_split=out_split, **kw)
 
     # ---- transformer pieces --------------------------------------------------------------------
     def _ffn(self, y, x_res, P, bt, th, tw, Hf, Wf):
@@ -370,23 +377,25 @@ class FGT(nn.Module):
         ops.nchw_to_nhwc(flows.reshape(bt, cfg["flow_in"], H, W).float(), f_in, coff=0, zero_to=fin)
         E = P["enc"]
         strides = [sp[2] for sp in EncoderParams.SPEC]
+        sc = "only" if self._split_chain() else None
         e = x_in
         x0 = None
         for i in range(9):
             if i == 4:
                 x0 = e                                                         # model.py:58-59
+            osp = ("both" if sc else None) if i == 8 else sc                   # the last layer also feeds fold()'s fp32 residual
             if i <= 4:
-                e = ops.conv2d(e, E[i], stride=strides[i], pad=1, act="lrelu")
+                e = ops.conv2d(e, E[i], stride=strides[i], pad=1, act="lrelu", out_split=osp)
             else:
-                e = ops.conv2d(x0, E[i], x1=e, stride=1, pad=1, act="lrelu")    # grouped concat, model.py:60-65
-        enc = e
+                e = ops.conv2d(x0, E[i], x1=e, stride=1, pad=1, act="lrelu", out_split=osp)    # grouped concat, model.py:60-65
+        enc, enc_in = e if sc else (e, e)
         FE = P["fenc"]
-        fe = self._block(f_in, FE[0], stride=1, pad=2, pad_mode="replicate")    # ReplicationPad2d(2) + 5x5 conv
-        fe = self._block(fe, FE[1], stride=2, pad=1)
-        fe = self._block(fe, FE[2], stride=1, pad=1)
-        fe = self._block(fe, FE[3], stride=2, pad=1)
+        fe = self._block(f_in, FE[0], stride=1, pad=2, pad_mode="replicate", out_split=sc)    # ReplicationPad2d(2) + 5x5 conv
+        fe = self._block(fe, FE[1], stride=2, pad=1, out_split=sc)
+        fe = self._block(fe, FE[2], stride=1, pad=1, out_split=sc)
+        fe = self._block(fe, FE[3], stride=2, pad=1, out_split=sc)
         s, p = cfg["s"][0], cfg["p"][0]
-        tok = ops.conv2d(enc, P["p2v"], stride=s, pad=p)
+        tok = ops.conv2d(enc_in, P["p2v"], stride=s, pad=p)
         ftok = ops.conv2d(fe, P["fp2v"], stride=s, pad=p)
         th, tw = tok.shape[1], tok.shape[2]
         return enc, tok.view(bt * th * tw, -1), ftok.view(bt * th * tw, -1), th, tw
@@ -413,9 +422,12 @@ class FGT(nn.Module):
         Y = ops.linear(x, P["v2p"])
         feat = ops.fold(Y, bt, th, tw, P["v2p_c"], cfg["k"][0], cfg["s"][0], cfg["p"][0], Hf, Wf, normalize=False, res=enc)
         D = P["dec"]
-        y = self._block(feat, D[0], stride=1, pad=1, upsample=True)
-        y = self._block(y, D[1], stride=1, pad=1)
-        y = self._block(y, D[2], stride=1, pad=1, upsample=True)
+        sc = "only" if self._split_chain() else None
+        if sc:
+            feat = ops.split(feat)
+        y = self._block(feat, D[0], stride=1, pad=1, upsample=True, out_split=sc)
+        y = self._block(y, D[1], stride=1, pad=1, out_split=sc)
+        y = self._block(y, D[2], stride=1, pad=1, upsample=True)              # fp32: the Cout = 3 kernel below gathers fp32
         if D[3][1] is None:
             return ops.conv2d(y, D[3][0], stride=1, pad=1, act="tanh", out_nchw=True)   # final conv + torch.tanh
         y = self._block(y, D[3], act=None, stride=1, pad=1)

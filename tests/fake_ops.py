@@ -16,6 +16,26 @@ _ACT = {None: lambda v, s: v, "none": lambda v, s: v, "lrelu": lambda v, s: F.le
         "sigmoid": lambda v, s: torch.sigmoid(v), "tanh": lambda v, s: torch.tanh(v)}
 
 
+DEFAULT_CONV_PRECISION = "fp32"      # tests flip it to "bf16x3" to walk the split-chain plumbing of the host code
+
+
+class Split:
+    """Stand-in for ops.Split: carries the fp32 tensor the split planes stand for (the CPU spec is exact; the 2^-16 rounding of the
+    real format is a kernel property, pinned on the GPU in tests/test_split_gpu.py)."""
+
+    def __init__(self, x):
+        self.x = x
+
+    @property
+    def shape(self):
+        return self.x.shape
+
+
+def split(x, relu=False, out=None):
+    assert not isinstance(x, Split), "double split"
+    return Split(F.relu(x) if relu else x)
+
+
 def _dense_weight(pc):
     G, Cout_g = pc.groups, pc.Cout // pc.groups
     w = pc.w[:, :Cout_g, :pc.K].reshape(G, Cout_g, pc.kh, pc.kw, pc.Cg).permute(0, 1, 4, 2, 3)
@@ -23,7 +43,18 @@ def _dense_weight(pc):
 
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
-           epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None):
+           epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None,
+           out_split=None, out_s=None):
+    if out_split:
+        assert not out_nchw and out_s is None
+        y = conv2d(x, pc, x1, stride, pad, dil, upsample, pad_mode, in_relu, act, slope, epi, aux1, aux2, act2, out_scale, out)
+        return Split(y) if out_split == "only" else (y, Split(y))
+    if isinstance(x, Split):
+        assert DEFAULT_CONV_PRECISION == "bf16x3" or precision == "bf16x3", "Split inputs need the bf16x3 mode"
+        assert not in_relu and (x1 is None or isinstance(x1, Split))
+        x, x1 = x.x, (None if x1 is None else x1.x)
+    else:
+        assert not isinstance(x1, Split), "sources must both be split"
     x, N, H, W, C0, _ = _as_map(x)
     G = pc.groups
     if x1 is not None:

@@ -19,9 +19,14 @@ def fake(monkeypatch):
     monkeypatch.setattr(fgt_model, "PackedConv", fake_ops.PackedConv)
 
 
+@pytest.mark.parametrize("split_chain", [False, True], ids=["fp32-tensors", "split-chain"])
 @pytest.mark.parametrize("name,conv_type", [("fgt_vanilla_64x96x3.npz", "vanilla"), ("fgt_vanilla_48x80x3.npz", "vanilla"),
                                             ("fgt_gated_48x64x2.npz", "gated")])
-def test_fgt_host_logic_matches_reference_golden(fake, name, conv_type):
+def test_fgt_host_logic_matches_reference_golden(fake, monkeypatch, name, conv_type, split_chain):
+    """split_chain: the bf16x3 mode's plumbing (conv epilogues hand ops.Split tensors to the next conv) over the lossless
+    CPU stand-in: the same golden output must come out, i.e. every Split reaches the consumer its fp32 twin would."""
+    if split_chain:
+        monkeypatch.setattr(fake_ops, "DEFAULT_CONV_PRECISION", "bf16x3")
     g = load_golden(name)
     m = Model(dict(DEFAULT_CONFIG, conv_type=conv_type)).eval()
     m.load_state_dict(synth_state_dict(m.state_dict(), seed=0), strict=True)

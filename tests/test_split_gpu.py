@@ -35,6 +35,9 @@ def test_split_format(dev):
     xr = x.clamp_min(0)
     sr = ops.split(x.to(dev), relu=True)
     assert torch.equal(sr.data[0].cpu(), xr.to(torch.bfloat16))
+    big = _rand(70000, 256, seed=3).to(dev)            # > 2^22 float4s: more work items than one grid pass
+    sb = ops.split(big)
+    assert torch.equal(sb.data[0], big.to(torch.bfloat16)) and torch.equal(sb.data[1], (big - sb.data[0].float()).to(torch.bfloat16))
     wide = _rand(50, 96, seed=2).to(dev)
     sv = ops.split(wide[:, 16:48])                     # channel slice of a wider buffer
     assert torch.equal(sv.data[0].cpu(), wide[:, 16:48].cpu().to(torch.bfloat16))

@@ -50,3 +50,9 @@ if [ "${1:-}" != "quick" ]; then
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cut -c1-160 "$f" | head -16
 fi
+if [ "${1:-}" != "quick" ]; then
+  echo "== 2-rank rehearsal of bench.py on this single GPU (gloo, collectives staged through the host): weak headline + strong extra"
+  FGT_BENCH_SHARE_GPU=1 FGT_BENCH_BACKEND=gloo FGT_TUNING_FILE="$PWD/gpurun_out/tuning.json" timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+    --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --no-prof > gpurun_out/bench_2rank_rehearsal.log 2>&1
+  echo "rehearsal exit: $?"; grep '^{' gpurun_out/bench_2rank_rehearsal.log | cut -c1-1200
+fi
