@@ -233,7 +233,7 @@ def main():
             passes = 1 if prec == "fp32" else 3          # MFMA flops issued per algorithmic flop
             peak = PEAK_FP32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
             ach = passes * k_flops / (k_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": f"conv_igemm_kernel ({prec} implicit-GEMM conv + all Linear layers)",
+            out["roofline"] = {"bound": "mfma", "kernel": f"conv_igemm_kernel / conv_split_kernel ({prec} implicit-GEMM conv + all Linear layers; every fgt_conv2d launch)",
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": conv_traffic(prec),
                                "algorithmic_tflops": round(k_flops / (k_ms * 1e-3) / 1e12, 2), "mfma_passes_per_product": passes,

@@ -400,10 +400,11 @@ class FGT(nn.Module):
         th, tw = tok.shape[1], tok.shape[2]
         return enc, tok.view(bt * th * tw, -1), ftok.view(bt * th * tw, -1), th, tw
 
-    def transform_decode(self, enc, x, f, b, t, th, tw, n_out=None):
-        """model.py:272-283 given per-frame features.  `n_out` (b == 1 only): soft composition + decoder run for the first
-        n_out frames only — the tool discards the decoded reference frames (tool/video_inpainting.py:727: only
-        `range(len(neighbor_ids))` is read) and both stages are per-frame, so the kept frames are unchanged."""
+    def transform_decode(self, enc, x, f, b, t, th, tw, n_out=None, keep=None):
+        """model.py:272-283 given per-frame features.  Soft composition + decoder run only for the frames whose output is
+        consumed — the tool discards the decoded reference frames (tool/video_inpainting.py:727: only
+        `range(len(neighbor_ids))` is read) and both stages are per-frame, so the kept frames are unchanged:
+        `n_out` (b == 1): the first n_out frames; `keep` (any b): an int64 device tensor of frame indices in [0, b*t)."""
         P = self.packed()
         cfg = self.cfg
         bt = b * t
@@ -415,8 +416,13 @@ class FGT(nn.Module):
         for pt, ps in P["blocks"]:
             x = self._temporal(x, pt, b, t, th, tw, Hf, Wf)
             x = self._spatial(x, f, ps, bt, th, tw, Hf, Wf)
-        if n_out is not None and n_out < bt:
-            assert b == 1, "n_out needs a single clip (frames of one batch element are contiguous)"
+        if keep is not None:
+            assert n_out is None
+            x = x.view(bt, th * tw, -1).index_select(0, keep).view(keep.numel() * th * tw, -1)
+            enc = enc.index_select(0, keep)
+            bt = keep.numel()
+        elif n_out is not None and n_out < bt:
+            assert b == 1, "n_out needs a single clip (frames of one batch element are contiguous); use keep= for b > 1"
             bt = n_out
             x, enc = x[: bt * th * tw], enc[:bt]
         Y = ops.linear(x, P["v2p"])

@@ -67,7 +67,7 @@ def compose_torch(out, nb, frames01, masks, comp, visited):
 
 class ClipRunner:
     def __init__(self, model, frames01, flows_normed, masks, neighbor_stride=5, ref_length=10, num_ref=-1,
-                 rank=0, world=1, forward=None, group=None, cache_features=None, encode_chunk=20, use_graphs=None):
+                 rank=0, world=1, forward=None, group=None, cache_features=None, encode_chunk=20, use_graphs=None, window_batch=4):
         self.model = model
         self.frames01, self.flows, self.masks = frames01, flows_normed, masks
         self.n = frames01.shape[1]
@@ -99,6 +99,22 @@ class ClipRunner:
         # hipGraph replay of the per-window launch sequence (one graph per window length t), only with the feature cache
         self.use_graphs = (self.on_gpu and self.cache_features) if use_graphs is None else (use_graphs and self.on_gpu and self.cache_features)
         self._graphs = None
+        # Window batching (feature-cache path): windows of equal length t are independent batch elements of the reference model
+        # (b > 1: every stage is per frame or per (b, zone)), so up to `window_batch` of this rank's windows go through the
+        # transformer + decoder as ONE forward.  Per-row results do not depend on how many rows a GEMM launch carries, so the
+        # outputs are bit-identical to running the windows one by one; the launches are 3-4x larger (M = 12240 rows per
+        # window leaves 0.75- and 2.25-round tile grids on 256 CUs) and 3-4x fewer.
+        self.window_batch = max(1, int(window_batch))
+        by_t = {}
+        for wi in self.mine:
+            by_t.setdefault(len(self.sched[wi][0]) + len(self.sched[wi][1]), []).append(wi)
+        self.groups = [ws[i:i + self.window_batch] for _, ws in sorted(by_t.items()) for i in range(0, len(ws), self.window_batch)]
+        self._group_ids, self._group_keep = [], []
+        for ws in self.groups:
+            t = len(self.sched[ws[0]][0]) + len(self.sched[ws[0]][1])
+            self._group_ids.append(torch.cat([self._ids[wi] for wi in ws]))
+            self._group_keep.append(torch.tensor([j * t + i for j, wi in enumerate(ws) for i in range(len(self.sched[wi][0]))],
+                                                 dtype=torch.int64, device=self.dev))
 
     def run_window(self, wi):
         ids = self._ids[wi]
@@ -137,39 +153,39 @@ class ClipRunner:
         o1, o2 = Hf * Wf * C, Hf * Wf * C + n_tok * c
         return flat[:, :o1].reshape(self.n, Hf, Wf, C), flat[:, o1:o2].reshape(self.n, n_tok, c), flat[:, o2:].reshape(self.n, n_tok, cf), th, tw
 
-    def run_window_cached(self, wi, feats):
+    def run_group_cached(self, gi, feats):
+        """Transformer + decoder for one group of equal-length windows as a single batched forward; returns {window: out}."""
         enc, tok, ftok, th, tw = feats
-        ids = self._ids[wi]
-        t = ids.numel()
-        e, x, f = enc[ids].contiguous(), tok[ids].reshape(t * th * tw, -1), ftok[ids].reshape(t * th * tw, -1)
-        nb = len(self.sched[wi][0])
+        ws, ids, keep = self.groups[gi], self._group_ids[gi], self._group_keep[gi]
+        b, bt = len(ws), ids.numel()
+        t = bt // b
+        e, x, f = enc.index_select(0, ids), tok.index_select(0, ids).reshape(bt * th * tw, -1), ftok.index_select(0, ids).reshape(bt * th * tw, -1)
+        net = self.model.net
         if self.use_graphs:
             if self._graphs is None:
                 from .graph import GraphCache
-                net = self.model.net
-                # the neighbour count travels as the SHAPE of a dummy tensor: graphs are cached per input-shape signature
-                self._graphs = GraphCache(lambda e_, x_, f_, n_: net.transform_decode(e_, x_, f_, 1, e_.shape[0], th, tw, n_out=n_.shape[0]))
-            out = self._graphs(e, x, f, torch.empty(nb, device=self.dev))[:nb]
-            return out.clone() if self.world > 1 else out     # the static output buffer is reused by the next window of this length
-        return self.model.net.transform_decode(e, x, f, 1, t, th, tw, n_out=nb)
+                # b travels as the SHAPE of a dummy tensor: graphs are cached per input-shape signature
+                self._graphs = GraphCache(lambda e_, x_, f_, k_, b_: net.transform_decode(e_, x_, f_, b_.shape[0], e_.shape[0] // b_.shape[0],
+                                                                                       th, tw, keep=k_))
+            out = self._graphs(e, x, f, keep, torch.empty(b, device=self.dev)).clone()   # the static buffer is reused by the next group of this shape
+        else:
+            out = net.transform_decode(e, x, f, b, t, th, tw, keep=keep)
+        outs, o = {}, 0
+        for wi in ws:
+            nb = len(self.sched[wi][0])
+            outs[wi] = out[o:o + nb]
+            o += nb
+        return outs
 
     def run(self):
         """One pass over the clip.  Returns comp [N,H,W,3] fp32 (0..255 scale, before the final astype(uint8))."""
         comp = torch.empty(self.n, self.H, self.W, 3, dtype=torch.float32, device=self.dev)
-        if self.on_gpu and self.world == 1:
-            # single rank: windows run in ascending order, so each one is composed as soon as it is produced
-            # (its output buffer may be a graph-static buffer that the next window of the same length overwrites)
-            f01, mk = self.frames01[0].contiguous(), self.masks[0].contiguous()
-            with torch.no_grad():
-                feats = self.encode_clip() if self.cache_features else None
-                for wi in range(len(self.sched)):
-                    out = self.run_window_cached(wi, feats) if self.cache_features else self.run_window(wi)
-                    ops.compose_blend(out, self._nb[wi], self._first[wi], f01, mk, comp)
-            return comp
         if self.cache_features:
             with torch.no_grad():
                 feats = self.encode_clip()
-                outs = {wi: self.run_window_cached(wi, feats) for wi in self.mine}
+                outs = {}
+                for gi in range(len(self.groups)):
+                    outs.update(self.run_group_cached(gi, feats))
         else:
             outs = {wi: self.run_window(wi) for wi in self.mine}
         if self.world > 1:

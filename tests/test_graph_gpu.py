@@ -32,6 +32,28 @@ def test_cliprunner_graph_replay_equals_eager(dev):
     assert torch.equal(a, eager) and torch.equal(b, eager)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_window_batching_bit_equal(prec, dev, monkeypatch):
+    """Batching equal-length windows as b > 1 (ClipRunner.window_batch) changes launch sizes only: bit-identical composite,
+    eager and under hipGraph replay, in both arithmetic modes (bf16x3 also walks the pre-split conv chains)."""
+    from fgt_amd import ops
+    from fgt_amd.fgt_model import DEFAULT_CONFIG, Model
+    from fgt_amd.scheduler import ClipRunner
+    monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", prec)
+    monkeypatch.setattr(ops, "DEFAULT_ATTN_PRECISION", prec)
+    m = Model(dict(DEFAULT_CONFIG)).eval()
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=0), strict=True)
+    m = m.to(dev)
+    fr, fl, ms = synth_clip(46, 64, 96, seed=5, device=dev)
+    one = ClipRunner(m, fr, fl, ms, use_graphs=False, window_batch=1)
+    four = ClipRunner(m, fr, fl, ms, use_graphs=False, window_batch=4)
+    assert max(len(g) for g in four.groups) >= 3
+    a = one.run()
+    assert torch.equal(four.run(), a)
+    g = ClipRunner(m, fr, fl, ms, use_graphs=True, window_batch=3)
+    assert torch.equal(g.run(), a) and torch.equal(g.run(), a)
+
+
 def test_raft_and_lafc_graph_replay_equal_eager(dev):
     from fgt_amd import lafc_model, raft_model
     r = raft_model.RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).eval()

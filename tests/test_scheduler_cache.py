@@ -45,6 +45,22 @@ def test_cached_equals_uncached_equals_oracle(monkeypatch):
         fgt_model.ops, fgt_model.PackedConv = real_ops, real_pc
 
 
+def test_window_batching_is_exact():
+    """Equal-length windows batched as b > 1 through transform_decode(keep=...) == one window per forward (the CPU spec's
+    torch convs may differ in the last bit with the batch size, hence the same +-1 uint8 allowance as above)."""
+    real_ops, real_pc = fgt_model.ops, fgt_model.PackedConv
+    try:
+        m, sd, fr, fl, ms = _setup()
+        one = ClipRunner(m, fr, fl, ms, neighbor_stride=3, ref_length=4, cache_features=True, window_batch=1)
+        four = ClipRunner(m, fr, fl, ms, neighbor_stride=3, ref_length=4, cache_features=True, window_batch=4)
+        assert all(len(g) == 1 for g in one.groups) and max(len(g) for g in four.groups) >= 2
+        assert sorted(w for g in four.groups for w in g) == list(range(len(four.sched)))
+        a, b = one.run(), four.run()
+        assert (b - a).abs().max().item() <= 1.0 and ((b - a).abs() > 0).float().mean().item() < 1e-3
+    finally:
+        fgt_model.ops, fgt_model.PackedConv = real_ops, real_pc
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

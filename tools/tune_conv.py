@@ -6,6 +6,7 @@ configuration.  Run on the GPU box; writes gpurun_out/tune_conv.json and prints 
 """
 import argparse
 import json
+import math
 import os
 import sys
 
@@ -46,23 +47,25 @@ def main():
     torch.cuda.synchronize()
     uniq = {}
     for x, pc, kw, out in calls:
-        x4 = ops._as_map(x)[0]
+        unwrap = lambda t: t.hi if isinstance(t, ops.Split) else t
+        x4 = ops._as_map(unwrap(x))[0]
         x1 = kw.get("x1")
-        c1 = 0 if x1 is None else ops._as_map(x1)[4]
-        key = (tuple(x4.shape), c1, pc.Cout, pc.groups, pc.kh, pc.kw, str(kw.get("stride", 1)), str(kw.get("pad", 0)), bool(kw.get("upsample")), kw.get("epi"))
+        c1 = 0 if x1 is None else ops._as_map(unwrap(x1))[4]
+        key = (tuple(x4.shape), "split" if isinstance(x, ops.Split) else "fp32", c1, pc.Cout, pc.groups, pc.kh, pc.kw, str(kw.get("stride", 1)), str(kw.get("pad", 0)), bool(kw.get("upsample")), kw.get("epi"))
         if key not in uniq:
             uniq[key] = [x, pc, kw, out, 0]
         uniq[key][4] += 1
     tiles = args.tiles.split(",")
     rows = []
     for key, (x, pc, kw, out, count) in uniq.items():
-        o4 = ops._as_map(out)[0] if not kw.get("out_nchw") else out
-        M = out.numel() // pc.Cout
+        osp = kw.get("out_split")
+        o32, o_s = (out if osp == "both" else ((None, out) if osp == "only" else (out, None)))
+        M = math.prod((o32 if o32 is not None else o_s).shape) // pc.Cout
         flops = 2.0 * M * (pc.Cout // pc.groups) * pc.K * pc.groups
-        row = {"in": list(key[0]), "C1": key[1], "Cout": pc.Cout, "groups": pc.groups, "k": [pc.kh, pc.kw], "stride": key[6], "pad": key[7],
-               "upsample": key[8], "epi": key[9], "calls": count, "gflop": flops / 1e9, "tf": {}}
+        row = {"in": list(key[0]) + [key[1]], "C1": key[2], "Cout": pc.Cout, "groups": pc.groups, "k": [pc.kh, pc.kw], "stride": key[7], "pad": key[8],
+               "upsample": key[9], "epi": key[10], "calls": count, "gflop": flops / 1e9, "tf": {}}
         kw2 = dict(kw)
-        kw2["out"] = out
+        kw2["out"], kw2["out_s"] = o32, o_s
         for tile in tiles:
             kw2["tile"] = tile
             try:
@@ -84,9 +87,9 @@ def main():
     json.dump(rows, open("gpurun_out/tune_conv.json", "w"), indent=1)
     tot = sum(r["gflop"] * r["calls"] for r in rows)
     print(f"t={args.t}: {len(calls)} conv2d launches, {len(rows)} distinct, {tot / 1e3:.2f} TFLOP total")
-    print("%-28s %4s %5s %3s %6s %5s %8s | " % ("input", "C1", "Cout", "g", "k", "calls", "GFLOP") + " ".join("%8s" % t for t in tiles))
+    print("%-36s %4s %5s %3s %6s %5s %8s | " % ("input", "C1", "Cout", "g", "k", "calls", "GFLOP") + " ".join("%8s" % t for t in tiles))
     for r in rows:
-        print("%-28s %4d %5d %3d %6s %5d %8.2f | " % (str(r["in"]), r["C1"], r["Cout"], r["groups"], "%dx%d" % tuple(r["k"]), r["calls"], r["gflop"]) +
+        print("%-36s %4d %5d %3d %6s %5d %8.2f | " % (str(r["in"]), r["C1"], r["Cout"], r["groups"], "%dx%d" % tuple(r["k"]), r["calls"], r["gflop"]) +
               " ".join("%8s" % ("-" if r["tf"][t] is None else "%.1f" % r["tf"][t]) for t in tiles))
 
 
