@@ -112,8 +112,10 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     const __bf16* wrow[B_IT];
     const long w_ps = (long)d.groups * d.Npad * d.Kpad;
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it)
-        wrow[it] = reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + bn0 + (wave + it * NW) * 16 + lrow) * d.Kpad + kc * 8;
+    for (int it = 0; it < B_IT; ++it) {
+        const int brow = bn0 + (wave + it * NW) * 16 + lrow;          // rows past Npad (tiles wider than the 128-row padding): zeros
+        wrow[it] = brow < d.Npad ? reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + brow) * d.Kpad + kc * 8 : nullptr;
+    }
 
     char* const lds = reinterpret_cast<char*>(smem);
     constexpr int STAGE_B = STAGE * 4;
@@ -132,10 +134,11 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
         for (int it = 0; it < B_IT; ++it) {
             if (GB % NW == 0 || wave + it * NW < GB) {           // wave-uniform
                 char* dst = st + 2 * BM * 64 + (wave + it * NW) * 1024;
-                glds16(wrow[it], dst);                           // B_hi
-                glds16(wrow[it] + w_ps, dst + BN * 64);          // B_lo
+                const bool bok = BN <= 128 || wrow[it] != nullptr;
+                glds16(bok ? wrow[it] : zp, dst);                           // B_hi
+                glds16(bok ? wrow[it] + w_ps : zp, dst + BN * 64);          // B_lo
             }
-            wrow[it] += BK;
+            if (BN <= 128 || wrow[it] != nullptr) wrow[it] += BK;
         }
         k_cur += BK;
         ci += BK;
@@ -249,6 +252,7 @@ int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_128x128x8: return launch<128, 128, 2, 4, 4>(p, s);
         case FGT_TILE_256x128x16: return launch<256, 128, 4, 4, 4>(p, s);
         case FGT_TILE_256x64x8: return launch<256, 64, 4, 2, 2>(p, s);
+        case FGT_TILE_256x256x8: return launch<256, 256, 2, 4, 2>(p, s);
         default: fgt_set_error("fgt_conv2d: unknown tile %d", tile); return FGT_EINVAL;
     }
 }

@@ -108,6 +108,7 @@ typedef struct fgt_conv_desc {
 #define FGT_TILE_128x128x8 6   /* 128x128 tile on 8 wavefronts (64x32 each) */
 #define FGT_TILE_256x128x16 7  /* 256x128 tile on 16 wavefronts */
 #define FGT_TILE_256x64x8 8    /* 256x64 tile on 8 wavefronts (Cout = 64 layers) */
+#define FGT_TILE_256x256x8 9   /* 256x256 tile on 8 wavefronts of 128x64, one workgroup per CU (split inputs only) */
 
 int fgt_conv2d(const fgt_conv_desc* d, const void* x0, const void* x1, const float* w_packed,
                const float* cscale /* [Cout] or NULL */, const float* cbias /* [Cout] or NULL */,

@@ -14,7 +14,7 @@ from util import report
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-TILES = ["128x128", "128x64", "64x64", "128x32", "256x128", "128x128x8", "256x128x16", "256x64x8"]
+TILES = ["128x128", "128x64", "64x64", "128x32", "256x128", "128x128x8", "256x128x16", "256x64x8", "256x256x8"]
 
 
 def _rand(*shape, seed=0, scale=1.0):

@@ -25,8 +25,14 @@ LAYERS = {  # name: (N, H, W, C0, C1, Cout, groups, k, stride, pad)
     "qkv   512->1536": (1, 1, 12240, 512, 0, 1536, 1, 1, 1, 0),
     "proj  512->512": (1, 1, 12240, 512, 0, 512, 1, 1, 1, 0),
     "k     768->512": (1, 1, 17340, 768, 0, 512, 1, 1, 1, 0),
+    # four equal-length windows batched (ClipRunner.window_batch = 4)
+    "b4 ffn1 512->1960": (1, 1, 48960, 512, 0, 1960, 1, 1, 1, 0),
+    "b4 ffn2 40->512 7x7s3": (68, 60, 108, 40, 0, 512, 1, 7, 3, 3),
+    "b4 qkv  512->1536": (1, 1, 48960, 512, 0, 1536, 1, 1, 1, 0),
+    "b4 proj 512->512": (1, 1, 48960, 512, 0, 512, 1, 1, 1, 0),
+    "b4 k    768->512": (1, 1, 69360, 768, 0, 512, 1, 1, 1, 0),
 }
-TILES = ["128x128", "64x64", "128x64", "256x128", "128x128x8", "256x128x16", "256x64x8"]
+TILES = ["128x128", "128x64", "256x128", "128x128x8", "256x128x16", "256x64x8", "256x256x8"]
 
 
 def bench(fn, reps):
@@ -62,7 +68,11 @@ def main():
         cells = []
         for t in TILES:
             o1, o2 = torch.empty_like(out), torch.empty_like(out)
-            ms_a = bench(lambda: ops.conv2d(x, pc, x1=x1, stride=s, pad=p, act="lrelu", tile=t, precision="bf16x3", out=o1), a.reps)
+            if t == "256x256x8":        # split inputs only
+                ops.conv2d(x, pc, x1=x1, stride=s, pad=p, act="lrelu", tile="128x128", precision="bf16x3", out=o1)
+                ms_a = float("inf")
+            else:
+                ms_a = bench(lambda: ops.conv2d(x, pc, x1=x1, stride=s, pad=p, act="lrelu", tile=t, precision="bf16x3", out=o1), a.reps)
             ms_b = bench(lambda: ops.conv2d(xs, pc, x1=x1s, stride=s, pad=p, act="lrelu", tile=t, precision="bf16x3", out=o2), a.reps)
             eq = "" if torch.equal(o1, o2) and torch.equal(o1, out) else "!"
             cells.append(f"{fl / ms_a / 1e9:7.1f}/{fl / ms_b / 1e9:7.1f}{eq:1s} ")
