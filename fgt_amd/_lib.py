@@ -22,7 +22,7 @@ class ConvDesc(C.Structure):
                [("slope", C.c_float)] + \
                [(n, C.c_int) for n in ("epi", "act2", "ld_aux1", "ld_aux2")] + \
                [("out_scale", C.c_float)] + \
-               [(n, C.c_int) for n in ("Kpad", "Npad", "tile", "precision", "in_split", "out_split", "ldo_s", "ooff_s")] + \
+               [(n, C.c_int) for n in ("Kpad", "Npad", "tile", "precision", "in_split", "out_split", "ldo_s", "ooff_s", "w_il", "reserved0")] + \
                [(n, C.c_longlong) for n in ("ps0", "ps1", "pso")]
 
 

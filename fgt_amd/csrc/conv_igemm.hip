@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_igemm_kernel(const Con
     for (int it = 0; it < B_IT; ++it) {
         const long rowi = (long)g * d.Npad + bn0 + r + it * RPP;
         if constexpr (PREC == 0) wrow[it] = p.w + rowi * d.Kpad + q * 4;
+        else if (d.w_il) wrow[it] = p.w + rowi * d.Kpad + (q >> 2) * 16 + (q & 3) * 4;   // interleaved rows of 2*Kpad bf16 = Kpad floats: [hi 32 | lo 32] per step
         else wrow[it] = p.w + ((q >> 2) * (long)d.groups * d.Npad * d.Kpad + rowi * d.Kpad) / 2 + (q & 3) * 4;   // in floats (2 bf16 each)
     }
 
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_igemm_kernel(const Con
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             vb[it] = *reinterpret_cast<const float4*>(kb_ok ? wrow[it] : zp);
-            wrow[it] += PREC == 0 ? BK : BK / 2;
+            wrow[it] += PREC == 0 ? BK : (d.w_il ? BK : BK / 2);
         }
         // advance the k decomposition
         k_cur += BK;
@@ -366,14 +367,18 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
                 "fgt_conv2d: channels (%d,%d,%d) not divisible by groups %d", d.C0, d.C1, d.Cout, d.groups);
     p.Cg0 = d.C0 / d.groups; p.Cg1 = d.C1 / d.groups; p.Cg = p.Cg0 + p.Cg1; p.Cout_g = d.Cout / d.groups;
     const int gran = d.in_split ? 8 : 4;    // elements per 16-byte gather
-    FGT_REQUIRE(d.in_split == 0 || d.in_split == 1, "fgt_conv2d: in_split must be 0 or 1");
+    FGT_REQUIRE(d.in_split >= 0 && d.in_split <= 2, "fgt_conv2d: in_split must be 0, 1 or 2");
+    if (d.in_split == 2)
+        FGT_REQUIRE(p.Cg0 % 32 == 0 && p.Cg1 % 32 == 0 && d.off0 % 32 == 0 && d.off1 % 32 == 0 && d.ld0 % 64 == 0 && (d.C1 == 0 || d.ld1 % 64 == 0),
+                    "fgt_conv2d: interleaved split inputs need Cin/groups and offsets multiples of 32, row strides multiples of 64");
+    FGT_REQUIRE(d.w_il == 0 || d.precision == FGT_PREC_BF16X3, "fgt_conv2d: w_il needs FGT_PREC_BF16X3");
     FGT_REQUIRE(p.Cg0 % gran == 0 && p.Cg1 % gran == 0, "fgt_conv2d: per-group channels (%d,%d) must be multiples of %d (pad the tensor)", p.Cg0, p.Cg1, gran);
     FGT_REQUIRE(d.ld0 % gran == 0 && d.off0 % gran == 0 && (d.C1 == 0 || (x1 && d.ld1 % gran == 0 && d.off1 % gran == 0)),
                 "fgt_conv2d: source strides/offsets must be multiples of %d elements", gran);
     if (d.in_split) {
         FGT_REQUIRE(d.precision == FGT_PREC_BF16X3, "fgt_conv2d: split inputs need FGT_PREC_BF16X3");
         FGT_REQUIRE(d.in_relu == 0, "fgt_conv2d: in_relu cannot be applied to split inputs (the producer applies it)");
-        FGT_REQUIRE(d.ps0 % 8 == 0 && d.ps0 > 0 && (d.C1 == 0 || (d.ps1 % 8 == 0 && d.ps1 > 0)), "fgt_conv2d: plane strides must be positive multiples of 8");
+        FGT_REQUIRE(d.in_split == 2 || (d.ps0 % 8 == 0 && d.ps0 > 0 && (d.C1 == 0 || (d.ps1 % 8 == 0 && d.ps1 > 0))), "fgt_conv2d: plane strides must be positive multiples of 8");
     }
     FGT_REQUIRE(d.out_split >= 0 && d.out_split <= 2, "fgt_conv2d: out_split must be 0, 1 or 2");
     FGT_REQUIRE(d.out_split == 1 || out != nullptr, "fgt_conv2d: null output");
@@ -382,6 +387,8 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
         FGT_REQUIRE(p.Cout_g % 4 == 0 && !d.out_nchw && d.ldo_s % 4 == 0 && d.ooff_s % 4 == 0 && d.pso % 4 == 0 && d.pso > 0,
                     "fgt_conv2d: out_split needs Cout/groups, ldo_s, ooff_s, pso multiples of 4 and NHWC output");
         FGT_REQUIRE(d.out_split == 1 || (d.ldo % 4 == 0 && d.ooff % 4 == 0), "fgt_conv2d: out_split = 2 needs ldo, ooff multiples of 4");
+        FGT_REQUIRE(d.pso != 32 || (p.Cout_g % 32 == 0 && d.ooff_s % 32 == 0 && d.ldo_s % 64 == 0),
+                    "fgt_conv2d: interleaved out_s (pso = 32) needs Cout/groups, ooff_s multiples of 32 and ldo_s a multiple of 64");
         FGT_REQUIRE(d.epi == FGT_EPI_NONE || d.ld_aux1 % 4 == 0, "fgt_conv2d: out_split needs ld_aux1 % 4 == 0");
         FGT_REQUIRE(d.epi != FGT_EPI_GRU || d.ld_aux2 % 4 == 0, "fgt_conv2d: out_split needs ld_aux2 % 4 == 0");
     }

@@ -52,14 +52,18 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     const __bf16* const zp = reinterpret_cast<const __bf16*>(p.zero_page);
     // (copied out of the kernel-argument struct: a select between two struct fields would otherwise be compiled as a
     //  select between their ADDRESSES followed by a vector load from the argument segment, i.e. a vmcnt(0) in the loop)
+    // il: hi/lo interleaved per 32 channels (in_split = 2): logical channel c -> element (c/32)*64 + c%32, lo 32 further.  A lane's
+    // chunk column kc*8 is the same in every K-step, so the element offset of logical channel chb + ci is 2*(chb + ci) - kc*8.
+    const bool il = d.in_split == 2;
     const int ld0 = d.ld0, ld1 = d.ld1;
-    const int chb0 = d.off0 + g * p.Cg0, chb1 = d.off1 + g * p.Cg1 - p.Cg0;
-    const long ps0 = p.ps0, ps1 = p.ps1;
+    const int chb0 = (d.off0 + g * p.Cg0) << (il ? 1 : 0), chb1 = (d.off1 + g * p.Cg1 - p.Cg0) << (il ? 1 : 0);
+    const long ps0 = il ? 32 : p.ps0, ps1 = il ? 32 : p.ps1;
     const int Cg0 = p.Cg0, Cg = p.Cg;
 
     // ---- this lane's DMA rows: row (lane >> 2) of each of its 16-row groups, k-chunk kc of every K-step
     const int lrow = lane >> 2;
     const int kc = (lane & 3) ^ ((lane >> 4) & 3);      // swizzle on the source side (all groups start at multiples of 16 rows)
+    const int il_sh = il ? 1 : 0, il_sub = il ? kc * 8 : 0;
     int a_iy0[A_IT], a_ix0[A_IT], a_nb[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
@@ -110,11 +114,13 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
 
     // weights: [2][groups][Npad][Kpad] bf16
     const __bf16* wrow[B_IT];
-    const long w_ps = (long)d.groups * d.Npad * d.Kpad;
+    const bool wil = d.w_il != 0;                       // interleaved weights: rows of 2*Kpad, [hi 32 | lo 32] per K-step
+    const long w_ps = wil ? 32 : (long)d.groups * d.Npad * d.Kpad;
+    const int w_adv = wil ? 2 * BK : BK;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         const int brow = bn0 + (wave + it * NW) * 16 + lrow;          // rows past Npad (tiles wider than the 128-row padding): zeros
-        wrow[it] = brow < d.Npad ? reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + brow) * d.Kpad + kc * 8 : nullptr;
+        wrow[it] = brow < d.Npad ? reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + brow) * (wil ? 2 * d.Kpad : d.Kpad) + kc * 8 : nullptr;
     }
 
     char* const lds = reinterpret_cast<char*>(smem);
@@ -125,7 +131,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const bool ok = kval && ((a_okmask >> it) & 1u);
-            const __bf16* src = a_base[it] + ci;
+            const __bf16* src = a_base[it] + ((ci << il_sh) - il_sub);
             char* dst = st + (wave + it * NW) * 1024;
             glds16(ok ? src : zp, dst);                          // A_hi rows
             glds16(ok ? src + a_ps : zp, dst + BM * 64);         // A_lo rows
@@ -138,7 +144,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
                 glds16(bok ? wrow[it] : zp, dst);                           // B_hi
                 glds16(bok ? wrow[it] + w_ps : zp, dst + BN * 64);          // B_lo
             }
-            if (BN <= 128 || wrow[it] != nullptr) wrow[it] += BK;
+            if (BN <= 128 || wrow[it] != nullptr) wrow[it] += w_adv;
         }
         k_cur += BK;
         ci += BK;

@@ -108,7 +108,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 if (want_split) {       // validated by the host: vec_ok holds whenever out_split is set
                     uint2 hi, lo;
                     split4(make_float4(v[0], v[1], v[2], v[3]), hi, lo);
-                    __bf16* o = p.out_s + (long)m * d.ldo_s + d.ooff_s + co;
+                    const int cs = d.ooff_s + co;       // pso == 32: interleaved layout, channel c -> (c/32)*64 + c%32, lo 32 further
+                    __bf16* o = p.out_s + (long)m * d.ldo_s + (p.pso == 32 ? ((cs >> 5) << 6) + (cs & 31) : cs);
                     *reinterpret_cast<uint2*>(o) = hi;
                     *reinterpret_cast<uint2*>(o + p.pso) = lo;
                 }

@@ -242,7 +242,7 @@ __global__ void split_kernel(const float* __restrict__ x, long rows, int C4, int
         if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
         uint2 hi, lo;
         fgt_split4(v, hi, lo);
-        __bf16* o = out + r * ld_s + c;
+        __bf16* o = out + r * ld_s + (ps == 32 ? ((c >> 5) << 6) + (c & 31) : c);     // ps == 32: interleaved per 32 channels
         *reinterpret_cast<uint2*>(o) = hi;
         *reinterpret_cast<uint2*>(o + ps) = lo;
     }

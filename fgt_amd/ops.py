@@ -66,21 +66,27 @@ def _require_dev(*ts):
 
 
 class Split:
-    """A "split" activation tensor (include/fgt_hip.h, fgt_conv_desc.in_split): `data` is bf16 [2, *shape]; data[0] = hi =
-    bf16_rne(x), data[1] = lo = bf16_rne(x - hi) of the fp32 tensor `shape` it stands for.  Produced once by the kernel that
-    computes x (conv epilogue, layernorm, fold, attention, or ops.split), consumed by fgt_conv2d's LDS-DMA loader."""
+    """A "split" activation tensor (include/fgt_hip.h, fgt_conv_desc.in_split): the bf16 pair hi = bf16_rne(x),
+    lo = bf16_rne(x - hi) of the fp32 tensor `shape` it stands for (same bytes as fp32).  Two layouts:
+      planes       data = bf16 [2, *shape]: data[0] = hi, data[1] = lo (any channel count that is a multiple of 8);
+      interleaved  data = bf16 [*shape[:-1], 2*C]: per 32 channels [hi 32 | lo 32], so the 64 + 64 bytes one K-step of the conv
+                   kernel needs from a pixel are ONE 128-byte line (C % 32 == 0).
+    Produced once by the kernel that computes x (conv epilogue or ops.split), consumed by fgt_conv2d's LDS-DMA loader."""
 
-    def __init__(self, data):
-        assert data.dtype == torch.bfloat16 and data.shape[0] == 2 and data.is_cuda
-        self.data = data
+    def __init__(self, data, interleaved=False):
+        assert data.dtype == torch.bfloat16 and data.is_cuda and (interleaved or data.shape[0] == 2)
+        self.data, self.il = data, interleaved
 
     @staticmethod
-    def empty(shape, device):
+    def empty(shape, device, interleaved=False):
+        if interleaved:
+            assert shape[-1] % 32 == 0, "interleaved split tensors need C % 32 == 0"
+            return Split(torch.empty(tuple(shape[:-1]) + (2 * shape[-1],), dtype=torch.bfloat16, device=device), True)
         return Split(torch.empty((2,) + tuple(shape), dtype=torch.bfloat16, device=device))
 
     @property
     def shape(self):
-        return self.data.shape[1:]
+        return torch.Size(tuple(self.data.shape[:-1]) + (self.data.shape[-1] // 2,)) if self.il else self.data.shape[1:]
 
     @property
     def device(self):
@@ -88,31 +94,40 @@ class Split:
 
     @property
     def hi(self):
-        return self.data[0]
+        """The tensor whose data_ptr / strides describe the hi values (planes: plane 0; interleaved: the 2*C-wide rows)."""
+        return self.data if self.il else self.data[0]
 
     @property
     def ps(self):
-        return self.data.stride(0)
+        return 32 if self.il else self.data.stride(0)
 
     def view(self, *shape):
-        return Split(self.data.view(2, *shape))
+        return Split(self.data.view(*shape[:-1], 2 * shape[-1]), True) if self.il else Split(self.data.view(2, *shape))
 
     def __getitem__(self, idx):            # leading-dimension slices (rows / frames)
-        return Split(self.data[:, idx])
+        return Split(self.data[idx], True) if self.il else Split(self.data[:, idx])
+
+    def planes(self):
+        """(hi, lo) as bf16 tensors of the logical shape (tests / debugging)."""
+        if not self.il:
+            return self.data[0], self.data[1]
+        d = self.data.reshape(*self.data.shape[:-1], -1, 2, 32)
+        return d[..., 0, :].reshape(self.shape), d[..., 1, :].reshape(self.shape)
 
     def float(self):
         """hi + lo as fp32 (tests / debugging: 16 mantissa bits of the original)."""
-        return self.data[0].float() + self.data[1].float()
+        hi, lo = self.planes()
+        return hi.float() + lo.float()
 
 
-def split(x, relu=False, out=None):
+def split(x, relu=False, out=None, interleave=False):
     """fp32 [rows, C] / [N,H,W,C] -> Split (fgt_split)."""
     _require_dev(x)
     x4, N, H, W, Cc, ld = _as_map(x)
     if out is None:
-        out = Split.empty(x.shape, x.device)
+        out = Split.empty(x.shape, x.device, interleave)
     o4, oN, oH, oW, oC, ldo = _as_map(out.hi)
-    assert (oN * oH * oW, oC) == (N * H * W, Cc)
+    assert (oN * oH * oW, oC) == (N * H * W, Cc * (2 if out.il else 1))
     check(_lib.lib().fgt_split(_ptr(x4), N * H * W, Cc, ld, _ptr(out.data), ldo, out.ps, int(relu), _stream()), "fgt_split")
     return out
 
@@ -171,23 +186,33 @@ class PackedConv:
         self.scale = None if scale is None else scale.detach().float().contiguous()
 
 
-def _split_weights(pc):
-    """[2, groups, Npad, Kpad] bf16: hi = bf16_rne(w), lo = bf16_rne(w - hi) — the bf16x3 kernel's weight image."""
-    if pc._w_split is None:
+WEIGHTS_INTERLEAVED = os.environ.get("FGT_W_IL", "1") != "0"
+
+
+def _split_weights(pc, interleaved=None):
+    """The bf16x3 kernels' weight image: hi = bf16_rne(w), lo = bf16_rne(w - hi), as two planes [2, groups, Npad, Kpad] or
+    (fgt_conv_desc.w_il) interleaved per K-step [groups, Npad, Kpad/32, (hi 32 | lo 32)] — one 128-byte line per row and step."""
+    il = WEIGHTS_INTERLEAVED if interleaved is None else interleaved
+    cache = pc.__dict__.setdefault("_w_split_cache", {})
+    if il not in cache:
         hi = pc.w.to(torch.bfloat16)
         lo = (pc.w - hi.float()).to(torch.bfloat16)
-        pc._w_split = torch.stack([hi, lo], 0).contiguous()
-    return pc._w_split
+        if il:
+            G, Np, Kp = hi.shape
+            cache[il] = torch.stack([hi.view(G, Np, Kp // 32, 32), lo.view(G, Np, Kp // 32, 32)], 3).contiguous()
+        else:
+            cache[il] = torch.stack([hi, lo], 0).contiguous()
+    return cache[il], il
 
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
            epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None,
-           out_split=None, out_s=None):
+           out_split=None, out_s=None, out_il=False):
     """fgt_conv2d.  x (and optional x1) are channels-last maps (fp32 tensors, or `Split`s for the LDS-DMA bf16x3 path);
     returns/outputs a channels-last map (or NCHW).  out_split: None -> fp32 result; "only" -> a Split; "both" -> (fp32, Split)."""
     in_split = isinstance(x, Split)
     if in_split:
-        assert x1 is None or isinstance(x1, Split), "conv2d: both sources must be split"
+        assert x1 is None or (isinstance(x1, Split) and x1.il == x.il), "conv2d: both sources must be split the same way"
         xs, x1s = x, x1
         x, x1 = xs.hi, (None if x1s is None else x1s.hi)
     else:
@@ -198,6 +223,8 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     if x1 is not None:
         x1, N1, H1, W1, C1, ld1 = _as_map(x1)
         assert (N1, H1, W1) == (N, H, W), "conv2d: sources differ in geometry"
+    if in_split and xs.il:
+        C0, C1 = C0 // 2, C1 // 2                    # interleaved rows hold 2*C elements
     assert C0 + C1 == pc.Cin, f"conv2d: input channels {C0}+{C1} != packed {pc.Cin}"
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
@@ -230,7 +257,7 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     d.precision = PREC[precision if precision is not None else DEFAULT_CONV_PRECISION]
     if pc.Cout // pc.groups <= 4 and d.tile == 0 and not in_split and not osp:
         d.precision = 0                      # Cout <= 4 layers run the fp32 VALU direct-conv kernels
-    d.in_split = int(in_split)
+    d.in_split = (2 if xs.il else 1) if in_split else 0
     if in_split:
         if d.precision != PREC["bf16x3"]:
             raise RuntimeError("conv2d: Split inputs need precision='bf16x3'")
@@ -238,16 +265,20 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     d.out_split = osp
     if osp:
         if out_s is None:
-            out_s = Split.empty((N, Ho, Wo, pc.Cout), x.device)
+            out_s = Split.empty((N, Ho, Wo, pc.Cout), x.device, interleaved=bool(out_il))
         s4, sN, sH, sW, sC, ldo_s = _as_map(out_s.hi)
-        assert (sN * sH * sW, sC) == (N * Ho * Wo, pc.Cout), f"conv2d: out_s shape {tuple(out_s.shape)}"
+        assert (sN * sH * sW, sC) == (N * Ho * Wo, pc.Cout * (2 if out_s.il else 1)), f"conv2d: out_s shape {tuple(out_s.shape)}"
         d.ldo_s, d.ooff_s, d.pso = ldo_s, 0, out_s.ps
-    wbuf = pc.w if d.precision == 0 else _split_weights(pc)
+    if d.precision == 0:
+        wbuf = pc.w
+    else:
+        wbuf, wil = _split_weights(pc)
+        d.w_il = int(wil)
     args = (C.byref(d), _ptr(x), _ptr(x1), _ptr(wbuf), _ptr(pc.scale), _ptr(pc.bias), _ptr(aux1), _ptr(aux2), _ptr(out),
             _ptr(None if out_s is None else out_s.data))
     if d.tile == 0 and AUTOTUNE and pc.Cout // pc.groups > 4:
         key = (N, H, W, C0, C1, pc.Cout, pc.groups, pc.kh, pc.kw, sh, sw, ph, pw, dh, dw, d.upsample, d.epi, d.out_nchw, d.precision,
-               d.in_split, d.out_split)
+               d.in_split, d.out_split, d.w_il, int(bool(osp) and out_s.il))
         best = _tile_cache.get(key)
         if best is None:
             best = _tile_cache[key] = _autotune(d, args)

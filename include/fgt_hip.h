@@ -90,10 +90,17 @@ typedef struct fgt_conv_desc {
      * its im2col tiles global -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4) and does no conversion at all.        */
     int in_split;           /* 0: x0/x1 are fp32 (split inside the kernel, per tile)
                              * 1: x0/x1 point to split tensors; ld/off in bf16 elements; needs Cin/groups, ld, off % 8 == 0,
-                             *    in_relu == 0 (the producer applies it)                                                 */
+                             *    in_relu == 0 (the producer applies it)
+                             * 2: as 1 but hi/lo INTERLEAVED per 32 channels: channel c of a pixel lives at element
+                             *    (c/32)*64 + c%32 (hi) and +32 (lo) of a row of 2*C elements, so the 32 hi and 32 lo values of
+                             *    one K-step are ONE 128-byte line (planes: two half-used lines).  ld* = row stride in elements
+                             *    (>= 2*C), off* = LOGICAL first channel; needs Cin/groups and off % 32 == 0; ps* unused.    */
     int out_split;          /* 0: fp32 `out` only | 1: split `out_s` only | 2: both (needs Cout/groups, ldo_s, ooff_s % 4 == 0,
                              *    out_nchw == 0)                                                                         */
-    int ldo_s, ooff_s;      /* row stride / first channel of out_s (bf16 elements)                                       */
+    int ldo_s, ooff_s;      /* row stride / first channel of out_s (bf16 elements; out_split with pso == 32 writes the
+                             * interleaved layout of in_split = 2: ldo_s >= 2*Cout, needs Cout/groups % 32 == 0)          */
+    int w_il;               /* 1: w_packed is [groups][Npad][Kpad/32][hi 32 | lo 32] (interleaved) instead of two planes   */
+    int reserved0;
     long long ps0, ps1, pso;/* plane strides (bf16 elements) of x0, x1, out_s                                            */
 } fgt_conv_desc;
 

@@ -149,3 +149,62 @@ def test_split_rejections(dev):
         ops.conv2d(ops.split(x), pc, pad=1, precision="fp32")
     with pytest.raises(RuntimeError, match="in_relu"):
         ops.conv2d(ops.split(x), pc, pad=1, precision="bf16x3", in_relu=True, tile="64x64")
+
+
+# ---- interleaved layout (in_split = 2, w_il): [hi 32 | lo 32] per 32 channels = one 128-byte line per pixel and K-step
+IL_CASES = [c for c in SPLIT_CASES if (c[4] // c[10]) % 32 == 0]
+
+
+def test_split_interleaved_format(dev):
+    from fgt_amd import ops
+    x = _rand(3, 5, 7, 96, seed=1, scale=2.0).to(dev)
+    a, b = ops.split(x), ops.split(x, interleave=True)
+    assert b.data.shape == (3, 5, 7, 192) and tuple(b.shape) == (3, 5, 7, 96)
+    hi, lo = b.planes()
+    assert torch.equal(hi, a.data[0]) and torch.equal(lo, a.data[1])
+    assert torch.equal(b.data[..., 0:32], a.data[0][..., 0:32]) and torch.equal(b.data[..., 32:64], a.data[1][..., 0:32])
+    assert torch.equal(b.data[..., 64:96], a.data[0][..., 32:64])
+
+
+@pytest.mark.parametrize("case", IL_CASES, ids=[c[0] for c in IL_CASES])
+@pytest.mark.parametrize("tile", ["128x128", "64x64", "128x128x8", "256x128x16", "256x256x8"])
+@pytest.mark.parametrize("w_il", [False, True], ids=["w-planes", "w-interleaved"])
+def test_conv_interleaved_inputs_bit_equal(case, tile, w_il, dev, monkeypatch):
+    from fgt_amd import ops
+    name, N, H, W, Cin, Cout, k, s, p, d, g = case
+    kh, kw = (k, k) if isinstance(k, int) else k
+    x = _rand(N, H, W, Cin, seed=1).to(dev)
+    w = _rand(Cout, Cin // g, kh, kw, seed=2, scale=1.0 / math.sqrt(Cin // g * kh * kw))
+    pc = ops.PackedConv(w.to(dev), _rand(Cout, seed=3).to(dev), groups=g)
+    monkeypatch.setattr(ops, "WEIGHTS_INTERLEAVED", False)
+    ref = ops.conv2d(x, pc, stride=s, pad=p, dil=d, act="lrelu", tile="128x128", precision="bf16x3")
+    monkeypatch.setattr(ops, "WEIGHTS_INTERLEAVED", w_il)
+    a = ops.conv2d(x, pc, stride=s, pad=p, dil=d, act="lrelu", tile=tile if tile != "256x256x8" else "128x128", precision="bf16x3")
+    b = ops.conv2d(ops.split(x, interleave=True), pc, stride=s, pad=p, dil=d, act="lrelu", tile=tile, precision="bf16x3")
+    c = ops.conv2d(ops.split(x), pc, stride=s, pad=p, dil=d, act="lrelu", tile=tile, precision="bf16x3")
+    assert torch.equal(a, ref) and torch.equal(b, ref) and torch.equal(c, ref)
+
+
+def test_conv_interleaved_two_source_and_out_il(dev):
+    from fgt_amd import ops
+    N, H, W, g = 2, 15, 27, 2
+    x0, o = _rand(N, H, W, 256, seed=1).to(dev), _rand(N, H, W, 384, seed=2).to(dev)
+    w, b = _rand(512, 640 // g, 3, 3, seed=3, scale=0.05), _rand(512, seed=4)
+    pc = ops.PackedConv(w.to(dev), b.to(dev), groups=g)
+    ref = ops.conv2d(x0, pc, x1=o, stride=1, pad=1, act="lrelu", precision="bf16x3")
+    for tile in ("auto", "128x128x8", "64x64"):
+        r32, rs = ops.conv2d(ops.split(x0, interleave=True), pc, x1=ops.split(o, interleave=True), stride=1, pad=1, act="lrelu",
+                             precision="bf16x3", tile=tile, out_split="both", out_il=True)
+        assert torch.equal(r32, ref) and rs.il
+        hi, lo = rs.planes()
+        want = ops.split(ref)
+        assert torch.equal(hi, want.data[0]) and torch.equal(lo, want.data[1])
+    # conv -> conv chain in interleaved form
+    w2 = _rand(64, 512, 3, 3, seed=5, scale=0.02)
+    pc2 = ops.PackedConv(w2.to(dev), None)
+    a = ops.conv2d(ref, pc2, pad=1, stride=2, precision="bf16x3")
+    bb = ops.conv2d(rs, pc2, pad=1, stride=2, precision="bf16x3")
+    assert torch.equal(a, bb)
+    with pytest.raises(RuntimeError, match="multiples of 32"):
+        ops.conv2d(ops.Split(torch.zeros(1, 8, 8, 80, dtype=torch.bfloat16, device=dev), True),
+                   ops.PackedConv(_rand(16, 40, 3, 3, seed=2).to(dev), None), pad=1, precision="bf16x3", tile="64x64")
