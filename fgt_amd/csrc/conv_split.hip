@@ -14,9 +14,13 @@
 // on the SOURCE side: lane l fetches the k-chunk (l & 3) ^ ((l >> 4) & 3) of its row.  Out-of-image taps and the K tail read
 // the library's zero page (select on the address).
 //
-// Pipeline: two LDS stages; tile kt+1's DMAs are issued at the top of step kt and land while the 12-24 MFMAs of the step
-// run; `s_waitcnt vmcnt(0)` + one barrier per K-step publishes them (the reads of a stage happen strictly after the
-// barrier that follows the wait, as the LDS-DMA ordering rule requires).
+// Pipeline: a ring of NS LDS stages.  At the top of step kt the DMAs of tile kt+NS-1 are issued into the stage whose reads ended
+// before the previous barrier; the step's fragment reads and MFMAs run on stage kt % NS; then `s_waitcnt vmcnt(DPT*(NS-2))`
+// (DPT = DMA instructions per tile and wavefront, a compile-time constant: every wavefront issues the same number, each as ONE
+// instruction whatever the lanes' in-image predicates) retires tile kt+1 and leaves the younger tiles in flight across the
+// barrier that publishes it (raw s_barrier: __syncthreads() would drain vmcnt to 0).  The reads of a stage happen strictly
+// after the barrier that follows the wait, as the LDS-DMA ordering rule requires.  NS = 2 is the plain double buffer
+// (two workgroups per CU cover each other); NS = 3 with a 256x128 tile is one workgroup per CU with 96 KB of tiles in flight.
 #include "conv_tile.h"
 
 namespace {
@@ -28,15 +32,29 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int MINW, bool PIN>
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 15, "vmcnt immediate");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else static_assert(N == 0, "add the immediate");
+}
+
+template <int BM, int BN, int WM, int WN, int MINW, int NS>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const ConvP p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr int STAGE = (BM + BN) * LDB;              // floats per stage (= (BM+BN) * 64 bf16 = hi + lo planes)
     constexpr int GA = BM / 16, GB = BN / 16;           // 16-row DMA groups per plane
-    constexpr int A_IT = GA / NW;                       // A groups per wavefront
-    constexpr int B_IT = (GB + NW - 1) / NW;            // B groups per wavefront (the last may be absent)
-    static_assert(GA % NW == 0 && A_IT >= 1 && TM >= 1 && TN >= 1, "tile / wavefront geometry");
+    constexpr int A_IT = GA / NW;                       // A groups per wavefront (hi and lo plane of the same rows)
+    constexpr int B_IT = 2 * GB / NW;                   // B (group, plane) pieces per wavefront: piece j = wave + it*NW -> plane j / GB, group j % GB
+    constexpr int DPT = 2 * A_IT + B_IT;                // DMA instructions per tile and wavefront
+    static_assert(GA % NW == 0 && A_IT >= 1 && (2 * GB) % NW == 0 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile / wavefront geometry");
+    static_assert(NS >= 2 && NS <= 4, "LDS ring depth");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const fgt_conv_desc& d = p.d;
@@ -112,39 +130,46 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     };
     retap();
 
-    // weights: [2][groups][Npad][Kpad] bf16
+    // weights: planes [2][groups][Npad][Kpad] bf16, or interleaved rows of 2*Kpad (w_il)
     const __bf16* wrow[B_IT];
-    const bool wil = d.w_il != 0;                       // interleaved weights: rows of 2*Kpad, [hi 32 | lo 32] per K-step
+    const bool wil = d.w_il != 0;                       // interleaved weights: [hi 32 | lo 32] per K-step
     const long w_ps = wil ? 32 : (long)d.groups * d.Npad * d.Kpad;
     const int w_adv = wil ? 2 * BK : BK;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        const int brow = bn0 + (wave + it * NW) * 16 + lrow;          // rows past Npad (tiles wider than the 128-row padding): zeros
-        wrow[it] = brow < d.Npad ? reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + brow) * (wil ? 2 * d.Kpad : d.Kpad) + kc * 8 : nullptr;
+        const int piece = wave + it * NW, plane = piece / GB, grp = piece % GB;
+        const int brow = bn0 + grp * 16 + lrow;          // rows past Npad (tiles wider than the 128-row padding): zeros
+        wrow[it] = brow < d.Npad ? reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + brow) * (wil ? 2 * d.Kpad : d.Kpad) + kc * 8 + plane * w_ps
+                                 : nullptr;
     }
 
     char* const lds = reinterpret_cast<char*>(smem);
     constexpr int STAGE_B = STAGE * 4;
-    auto issue_tile = [&](int buf) {
-        char* st = lds + buf * STAGE_B;
+    // one DMA instruction per piece whatever the predicates: the zero-page select is arithmetic on the address (a select between
+    // a uniform and a per-lane pointer gets compiled into two exec-masked instructions, which would make the vmcnt count vary)
+    const unsigned long zpi = reinterpret_cast<unsigned long>(zp);
+    auto sel = [&](const __bf16* ptr, bool ok) {
+        const unsigned long a = reinterpret_cast<unsigned long>(ptr);
+        return reinterpret_cast<const void*>(zpi + ((a - zpi) & (ok ? ~0ul : 0ul)));
+    };
+    auto issue_tile = [&](int slot) {
+        char* st = lds + slot * STAGE_B;
         const bool kval = k_cur < p.K;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const bool ok = kval && ((a_okmask >> it) & 1u);
             const __bf16* src = a_base[it] + ((ci << il_sh) - il_sub);
             char* dst = st + (wave + it * NW) * 1024;
-            glds16(ok ? src : zp, dst);                          // A_hi rows
-            glds16(ok ? src + a_ps : zp, dst + BM * 64);         // A_lo rows
+            glds16(sel(src, ok), dst);                           // A_hi rows
+            glds16(sel(src + a_ps, ok), dst + BM * 64);          // A_lo rows
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            if (GB % NW == 0 || wave + it * NW < GB) {           // wave-uniform
-                char* dst = st + 2 * BM * 64 + (wave + it * NW) * 1024;
-                const bool bok = BN <= 128 || wrow[it] != nullptr;
-                glds16(bok ? wrow[it] : zp, dst);                           // B_hi
-                glds16(bok ? wrow[it] + w_ps : zp, dst + BN * 64);          // B_lo
-            }
-            if (BN <= 128 || wrow[it] != nullptr) wrow[it] += w_adv;
+            const int piece = wave + it * NW, plane = piece / GB, grp = piece % GB;    // wave-uniform
+            char* dst = st + 2 * BM * 64 + plane * BN * 64 + grp * 1024;
+            const bool bok = BN <= 128 || wrow[it] != nullptr;
+            glds16(sel(wrow[it], bok), dst);
+            if (bok) wrow[it] += w_adv;
         }
         k_cur += BK;
         ci += BK;
@@ -167,12 +192,17 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
 
     const int l31 = lane & 31, lh = lane >> 5;
 
-    issue_tile(0);
-    __syncthreads();            // (emits s_waitcnt vmcnt(0): the DMAs are LDS writes in flight)
+    // ---- prologue: tiles 0 .. NS-2 in flight, tile 0 landed
+    constexpr int AHEAD = NS - 1;
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t)
+        if (t < p.nk) issue_tile(t);
+    if (p.nk >= AHEAD) wait_vmcnt<DPT * (AHEAD - 1)>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    int slot = 0, slot_in = AHEAD % NS;
     for (int kt = 0; kt < p.nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < p.nk) issue_tile(buf ^ 1);
-        const __bf16* base = reinterpret_cast<const __bf16*>(smem + buf * STAGE);
+        if (kt + AHEAD < p.nk) issue_tile(slot_in);
+        const __bf16* base = reinterpret_cast<const __bf16*>(smem + slot * STAGE);
         // operand rows: wave-tile base (multiple of 32) + l31, so (row >> 2) & 3 == (l31 >> 2) & 3 for every fragment
         bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
 #pragma unroll
@@ -191,7 +221,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
                 bl[ks][j] = *reinterpret_cast<const bf16x8*>(Bhi + BN * LDB + j * 32 * LDB);
             }
         }
-        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);   // keep all fragment reads of the step ahead of its MFMAs
+        __builtin_amdgcn_sched_barrier(0);   // keep all fragment reads of the step ahead of its MFMAs
         // same product order as conv_igemm.hip (lo*hi, hi*lo, hi*hi per k-half): bit-identical accumulators
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -208,22 +238,28 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
         }
-        // (the barrier and its vmcnt(0) must stay BEHIND the MFMAs: hoisted above them, the DMA latency of tile kt+1 is exposed
-        //  in front of this wavefront's matrix work instead of running underneath it)
-        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        // The wait + barrier stay BEHIND the MFMAs (hoisted above them, the DMA latency would be exposed in front of this
+        // wavefront's matrix work instead of running underneath it).  Tile kt+1 must have landed; while NS-2 younger tiles exist
+        // they stay in flight (the last NS-2 steps drain everything: a constant immediate needs a constant tile count).
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + AHEAD < p.nk) wait_vmcnt<DPT * (AHEAD - 1)>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        slot_in = slot_in + 1 == NS ? 0 : slot_in + 1;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
 }
 
-template <int BM, int BN, int WM, int WN, int MINW, bool PIN>
-int launch_pin(const ConvP& p, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2>
+int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
-    constexpr size_t smem = 2ul * (BM + BN) * LDB * sizeof(float);
+    constexpr size_t smem = (size_t)NS * (BM + BN) * LDB * sizeof(float);
+    static_assert(smem <= 160 * 1024, "LDS ring does not fit");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, PIN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
             fgt_set_error("hipFuncSetAttribute(conv_split %dx%d): %s", BM, BN, hipGetErrorString(e));
@@ -236,14 +272,8 @@ int launch_pin(const ConvP& p, hipStream_t s) {
     q.ntiles = cdiv(p.Cout_g, BN);
     q.mchunk = cdiv(q.mtiles, 8);
     dim3 grid(q.xcd_swizzle ? 8 * q.mchunk * q.ntiles : q.mtiles * q.ntiles, p.d.groups);
-    hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, MINW, PIN>), grid, dim3(NT), smem, s, q);
+    hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, MINW, NS>), grid, dim3(NT), smem, s, q);
     return fgt_check_launch("conv_split");
-}
-
-template <int BM, int BN, int WM, int WN, int MINW = 2>
-int launch(const ConvP& p, hipStream_t s) {
-    // p.pipe (FGT_CONV_PIPE, default 1): 1 = fragment reads pinned ahead of the MFMAs, 0 = the compiler's own interleave
-    return p.pipe ? launch_pin<BM, BN, WM, WN, MINW, true>(p, s) : launch_pin<BM, BN, WM, WN, MINW, false>(p, s);
 }
 
 }  // namespace
@@ -258,7 +288,9 @@ int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_128x128x8: return launch<128, 128, 2, 4, 4>(p, s);
         case FGT_TILE_256x128x16: return launch<256, 128, 4, 4, 4>(p, s);
         case FGT_TILE_256x64x8: return launch<256, 64, 4, 2, 2>(p, s);
-        case FGT_TILE_256x256x8: return launch<256, 256, 2, 4, 2>(p, s);
+        case FGT_TILE_256x128x8_S3: return launch<256, 128, 4, 2, 2, 3>(p, s);       // one workgroup per CU, 3-stage ring (144 KB)
+        case FGT_TILE_256x128x16_S3: return launch<256, 128, 4, 4, 4, 3>(p, s);
+        case FGT_TILE_128x128x8_S4: return launch<128, 128, 2, 4, 4, 4>(p, s);        // one workgroup per CU, 4-stage ring (128 KB)
         default: fgt_set_error("fgt_conv2d: unknown tile %d", tile); return FGT_EINVAL;
     }
 }
