@@ -44,7 +44,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N == 0, "add the immediate");
 }
 
-template <int BM, int BN, int WM, int WN, int MINW, int NS>
+template <int BM, int BN, int WM, int WN, int MINW, int NS, bool PP>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const ConvP p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     constexpr int DPT = 2 * A_IT + B_IT;                // DMA instructions per tile and wavefront
     static_assert(GA % NW == 0 && A_IT >= 1 && (2 * GB) % NW == 0 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile / wavefront geometry");
     static_assert(NS >= 2 && NS <= 4, "LDS ring depth");
+    static_assert(!PP || (NS >= 3 && NW % 2 == 0), "ping-pong needs a ring of >= 3 stages and an even wavefront count");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const fgt_conv_desc& d = p.d;
@@ -200,11 +201,10 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     if (p.nk >= AHEAD) wait_vmcnt<DPT * (AHEAD - 1)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     int slot = 0, slot_in = AHEAD % NS;
-    for (int kt = 0; kt < p.nk; ++kt) {
-        if (kt + AHEAD < p.nk) issue_tile(slot_in);
+
+    auto read_frags = [&](bf16x8 (&ah)[2][TM], bf16x8 (&al)[2][TM], bf16x8 (&bh)[2][TN], bf16x8 (&bl)[2][TN]) {
         const __bf16* base = reinterpret_cast<const __bf16*>(smem + slot * STAGE);
         // operand rows: wave-tile base (multiple of 32) + l31, so (row >> 2) & 3 == (l31 >> 2) & 3 for every fragment
-        bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int so = swz(l31, ks * 2 + lh);
@@ -221,8 +221,9 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
                 bl[ks][j] = *reinterpret_cast<const bf16x8*>(Bhi + BN * LDB + j * 32 * LDB);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep all fragment reads of the step ahead of its MFMAs
-        // same product order as conv_igemm.hip (lo*hi, hi*lo, hi*hi per k-half): bit-identical accumulators
+    };
+    // same product order as conv_igemm.hip (lo*hi, hi*lo, hi*hi per k-half): bit-identical accumulators
+    auto mfmas = [&](bf16x8 (&ah)[2][TM], bf16x8 (&al)[2][TM], bf16x8 (&bh)[2][TN], bf16x8 (&bl)[2][TN]) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -238,28 +239,66 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
         }
-        // The wait + barrier stay BEHIND the MFMAs (hoisted above them, the DMA latency would be exposed in front of this
-        // wavefront's matrix work instead of running underneath it).  Tile kt+1 must have landed; while NS-2 younger tiles exist
-        // they stay in flight (the last NS-2 steps drain everything: a constant immediate needs a constant tile count).
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + AHEAD < p.nk) wait_vmcnt<DPT * (AHEAD - 1)>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        slot = slot + 1 == NS ? 0 : slot + 1;
-        slot_in = slot_in + 1 == NS ? 0 : slot_in + 1;
+    };
+
+    if constexpr (!PP) {
+        for (int kt = 0; kt < p.nk; ++kt) {
+            if (kt + AHEAD < p.nk) issue_tile(slot_in);
+            bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+            read_frags(ah, al, bh, bl);
+            __builtin_amdgcn_sched_barrier(0);   // keep all fragment reads of the step ahead of its MFMAs
+            mfmas(ah, al, bh, bl);
+            // The wait + barrier stay BEHIND the MFMAs (hoisted above them, the DMA latency would be exposed in front of this
+            // wavefront's matrix work instead of running underneath it).  Tile kt+1 must have landed; while NS-2 younger tiles
+            // exist they stay in flight (the last NS-2 steps drain everything: a constant immediate needs a constant count).
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + AHEAD < p.nk) wait_vmcnt<DPT * (AHEAD - 1)>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            slot_in = slot_in + 1 == NS ? 0 : slot_in + 1;
+        }
+    } else {
+        // Ping-pong: the wavefronts form two groups (one wavefront of each group per SIMD).  A step is two barrier-delimited
+        // phases, R = {issue the DMAs of tile kt+NS-1, read tile kt's fragments, wait until this wavefront's pieces of tile kt+1
+        // have landed} and M = {the MFMAs}.  Group 1 runs ONE barrier behind group 0, so in every interval one group is in R
+        // (LDS + address work) while the other is in M (matrix pipe): the two halves of a K-step that a lock-stepped workgroup
+        // serialises overlap across the groups.  Ordering (intervals numbered by barrier count, G0: R(k) in 2k, M(k) in 2k+1;
+        // G1 one later): tile k+1 is read from interval 2k+2 on, every wavefront's wait for its pieces sits in its R(k) (<= 2k+1);
+        // the stage of tile k-1 is overwritten from interval 2k on, its last reads are in G1's R(k-1) (2k-1).
+        const bool g1 = wave >= NW / 2;
+        if (g1) __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < p.nk; ++kt) {
+            if (kt + AHEAD < p.nk) issue_tile(slot_in);
+            bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+            read_frags(ah, al, bh, bl);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + AHEAD < p.nk) wait_vmcnt<DPT * (AHEAD - 1)>(); else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            mfmas(ah, al, bh, bl);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            slot_in = slot_in + 1 == NS ? 0 : slot_in + 1;
+        }
+        if (!g1) __builtin_amdgcn_s_barrier();
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
 }
 
-template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2>
+template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2, bool PP = false>
 int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr size_t smem = (size_t)NS * (BM + BN) * LDB * sizeof(float);
     static_assert(smem <= 160 * 1024, "LDS ring does not fit");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
             fgt_set_error("hipFuncSetAttribute(conv_split %dx%d): %s", BM, BN, hipGetErrorString(e));
@@ -272,7 +311,7 @@ int launch(const ConvP& p, hipStream_t s) {
     q.ntiles = cdiv(p.Cout_g, BN);
     q.mchunk = cdiv(q.mtiles, 8);
     dim3 grid(q.xcd_swizzle ? 8 * q.mchunk * q.ntiles : q.mtiles * q.ntiles, p.d.groups);
-    hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, MINW, NS>), grid, dim3(NT), smem, s, q);
+    hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP>), grid, dim3(NT), smem, s, q);
     return fgt_check_launch("conv_split");
 }
 
@@ -291,6 +330,8 @@ int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_256x128x8_S3: return launch<256, 128, 4, 2, 2, 3>(p, s);       // one workgroup per CU, 3-stage ring (144 KB)
         case FGT_TILE_256x128x16_S3: return launch<256, 128, 4, 4, 4, 3>(p, s);
         case FGT_TILE_128x128x8_S4: return launch<128, 128, 2, 4, 4, 4>(p, s);        // one workgroup per CU, 4-stage ring (128 KB)
+        case FGT_TILE_256x128x8_PP: return launch<256, 128, 4, 2, 2, 3, true>(p, s);  // + ping-pong wavefront groups
+        case FGT_TILE_128x128x8_PP: return launch<128, 128, 2, 4, 4, 4, true>(p, s);
         default: fgt_set_error("fgt_conv2d: unknown tile %d", tile); return FGT_EINVAL;
     }
 }
