@@ -439,7 +439,7 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     int rc;
     if (direct) rc = fgt_conv_direct(p, s);   // Cout <= 4: VALU direct conv (fp32)
     else if (d.in_split) rc = fgt_conv_split_launch(tile, p, s);
-    else if (tile >= FGT_TILE_256x256x8) { fgt_set_error("fgt_conv2d: tile %d needs split inputs", tile); rc = FGT_EINVAL; }
+    else if (tile >= FGT_TILE_256x128x8_S3) { fgt_set_error("fgt_conv2d: tile %d needs split inputs", tile); rc = FGT_EINVAL; }
     else rc = d.precision == 0 ? launch_tile<0>(tile, p, s) : launch_tile<1>(tile, p, s);
     if (prof) {
         hipEventRecord(rec.b, s);

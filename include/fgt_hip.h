@@ -115,7 +115,7 @@ typedef struct fgt_conv_desc {
 #define FGT_TILE_128x128x8 6   /* 128x128 tile on 8 wavefronts (64x32 each) */
 #define FGT_TILE_256x128x16 7  /* 256x128 tile on 16 wavefronts */
 #define FGT_TILE_256x64x8 8    /* 256x64 tile on 8 wavefronts (Cout = 64 layers) */
-#define FGT_TILE_256x256x8 9   /* (retired: the 256x256 one-workgroup tile spilled and measured slower; the code is rejected) */
+/* 9: retired (256x256 one-workgroup tiles: 8 wavefronts of 128x64 or 16 of 64x64 spill at their VGPR caps and measured slower) */
 #define FGT_TILE_256x128x8_S3 10  /* split inputs only: 256x128 on 8 wavefronts, 3-stage LDS-DMA ring, one workgroup per CU */
 #define FGT_TILE_256x128x16_S3 11 /* split inputs only: 256x128 on 16 wavefronts, 3-stage ring */
 #define FGT_TILE_128x128x8_S4 12  /* split inputs only: 128x128 on 8 wavefronts, 4-stage ring */

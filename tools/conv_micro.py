@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--tile", default="128x128")
     ap.add_argument("--precision", default="bf16x3")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--split", default="", choices=["", "planes", "il"], help="feed pre-split inputs (LDS-DMA kernel)")
     a = ap.parse_args()
     N, H, W, C0, C1, Cout, g, k, s, p = LAYERS[a.layer]
     dev = torch.device("cuda:0")
@@ -33,6 +34,9 @@ def main():
     x1 = torch.randn(N, H, W, C1, device=dev) if C1 else None
     w = torch.randn(Cout, (C0 + C1) // g, k, k, device=dev) * 0.02
     pc = ops.PackedConv(w, torch.zeros(Cout, device=dev), groups=g)
+    if a.split:
+        x = ops.split(x, interleave=a.split == "il")
+        x1 = None if x1 is None else ops.split(x1, interleave=a.split == "il")
     out = None
     for _ in range(3):
         out = ops.conv2d(x, pc, x1=x1, stride=s, pad=p, act="lrelu", tile=a.tile, precision=a.precision, out=out)
@@ -45,7 +49,7 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
     fl = 2.0 * out.numel() // Cout * (Cout // g) * pc.K * g
-    print(f"{a.layer} tile={a.tile} prec={a.precision}: {ms * 1e3:.1f} us/launch, {fl / ms / 1e9:.1f} TFLOP/s algorithmic")
+    print(f"{a.layer} tile={a.tile} prec={a.precision} split={a.split or 'no'}: {ms * 1e3:.1f} us/launch, {fl / ms / 1e9:.1f} TFLOP/s algorithmic")
 
 
 if __name__ == "__main__":
