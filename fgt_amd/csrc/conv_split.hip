@@ -44,7 +44,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N == 0, "add the immediate");
 }
 
-template <int BM, int BN, int WM, int WN, int MINW, int NS, bool PP, bool AREG>
+template <int BM, int BN, int WM, int WN, int MINW, int NS, bool PP>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const ConvP p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -56,7 +56,6 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     static_assert(GA % NW == 0 && A_IT >= 1 && (2 * GB) % NW == 0 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile / wavefront geometry");
     static_assert(NS >= 2 && NS <= 4, "LDS ring depth");
     static_assert(!PP || (NS >= 3 && NW % 2 == 0), "ping-pong needs a ring of >= 3 stages and an even wavefront count");
-    static_assert(!AREG || (NS == 2 && !PP), "register-staged A operand: double buffer only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const fgt_conv_desc& d = p.d;
@@ -154,7 +153,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
         const unsigned long a = reinterpret_cast<unsigned long>(ptr);
         return reinterpret_cast<const void*>(zpi + ((a - zpi) & (ok ? ~0ul : 0ul)));
     };
-    auto issue_A = [&](int slot) {
+    auto issue_tile = [&](int slot) {
         char* st = lds + slot * STAGE_B;
         const bool kval = k_cur < p.K;
 #pragma unroll
@@ -165,30 +164,14 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
             glds16(sel(src, ok), dst);                           // A_hi rows
             glds16(sel(src + a_ps, ok), dst + BM * 64);          // A_lo rows
         }
-    };
-    // AREG: the A pieces travel through registers instead (global_load_dwordx4 -> ds_write_b128 into the same lane-linear image)
-    uint4 ra[A_IT][2];
-    auto load_A = [&]() {
-        const bool kval = k_cur < p.K;
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const bool ok = kval && ((a_okmask >> it) & 1u);
-            const __bf16* src = a_base[it] + ((ci << il_sh) - il_sub);
-            ra[it][0] = *reinterpret_cast<const uint4*>(sel(src, ok));
-            ra[it][1] = *reinterpret_cast<const uint4*>(sel(src + a_ps, ok));
+        for (int it = 0; it < B_IT; ++it) {
+            const int piece = wave + it * NW, plane = piece / GB, grp = piece % GB;    // wave-uniform
+            char* dst = st + 2 * BM * 64 + plane * BN * 64 + grp * 1024;
+            const bool bok = BN <= 128 || wrow[it] != nullptr;
+            glds16(sel(wrow[it], bok), dst);
+            if (bok) wrow[it] += w_adv;
         }
-    };
-    auto store_A = [&](int slot) {
-        char* st = lds + slot * STAGE_B + lane * 16;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            // (built component-wise: a whole-struct copy through this pointer keeps ra[] in scratch memory)
-            const uint4 h = ra[it][0], l = ra[it][1];
-            *reinterpret_cast<uint4*>(st + (wave + it * NW) * 1024) = make_uint4(h.x, h.y, h.z, h.w);
-            *reinterpret_cast<uint4*>(st + (wave + it * NW) * 1024 + BM * 64) = make_uint4(l.x, l.y, l.z, l.w);
-        }
-    };
-    auto advance_A = [&]() {
         k_cur += BK;
         ci += BK;
         if (ci >= seg_end) {
@@ -198,22 +181,6 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
             }
             retap();
         }
-    };
-    auto issue_B = [&](int slot) {
-        char* st = lds + slot * STAGE_B;
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int piece = wave + it * NW, plane = piece / GB, grp = piece % GB;    // wave-uniform
-            char* dst = st + 2 * BM * 64 + plane * BN * 64 + grp * 1024;
-            const bool bok = BN <= 128 || wrow[it] != nullptr;
-            glds16(sel(wrow[it], bok), dst);
-            if (bok) wrow[it] += w_adv;
-        }
-    };
-    auto issue_tile = [&](int slot) {
-        issue_A(slot);
-        issue_B(slot);
-        advance_A();
     };
 
     f32x16 acc[TM][TN];
@@ -228,19 +195,10 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
 
     // ---- prologue: tiles 0 .. NS-2 in flight, tile 0 landed
     constexpr int AHEAD = NS - 1;
-    if constexpr (!AREG) {
 #pragma unroll
-        for (int t = 0; t < AHEAD; ++t)
-            if (t < p.nk) issue_tile(t);
-        if (p.nk >= AHEAD) wait_vmcnt<DPT * (AHEAD - 1)>(); else wait_vmcnt<0>();
-    } else {
-        load_A(); advance_A();                 // tile 0
-        issue_B(0);
-        store_A(0);                            // (the compiler waits for the loads it stores)
-        if (p.nk > 1) { load_A(); advance_A(); }   // tile 1 stays in flight across the barrier
-        if (p.nk > 1) wait_vmcnt<2 * A_IT>(); else wait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
+    for (int t = 0; t < AHEAD; ++t)
+        if (t < p.nk) issue_tile(t);
+    if (p.nk >= AHEAD) wait_vmcnt<DPT * (AHEAD - 1)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     int slot = 0, slot_in = AHEAD % NS;
 
@@ -283,36 +241,13 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
         }
     };
 
-    if constexpr (AREG) {
-        // Register-staged A: LDS-DMA moves ~1 KB per 40-60 cycles per CU (measured: the DMA stream alone takes 58 % of the
-        // kernel), the vector-load path 1 KB per 16.  Only the weight tile uses the DMA engine here; the activation pieces are
-        // loaded one tile further ahead into 8 VGPRs per piece pair and written with ds_write_b128 (lane-linear: conflict free).
+    if constexpr (!PP) {
         for (int kt = 0; kt < p.nk; ++kt) {
-            if (kt + 1 < p.nk) {
-                store_A(slot_in);              // tile kt+1 (loaded during step kt-1)
-                issue_B(slot_in);
-                if (kt + 2 < p.nk) { load_A(); advance_A(); }
-            }
+            if (kt + AHEAD < p.nk) issue_tile(slot_in);
             bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
             read_frags(ah, al, bh, bl);
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(ah, al, bh, bl);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 2 < p.nk) wait_vmcnt<2 * A_IT>(); else wait_vmcnt<0>();      // the DMAs are older than the A loads
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            slot ^= 1;
-            slot_in ^= 1;
-        }
-    } else if constexpr (!PP) {
-        const int dbg = p.pipe;      // FGT_CONV_PIPE = 2 / 3 / 4: diagnostic modes (wrong results): no DMA / no MFMA / DMA only
-        for (int kt = 0; kt < p.nk; ++kt) {
-            if (kt + AHEAD < p.nk && dbg != 2) issue_tile(slot_in);
-            bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
-            if (dbg != 4) read_frags(ah, al, bh, bl);
             __builtin_amdgcn_sched_barrier(0);   // keep all fragment reads of the step ahead of its MFMAs
-            if (dbg < 3) mfmas(ah, al, bh, bl);
-            else if (dbg == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); acc[0][0][0] += (float)ah[0][0][0] + (float)bl[1][TN - 1][0]; }
+            mfmas(ah, al, bh, bl);
             // The wait + barrier stay BEHIND the MFMAs (hoisted above them, the DMA latency would be exposed in front of this
             // wavefront's matrix work instead of running underneath it).  Tile kt+1 must have landed; while NS-2 younger tiles
             // exist they stay in flight (the last NS-2 steps drain everything: a constant immediate needs a constant count).
@@ -356,14 +291,14 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
 }
 
-template <int BM, int BN, int WM, int WN, int MINW, int NS, bool PP, bool AREG>
-int launch_k(const ConvP& p, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2, bool PP = false>
+int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr size_t smem = (size_t)NS * (BM + BN) * LDB * sizeof(float);
     static_assert(smem <= 160 * 1024, "LDS ring does not fit");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, AREG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
             fgt_set_error("hipFuncSetAttribute(conv_split %dx%d): %s", BM, BN, hipGetErrorString(e));
@@ -376,16 +311,8 @@ int launch_k(const ConvP& p, hipStream_t s) {
     q.ntiles = cdiv(p.Cout_g, BN);
     q.mchunk = cdiv(q.mtiles, 8);
     dim3 grid(q.xcd_swizzle ? 8 * q.mchunk * q.ntiles : q.mtiles * q.ntiles, p.d.groups);
-    hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, AREG>), grid, dim3(NT), smem, s, q);
+    hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP>), grid, dim3(NT), smem, s, q);
     return fgt_check_launch("conv_split");
-}
-
-template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2, bool PP = false>
-int launch(const ConvP& p, hipStream_t s) {
-    // FGT_CONV_PIPE = 5 (double-buffered tiles only): activations through registers, weights by LDS-DMA
-    if constexpr (NS == 2 && !PP)
-        if (p.pipe == 5) return launch_k<BM, BN, WM, WN, MINW, NS, PP, true>(p, s);
-    return launch_k<BM, BN, WM, WN, MINW, NS, PP, false>(p, s);
 }
 
 }  // namespace
