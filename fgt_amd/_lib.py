@@ -59,10 +59,12 @@ SIGNATURES = {
     "fgt_instnorm_apply": [_P, _I, _I, _I, _I, _P, _F, _I, _P, _I, _I, _P, _I, _P],
     "fgt_axpby": [_P, _I, _F, _P, _I, _F, _L, _I, _I, _F, _P, _I, _P],
     "fgt_compose_blend": [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P],
+    "fgt_laplace_fill_workspace": [_I, _I, _I],
+    "fgt_laplace_fill": [_P, _P, _I, _I, _I, _I, _P, _P, _I, _F, _P],
     "fgt_prof_enable": [_I],
     "fgt_prof_collect": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)],
 }
-_RESTYPES = {"fgt_last_error": C.c_char_p, "fgt_prof_enable": None}
+_RESTYPES = {"fgt_last_error": C.c_char_p, "fgt_prof_enable": None, "fgt_laplace_fill_workspace": C.c_long}
 
 _lib = None
 

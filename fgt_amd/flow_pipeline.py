@@ -1,4 +1,5 @@
-"""Clip-level RAFT driver (tool/video_inpainting.py:233-288, `calculate_flow`) restructured for the MI355X — SURVEY §8f rank 2.
+"""Clip-level flow stage restructured for the MI355X — SURVEY §8f ranks 2 and 4: the RAFT driver
+(tool/video_inpainting.py:233-288, `calculate_flow`), the diffusion fill (:42-51) and the LAFC loop (:341-386, `complete_flow`).
 
 The reference calls RAFT once per adjacent pair and direction: 2(N-1) calls of batch 1, every frame is pushed through the
 feature encoder up to 4 times and through the context encoder twice, and at 432x240 a pair is only 1620 query pixels
@@ -8,6 +9,8 @@ feature encoder up to 4 times and through the context encoder twice, and at 432x
 Outputs are the reference's per-pair `flow_up` fields in its order.
 """
 import torch
+
+from . import ops
 
 
 def compute_flows(raft, frames, iters=20, batch=8, enc_batch=16):
@@ -46,10 +49,22 @@ def indices_gen(pivot, interval, frames, t):
     return out
 
 
-def complete_flows(lafc, flows, masks, diffused, num_flows=3, interval=3, batch=8):
-    """The LAFC loop of tool/video_inpainting.py:367-384 with `batch` pivots per LAFC call.
+def diffusion(flows, masks, iters=1000, tol=1e-6):
+    """`diffusion()` of tool/video_inpainting.py:42-51 (rf.regionfill per flow and channel, tool/utils/region_fill.py:7-63) for the
+    whole clip in one call: flows [1,2,t,H,W], masks [1,1,t,H,W] (non-zero = hole) -> diffused flows [1,2,t,H,W].
+    All 2t maps are solved together on the GPU (ops.laplace_fill); map (c, i) uses mask i."""
+    _, c, t, H, W = flows.shape
+    out = ops.laplace_fill(flows[0].reshape(c * t, H, W).float(), masks[0, 0], iters=iters, tol=tol)
+    return out.view(1, c, t, H, W)
+
+
+def complete_flows(lafc, flows, masks, diffused=None, num_flows=3, interval=3, batch=8):
+    """`complete_flow` of tool/video_inpainting.py:341-386: diffusion fill (when `diffused` is not given) + the LAFC loop of
+    :367-384 with `batch` pivots per LAFC call.
     flows, diffused [1,2,t,H,W]; masks [1,1,t,H,W] (already sliced for the direction, :350-353).  Returns [t,2,H,W]:
     completed flow inside the mask, the known flow outside (`output * pivot_mask + pivot_flow * (1 - pivot_mask)`)."""
+    if diffused is None:
+        diffused = diffusion(flows, masks)
     t = diffused.shape[2]
     pivot = num_flows // 2
     idx = torch.tensor([indices_gen(i, interval, num_flows, t) for i in range(t)], device=flows.device)    # [t, num_flows]

@@ -520,6 +520,21 @@ def compose_blend(out_nchw, ids, first, frames01, masks, comp):
 _prof_on = False
 
 
+def laplace_fill(maps, masks, iters=1000, tol=1e-6):
+    """fgt_laplace_fill: maps [B, H, W] fp32, masks [n_masks, H, W] (non-zero = hole; map b uses mask b % n_masks) -> filled [B, H, W].
+    tool/utils/region_fill.py:7-63 for every map at once (conjugate gradients, fixed `iters`, per-map freeze at tol * |r0|)."""
+    _require_dev(maps)
+    assert maps.dim() == 3 and masks.dim() == 3 and masks.shape[1:] == maps.shape[1:] and masks.is_cuda
+    maps = maps.contiguous()
+    m8 = (masks != 0).to(torch.uint8).contiguous()
+    B, H, W = maps.shape
+    out = torch.empty_like(maps)
+    ws = torch.empty(_lib.lib().fgt_laplace_fill_workspace(B, H, W), dtype=torch.uint8, device=maps.device)
+    check(_lib.lib().fgt_laplace_fill(_ptr(maps), _ptr(m8), B, m8.shape[0], H, W, _ptr(out), _ptr(ws), int(iters), float(tol), _stream()),
+          "fgt_laplace_fill")
+    return out
+
+
 def prof_enable(on):
     global _prof_on
     _prof_on = bool(on)

@@ -239,6 +239,17 @@ int fgt_axpby(const float* a, int lda, float sa, const float* b, int ldb, float 
 int fgt_compose_blend(const float* out_nchw, const int* ids, const int* first, int n, const float* frames01,
                       const float* masks, int H, int W, float* comp, void* stream);
 
+/* Laplace ("diffusion") fill of the masked pixels of B scalar H x W maps (flow channels), all maps at once, by conjugate
+ * gradients on the masked 5-point stencil:  n(p) x(p) - sum_{masked 4-neighbours} x(q) = sum_{unmasked in-image 4-neighbours} I(q),
+ * n(p) = 4 / 3 / 2 in-image neighbours; unmasked pixels are copied.  Problem b uses mask b % n_masks (uint8, non-zero = hole).
+ * `iters` CG iterations are always enqueued (no read-back); a map whose residual norm falls below tol * |r0| stops changing.
+ * Results are bit-reproducible (ordered two-stage reductions, no atomics).  workspace: fgt_laplace_fill_workspace() bytes, 8-byte
+ * aligned.  Replaces: rf.regionfill / diffusion(), tool/utils/region_fill.py:7-63, tool/video_inpainting.py:42-51 (scipy spsolve
+ * per map on the CPU). */
+long fgt_laplace_fill_workspace(int B, int H, int W);
+int fgt_laplace_fill(const float* I, const unsigned char* mask, int B, int n_masks, int H, int W, float* out, void* workspace,
+                     int iters, float tol, void* stream);
+
 /* ---- per-kernel timing of fgt_conv2d launches with HIP events on the launch stream (bench roofline) ----
  * fgt_prof_enable(1) makes every fgt_conv2d launch record an event pair and accumulate its algorithmic
  * flops (2*M*Cout_g*K*groups); fgt_prof_collect synchronises the events and returns totals. */

@@ -88,6 +88,28 @@ def main():
     t = timed(lambda: f(mf, fw, mk), 3)
     out.append({"case": "FGT window 864x480, t=26 (config #5 unit)", "ms": round(t * 1e3, 2), "frames_per_s_this_window": round(26 / t, 1),
                 "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "precision": a.precision})
+    # ---- diffusion fill of a clip's flows (tool/video_inpainting.py:42-51): 79 flows x 2 channels at 432x240, object-like holes
+    import numpy as np
+    from fgt_amd import flow_pipeline as FP
+    tt, H, W = 79, 240, 432
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    mk = torch.stack([(((yy - 120 - 0.3 * i) / 70.0) ** 2 + ((xx - 150 - 1.5 * i) / 80.0) ** 2 <= 1.0).float() for i in range(tt)])[None, None]
+    fl2 = torch.cumsum(torch.randn(1, 2, tt, H, W, generator=g), -1) * 0.3
+    dfl2, dmk = fl2.to(dev), mk.to(dev)
+    for iters in (300, 1000):
+        t = timed(lambda: FP.diffusion(dfl2, dmk, iters=iters), 2)
+        rec = {"case": f"diffusion fill, {tt} flows x 2 channels at {W}x{H}, ~{int(mk[0, 0, 0].sum())} px holes, {iters} CG iterations",
+               "ms_per_direction": round(t * 1e3, 2), "ms_per_flow": round(t * 1e3 / tt, 3)}
+        if a.cpu:
+            from oracle import fill_oracle as FO
+            got = FP.diffusion(dfl2, dmk, iters=iters)[0].permute(1, 2, 3, 0).cpu().numpy()        # [t,H,W,2]
+            t0 = time.perf_counter()
+            ref = np.stack([FO.regionfill(fl2[0, c, i].numpy(), mk[0, 0, i].numpy()) for i in range(3) for c in range(2)])
+            rec["cpu_oracle_ms_per_flow"] = round((time.perf_counter() - t0) * 1e3 / 3, 1)
+            gg = np.stack([got[i, :, :, c] for i in range(3) for c in range(2)])
+            rec["max_abs_vs_oracle_first3"] = float(np.abs(gg - ref).max())
+            rec["value_range"] = float(np.abs(ref).max())
+        out.append(rec)
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(out, open("gpurun_out/flow_bench.json", "w"), indent=1)
     for o in out:
