@@ -51,6 +51,11 @@ if [ "${1:-}" != "quick" ]; then
   [ -n "$f" ] && cut -c1-160 "$f" | head -16
 fi
 if [ "${1:-}" != "quick" ]; then
+  echo "== attention kernels (algorithmic TFLOP/s; fp32 peak 157.3, bf16x3 issues 3x)"
+  for p in fp32 bf16x3; do python tools/attn_micro.py --precision $p --t 17 2>&1 | grep attention; python tools/attn_micro.py --precision $p --t 17 --spatial 2>&1 | grep attention; done | tee gpurun_out/attn_micro.log
+  echo "== bench exact fp32 WITH the feature cache and window batching"
+  timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --precision fp32 > gpurun_out/bench_fp32.log 2>&1
+  grep '^{' gpurun_out/bench_fp32.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'],'fps', d['ms_per_step'],'ms', d.get('roofline'))"
   echo "== 2-rank rehearsal of bench.py on this single GPU (gloo, collectives staged through the host): weak headline + strong extra"
   FGT_BENCH_SHARE_GPU=1 FGT_BENCH_BACKEND=gloo FGT_TUNING_FILE="$PWD/gpurun_out/tuning.json" timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
     --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --no-prof > gpurun_out/bench_2rank_rehearsal.log 2>&1
