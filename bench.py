@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--no-cache", action="store_true", help="recompute the per-frame encoders in every window like the reference")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = one clip per rank (headline default); strong = one clip sharded by frames/windows over the ranks")
+    ap.add_argument("--window-batch", type=int, default=8, help="equal-length windows per transformer+decoder forward (bit-identical results)")
     ap.add_argument("--graphs", action="store_true", help="replay each window's launch sequence as a hipGraph (the roofline block is "
                                                           "then measured on one extra eager step after the timed region)")
     args = ap.parse_args()
@@ -143,9 +144,9 @@ def main():
     weak = world > 1 and args.scaling == "weak"
     frames, flows, masks = synth_clip(args.frames, args.height, args.width, seed=1234 + (rank if weak else 0), device=dev)
     if weak:        # clip-level data parallelism: this rank's own clip, the whole schedule, no collective on the data path
-        runner = ClipRunner(model, frames, flows, masks, rank=0, world=1, cache_features=not args.no_cache, use_graphs=args.graphs)
+        runner = ClipRunner(model, frames, flows, masks, rank=0, world=1, cache_features=not args.no_cache, use_graphs=args.graphs, window_batch=args.window_batch)
     else:
-        runner = ClipRunner(model, frames, flows, masks, rank=rank, world=world, cache_features=not args.no_cache, use_graphs=args.graphs)
+        runner = ClipRunner(model, frames, flows, masks, rank=rank, world=world, cache_features=not args.no_cache, use_graphs=args.graphs, window_batch=args.window_batch)
 
     def barrier():
         torch.cuda.synchronize()
@@ -202,7 +203,8 @@ def main():
                                    f"reference window schedule (neighbor_stride 5, step 10; sum t = {sum(len(a) + len(b) for a, b in runner.sched)})",
                        "windows": len(runner.sched), "sharding": (f"one clip per rank x {world} ranks, no data-path collective" if weak else
                                     f"windows round-robin over {world} rank(s)"),
-                       "conv_precision": prec, "per_frame_feature_cache": bool(runner.cache_features), "hip_graphs": bool(args.graphs)},
+                       "conv_precision": prec, "per_frame_feature_cache": bool(runner.cache_features), "hip_graphs": bool(args.graphs),
+                       "window_batch": runner.window_batch},
         }
         out["host_enqueue_ms_per_step"] = round(1e3 * host_dt / args.steps, 3)
         if clip_flops:
@@ -241,7 +243,7 @@ def main():
         dog.start()
         try:
             f2, fl2, m2 = synth_clip(args.frames, args.height, args.width, seed=1234, device=dev)
-            r2 = ClipRunner(model, f2, fl2, m2, rank=rank, world=world, cache_features=not args.no_cache, use_graphs=args.graphs)
+            r2 = ClipRunner(model, f2, fl2, m2, rank=rank, world=world, cache_features=not args.no_cache, use_graphs=args.graphs, window_batch=args.window_batch)
             r2.run()
             for _ in range(args.warmup):
                 r2.run()

@@ -67,7 +67,7 @@ def compose_torch(out, nb, frames01, masks, comp, visited):
 
 class ClipRunner:
     def __init__(self, model, frames01, flows_normed, masks, neighbor_stride=5, ref_length=10, num_ref=-1,
-                 rank=0, world=1, forward=None, group=None, cache_features=None, encode_chunk=20, use_graphs=None, window_batch=4):
+                 rank=0, world=1, forward=None, group=None, cache_features=None, encode_chunk=20, use_graphs=None, window_batch=8):
         self.model = model
         self.frames01, self.flows, self.masks = frames01, flows_normed, masks
         self.n = frames01.shape[1]
@@ -102,7 +102,7 @@ class ClipRunner:
         # Window batching (feature-cache path): windows of equal length t are independent batch elements of the reference model
         # (b > 1: every stage is per frame or per (b, zone)), so up to `window_batch` of this rank's windows go through the
         # transformer + decoder as ONE forward.  Per-row results do not depend on how many rows a GEMM launch carries, so the
-        # outputs are bit-identical to running the windows one by one; the launches are 3-4x larger (M = 12240 rows per
+        # outputs are bit-identical to running the windows one by one; the launches are up to 8x larger (M = 12240 rows per
         # window leaves 0.75- and 2.25-round tile grids on 256 CUs) and 3-4x fewer.
         self.window_batch = max(1, int(window_batch))
         by_t = {}
