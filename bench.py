@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = one clip per rank (headline default); strong = one clip sharded by frames/windows over the ranks")
     ap.add_argument("--window-batch", type=int, default=8, help="equal-length windows per transformer+decoder forward (bit-identical results)")
+    ap.add_argument("--encode-chunk", type=int, default=20, help="frames per call of the per-frame stages (conv encoders + soft split)")
     ap.add_argument("--graphs", action="store_true", help="replay each window's launch sequence as a hipGraph (the roofline block is "
                                                           "then measured on one extra eager step after the timed region)")
     args = ap.parse_args()
@@ -144,9 +145,9 @@ def main():
     weak = world > 1 and args.scaling == "weak"
     frames, flows, masks = synth_clip(args.frames, args.height, args.width, seed=1234 + (rank if weak else 0), device=dev)
     if weak:        # clip-level data parallelism: this rank's own clip, the whole schedule, no collective on the data path
-        runner = ClipRunner(model, frames, flows, masks, rank=0, world=1, cache_features=not args.no_cache, use_graphs=args.graphs, window_batch=args.window_batch)
+        runner = ClipRunner(model, frames, flows, masks, rank=0, world=1, cache_features=not args.no_cache, use_graphs=args.graphs, window_batch=args.window_batch, encode_chunk=args.encode_chunk)
     else:
-        runner = ClipRunner(model, frames, flows, masks, rank=rank, world=world, cache_features=not args.no_cache, use_graphs=args.graphs, window_batch=args.window_batch)
+        runner = ClipRunner(model, frames, flows, masks, rank=rank, world=world, cache_features=not args.no_cache, use_graphs=args.graphs, window_batch=args.window_batch, encode_chunk=args.encode_chunk)
 
     def barrier():
         torch.cuda.synchronize()
@@ -243,7 +244,7 @@ def main():
         dog.start()
         try:
             f2, fl2, m2 = synth_clip(args.frames, args.height, args.width, seed=1234, device=dev)
-            r2 = ClipRunner(model, f2, fl2, m2, rank=rank, world=world, cache_features=not args.no_cache, use_graphs=args.graphs, window_batch=args.window_batch)
+            r2 = ClipRunner(model, f2, fl2, m2, rank=rank, world=world, cache_features=not args.no_cache, use_graphs=args.graphs, window_batch=args.window_batch, encode_chunk=args.encode_chunk)
             r2.run()
             for _ in range(args.warmup):
                 r2.run()

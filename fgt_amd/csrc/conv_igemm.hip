@@ -1,4 +1,5 @@
-// Implicit-GEMM convolution / GEMM for gfx950 on the fp32 matrix cores.
+// Implicit-GEMM convolution / GEMM for gfx950 on the matrix cores, register-staged loader (fp32 activations in HBM).
+// (conv_split.hip is the sibling for activations that arrive pre-split into hi/lo bf16: LDS-DMA loader, same arithmetic.)
 //
 //   M = N*Ho*Wo output pixels, N = Cout per group, K = kh*kw*Cin_per_group (k = (ky*kw+kx)*Cg + ci).
 //
@@ -16,7 +17,8 @@
 //   1  bf16x3    every fp32 operand is split on the way into LDS into hi = bf16(x) and lo = bf16(x - hi) (RNE, one
 //                v_cvt_pk_bf16_f32 per pair) and each product is issued as three v_mfma_f32_32x32x16_bf16
 //                (lo*hi + hi*lo + hi*hi, fp32 accumulate): ~2^-16 relative error per product at 16/3 = 5.3x the
-//                fp32-MFMA rate.  LDS tiles are [rows][40] bf16 (80-byte rows: conflict-free ds_read_b128 operands).
+//                fp32-MFMA rate.  LDS tiles are [rows][32] bf16 with XOR-swizzled 16-byte slots (conv_tile.h); the weights arrive
+//                pre-split (planes, or interleaved per K-step: fgt_conv_desc.w_il).
 #include <stdlib.h>
 #include <vector>
 #include "common.h"
