@@ -28,7 +28,8 @@ class ConvDesc(C.Structure):
 
 class AttnDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("mode", "b", "t", "h", "w", "nh", "nw", "heads", "group", "ws", "n_global",
-                                       "ldq", "qoff", "ldk", "koff", "ldv", "voff", "ldg_k", "ldg_v", "ldo", "precision")]
+                                       "ldq", "qoff", "ldk", "koff", "ldv", "voff", "ldg_k", "ldg_v", "ldo", "precision", "out_split")] + \
+               [("pso", C.c_longlong)]
 
 
 _P = C.c_void_p
@@ -42,11 +43,11 @@ SIGNATURES = {
     "fgt_abi_version": [],
     "fgt_conv2d": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "fgt_split": [_P, _L, _I, _I, _P, _I, C.c_longlong, _I, _P],
-    "fgt_layernorm": [_P, _I, _I, _P, _I, _I, _L, _F, _P, _P, _P, _I, _P, _P, _P, _I, _P],
+    "fgt_layernorm": [_P, _I, _I, _P, _I, _I, _L, _F, _P, _P, _P, _I, _P, _P, _P, _I, C.c_longlong, C.c_longlong, _P],
     "fgt_attention": [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P],
     "fgt_dw_pool": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "fgt_dw3x3_residual": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
-    "fgt_fold": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P],
+    "fgt_fold": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, C.c_longlong, _P],
     "fgt_nchw_to_nhwc": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _F, _P],
     "fgt_nhwc_to_nchw": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
     "fgt_pad_tokens": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],

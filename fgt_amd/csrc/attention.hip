@@ -190,14 +190,22 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_kernel(const AttnP p) {
             orow = ((long)fr * d.h + y) * d.w + x;
         }
         if (keep) {
-            float* op = p.O + orow * d.ldo + choff + 4 * lh;
+            const long ob = orow * d.ldo + choff + 4 * lh;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4) {
                     const float4 v = make_float4(o[t][4 * e4 + 0] * inv, o[t][4 * e4 + 1] * inv,
                                                  o[t][4 * e4 + 2] * inv, o[t][4 * e4 + 3] * inv);
-                    *reinterpret_cast<float4*>(op + t * 32 + 8 * e4) = v;
+                    if (d.out_split) {       // O is the hi plane of a split tensor (bf16 elements), lo plane pso further
+                        uint2 hi, lo;
+                        fgt_split4(v, hi, lo);
+                        __bf16* o16 = reinterpret_cast<__bf16*>(p.O) + ob + t * 32 + 8 * e4;
+                        *reinterpret_cast<uint2*>(o16) = hi;
+                        *reinterpret_cast<uint2*>(o16 + d.pso) = lo;
+                    } else {
+                        *reinterpret_cast<float4*>(p.O + ob + t * 32 + 8 * e4) = v;
+                    }
                 }
         }
     }
@@ -424,14 +432,22 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_bf16x3_kernel(const AttnP p) 
             orow = ((long)fr * d.h + y) * d.w + x;
         }
         if (keep) {
-            float* op = p.O + orow * d.ldo + choff + 4 * lh;
+            const long ob = orow * d.ldo + choff + 4 * lh;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4) {
                     const float4 v = make_float4(o[t][4 * e4 + 0] * inv, o[t][4 * e4 + 1] * inv,
                                                  o[t][4 * e4 + 2] * inv, o[t][4 * e4 + 3] * inv);
-                    *reinterpret_cast<float4*>(op + t * 32 + 8 * e4) = v;
+                    if (d.out_split) {       // O is the hi plane of a split tensor (bf16 elements), lo plane pso further
+                        uint2 hi, lo;
+                        fgt_split4(v, hi, lo);
+                        __bf16* o16 = reinterpret_cast<__bf16*>(p.O) + ob + t * 32 + 8 * e4;
+                        *reinterpret_cast<uint2*>(o16) = hi;
+                        *reinterpret_cast<uint2*>(o16 + d.pso) = lo;
+                    } else {
+                        *reinterpret_cast<float4*>(p.O + ob + t * 32 + 8 * e4) = v;
+                    }
                 }
         }
     }
@@ -478,6 +494,7 @@ extern "C" int fgt_attention(const fgt_attn_desc* dd, const float* Q, const floa
     FGT_REQUIRE(problems <= 65535, "fgt_attention: too many problems (%d) for grid.y", problems);
     hipStream_t s = (hipStream_t)stream;
     FGT_REQUIRE(d.precision == 0 || d.precision == 1, "fgt_attention: unknown precision %d", d.precision);
+    FGT_REQUIRE(d.out_split == 0 || (d.out_split == 1 && d.pso > 0 && d.pso % 4 == 0), "fgt_attention: bad out_split / pso");
     if (p.n_q <= 64) {
         dim3 grid(cdiv(p.n_q, 64), problems);
         if (d.precision == 0) hipLaunchKernelGGL((attn_kernel<2>), grid, dim3(128), 0, s, p);

@@ -11,11 +11,25 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// fp32 store, or (ps > 0) the split format: `out` then points at the hi plane of a bf16 tensor, offsets / ps in bf16 elements
+__device__ __forceinline__ void store_f32_or_split(float* out, long off, long ps, const float4 v) {
+    if (ps > 0) {
+        uint2 hi, lo;
+        fgt_split4(v, hi, lo);
+        __bf16* o = reinterpret_cast<__bf16*>(out) + off;
+        *reinterpret_cast<uint2*>(o) = hi;
+        *reinterpret_cast<uint2*>(o + ps) = lo;
+    } else {
+        *reinterpret_cast<float4*>(out + off) = v;
+    }
+}
+
 // ------------------------------------------------------------------ LayerNorm: one wavefront per row
 constexpr int LN_MAXV = 4;  // float4 per lane -> C <= 1024
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1,
                                                         long rows, float eps, const float* gA, const float* bA, float* outA,
-                                                        int ldA, const float* gB, const float* bB, float* outB, int ldB) {
+                                                        int ldA, const float* gB, const float* bB, float* outB, int ldB,
+                                                        long psA, long psB) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -50,12 +64,10 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* x0, int C0,
             const float4 n = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd,
                                          (v[i].w - mean) * rstd);
             const float4 g = *reinterpret_cast<const float4*>(gA + c), b = *reinterpret_cast<const float4*>(bA + c);
-            *reinterpret_cast<float4*>(outA + row * ldA + c) =
-                make_float4(n.x * g.x + b.x, n.y * g.y + b.y, n.z * g.z + b.z, n.w * g.w + b.w);
+            store_f32_or_split(outA, row * ldA + c, psA, make_float4(n.x * g.x + b.x, n.y * g.y + b.y, n.z * g.z + b.z, n.w * g.w + b.w));
             if (outB) {
                 const float4 g2 = *reinterpret_cast<const float4*>(gB + c), b2 = *reinterpret_cast<const float4*>(bB + c);
-                *reinterpret_cast<float4*>(outB + row * ldB + c) =
-                    make_float4(n.x * g2.x + b2.x, n.y * g2.y + b2.y, n.z * g2.z + b2.z, n.w * g2.w + b2.w);
+                store_f32_or_split(outB, row * ldB + c, psB, make_float4(n.x * g2.x + b2.x, n.y * g2.y + b2.y, n.z * g2.z + b2.z, n.w * g2.w + b2.w));
             }
         }
     }
@@ -124,7 +136,7 @@ __global__ void __launch_bounds__(256) dw3x3_res_kernel(const float* x, int bt, 
 // ------------------------------------------------------------------ fold as a gather
 __global__ void __launch_bounds__(256) fold_kernel(const float* Y, int ldy, int frames, int th, int tw, int C, int k, int s,
                                                    int p, int Hf, int Wf, int normalize, const float* res, int ldres,
-                                                   float* out, int ldo) {
+                                                   float* out, int ldo, int relu, long ps_out) {
     const int c4n = C >> 2;
     const long total = (long)frames * Hf * Wf * c4n;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -154,7 +166,8 @@ __global__ void __launch_bounds__(256) fold_kernel(const float* Y, int ldy, int 
             const float4 rv = *reinterpret_cast<const float4*>(res + pix * ldres + c);
             acc[0] = rv.x + acc[0]; acc[1] = rv.y + acc[1]; acc[2] = rv.z + acc[2]; acc[3] = rv.w + acc[3];
         }
-        *reinterpret_cast<float4*>(out + pix * ldo + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (relu) { acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f); }
+        store_f32_or_split(out, pix * ldo + c, ps_out, make_float4(acc[0], acc[1], acc[2], acc[3]));
     }
 }
 
@@ -252,13 +265,14 @@ __global__ void split_kernel(const float* __restrict__ x, long rows, int C4, int
 
 extern "C" int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, long rows, float eps,
                              const float* gA, const float* bA, float* outA, int ldA, const float* gB, const float* bB,
-                             float* outB, int ldB, void* stream) {
+                             float* outB, int ldB, long long psA, long long psB, void* stream) {
     FGT_REQUIRE(x0 && gA && bA && outA && rows > 0, "fgt_layernorm: null pointer / empty");
     FGT_REQUIRE(C0 > 0 && C0 % 4 == 0 && C1 % 4 == 0 && (C0 + C1) <= 256 * LN_MAXV, "fgt_layernorm: C=(%d,%d) unsupported", C0, C1);
     FGT_REQUIRE(ld0 % 4 == 0 && (C1 == 0 || (x1 && ld1 % 4 == 0)) && ldA % 4 == 0 && (!outB || (gB && bB && ldB % 4 == 0)),
                 "fgt_layernorm: strides must be multiples of 4 floats");
+    FGT_REQUIRE(psA >= 0 && psB >= 0 && psA % 4 == 0 && psB % 4 == 0, "fgt_layernorm: plane strides must be non-negative multiples of 4");
     hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, rows,
-                       eps, gA, bA, outA, ldA, gB, bB, outB, ldB);
+                       eps, gA, bA, outA, ldA, gB, bB, outB, ldB, (long)psA, (long)psB);
     return fgt_check_launch("layernorm");
 }
 
@@ -282,12 +296,13 @@ extern "C" int fgt_dw3x3_residual(const float* x, int bt, int h, int w, int C, c
 }
 
 extern "C" int fgt_fold(const float* Y, int ldy, int frames, int th, int tw, int C, int k, int s, int p, int Hf, int Wf,
-                        int normalize, const float* res, int ldres, float* out, int ldo, void* stream) {
+                        int normalize, const float* res, int ldres, float* out, int ldo, int relu, long long ps_out, void* stream) {
     FGT_REQUIRE(Y && out && C % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && (!res || ldres % 4 == 0), "fgt_fold: bad arguments");
     FGT_REQUIRE((Hf + 2 * p - k) / s + 1 == th && (Wf + 2 * p - k) / s + 1 == tw, "fgt_fold: token grid %dx%d does not match output %dx%d", th, tw, Hf, Wf);
     const long total = (long)frames * Hf * Wf * (C / 4);
+    FGT_REQUIRE(ps_out >= 0 && ps_out % 4 == 0, "fgt_fold: plane stride must be a non-negative multiple of 4");
     hipLaunchKernelGGL(fold_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, Y, ldy, frames, th, tw, C, k, s, p,
-                       Hf, Wf, normalize, res, ldres, out, ldo);
+                       Hf, Wf, normalize, res, ldres, out, ldo, relu, (long)ps_out);
     return fgt_check_launch("fold");
 }
 

@@ -296,12 +296,15 @@ class FGT(nn.Module):
 
     # ---- transformer pieces --------------------------------------------------------------------
     def _ffn(self, y, x_res, P, bt, th, tw, Hf, Wf):
-        """x_res + FusionFeedForward(y)  (ffn_base.py:53-77)."""
+        """x_res + FusionFeedForward(y)  (ffn_base.py:53-77).  y may be a Split (bf16x3 mode)."""
         k, s, p = self.cfg["k"][0], self.cfg["s"][0], self.cfg["p"][0]
+        sc = self._split_chain()
         Y = ops.linear(y, P["conv1"])                                       # [bt*n, k*k*cc] tap-major
-        F = ops.fold(Y, bt, th, tw, P["cc"], k, s, p, Hf, Wf, normalize=True)  # fold(x) / fold(ones)
+        # fold(x) / fold(ones); in split mode the ReLU in front of the second Linear is applied here, once per value,
+        # and the map is handed over pre-split (otherwise it is applied on the gathered values inside the conv)
+        F = ops.fold(Y, bt, th, tw, P["cc"], k, s, p, Hf, Wf, normalize=True, relu=sc, out_split=sc)
         out = torch.empty_like(x_res)
-        ops.conv2d(F, P["conv2"], stride=s, pad=p, in_relu=True, epi="add", aux1=x_res, out=out.view(bt, th, tw, -1))
+        ops.conv2d(F, P["conv2"], stride=s, pad=p, in_relu=not sc, epi="add", aux1=x_res, out=out.view(bt, th, tw, -1))
         return out
 
     def _temporal(self, x, P, b, t, th, tw, Hf, Wf):
@@ -311,15 +314,17 @@ class FGT(nn.Module):
         zh, zw = math.ceil(th / G), math.ceil(tw / G)
         pad_r, pad_b = (zw - tw % zw) % zw, (zh - th % zh) % zh
         nh, nw = th + pad_b, tw + pad_r
-        s = ops.layernorm(x, *P["n1"])
-        if pad_r or pad_b:
+        padded = bool(pad_r or pad_b)
+        sc = self._split_chain()
+        s = ops.layernorm(x, *P["n1"], splitA=sc and not padded)            # GEMM operands travel pre-split in bf16x3 mode
+        if padded:
             s = ops.pad_tokens(s, bt, th, tw, nh, nw)
         qkv = ops.linear(s, P["qkv"])
-        a = ops.attention_temporal(qkv, b, t, nh, nw, cfg["heads"], G, c)
-        if pad_r or pad_b:
+        a = ops.attention_temporal(qkv, b, t, nh, nw, cfg["heads"], G, c, out_split=sc and not padded)
+        if padded:
             a = ops.pad_tokens(a, bt, nh, nw, th, tw)                      # crop (attention_base.py:71-72)
         x = ops.linear(a, P["out"], epi="add", aux1=x)
-        y = ops.layernorm(x, *P["n2"])
+        y = ops.layernorm(x, *P["n2"], splitA=sc)
         return self._ffn(y, x, P["ffn"], bt, th, tw, Hf, Wf)
 
     def _spatial(self, x, f, P, bt, th, tw, Hf, Wf):
@@ -337,13 +342,13 @@ class FGT(nn.Module):
         fw = ops.linear(xp, P["rw"], x1=fp, act="sigmoid", epi="mul", aux1=fp)          # f * sigmoid(Linear([x|f]))
         ng = (nh // gd) * (nw // gd)
         dev = x.device
-        kin = torch.empty(rows + bt * ng, c + cf, dtype=torch.float32, device=dev)
-        vin = torch.empty(rows + bt * ng, c, dtype=torch.float32, device=dev)
+        sc = self._split_chain()
+        new = (lambda r, ch: ops.Split.empty((r, ch), dev)) if sc else (lambda r, ch: torch.empty(r, ch, dtype=torch.float32, device=dev))
+        kin, vin, q_ln = new(rows + bt * ng, c + cf), new(rows + bt * ng, c), new(rows, c + cf)     # LN outputs = GEMM operands
         gk = torch.empty(bt * ng, c + cf, dtype=torch.float32, device=dev)
         gv = torch.empty(bt * ng, c, dtype=torch.float32, device=dev)
         ops.dw_pool(xp, fw, bt, nh, nw, gd, *P["gk"], out=gk)
         ops.dw_pool(xp, None, bt, nh, nw, gd, *P["gv"], out=gv)
-        q_ln = torch.empty(rows, c + cf, dtype=torch.float32, device=dev)
         ops.layernorm(xp, *P["qn"], x1=fw, gB=P["kn"][0], bB=P["kn"][1], outA=q_ln, outB=kin[:rows])
         ops.layernorm(gk, *P["kn"], outA=kin[rows:])
         ops.layernorm(xp, *P["vn"], outA=vin[:rows])
@@ -351,9 +356,9 @@ class FGT(nn.Module):
         q = ops.linear(q_ln, P["q"])
         kk = ops.linear(kin, P["k"])
         vv = ops.linear(vin, P["v"])
-        a = ops.attention_spatial(q, kk[:rows], vv[:rows], kk[rows:], vv[rows:], bt, th, tw, nh, nw, cfg["heads"], ws, ng)
+        a = ops.attention_spatial(q, kk[:rows], vv[:rows], kk[rows:], vv[rows:], bt, th, tw, nh, nw, cfg["heads"], ws, ng, out_split=sc)
         x = ops.linear(a, P["out"], epi="add", aux1=x)
-        y = ops.layernorm(x, *P["n"])
+        y = ops.layernorm(x, *P["n"], splitA=sc)
         return self._ffn(y, x, P["ffn"], bt, th, tw, Hf, Wf)
 
     # ---- per-frame stages (exposed separately so the clip scheduler can cache them) -------------

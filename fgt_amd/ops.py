@@ -323,52 +323,67 @@ def linear(x, pc, **kw):
     return {None: out, False: out, "only": out_s, "both": (out, out_s)}[osp]
 
 
-def layernorm(x0, gA, bA, x1=None, gB=None, bB=None, outA=None, outB=None, eps=1e-5):
-    """Row LayerNorm over [x0 | x1]; optional second affine output sharing the statistics."""
-    _require_dev(x0, x1, gA, bA, gB, bB, outA, outB)
+def _out_desc(t):
+    """(pointer-holding tensor, row stride, plane stride) of an fp32 tensor (ps = 0) or a planes-layout Split."""
+    if isinstance(t, Split):
+        assert not t.il, "fused split outputs use the planes layout"
+        return t.hi, t.hi.stride(0), t.ps
+    return t, (0 if t is None else t.stride(0)), 0
+
+
+def layernorm(x0, gA, bA, x1=None, gB=None, bB=None, outA=None, outB=None, eps=1e-5, splitA=False, splitB=False):
+    """Row LayerNorm over [x0 | x1]; optional second affine output sharing the statistics.  splitA / splitB (or passing a
+    Split as outA / outB) writes that output pre-split for the GEMM that consumes it."""
+    _require_dev(x0, x1, gA, bA, gB, bB)
     rows, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[1]
     if outA is None:
-        outA = torch.empty(rows, C0 + C1, dtype=torch.float32, device=x0.device)
+        outA = Split.empty((rows, C0 + C1), x0.device) if splitA else torch.empty(rows, C0 + C1, dtype=torch.float32, device=x0.device)
     if gB is not None and outB is None:
-        outB = torch.empty(rows, C0 + C1, dtype=torch.float32, device=x0.device)
+        outB = Split.empty((rows, C0 + C1), x0.device) if splitB else torch.empty(rows, C0 + C1, dtype=torch.float32, device=x0.device)
+    (tA, ldA, psA), (tB, ldB, psB) = _out_desc(outA), _out_desc(outB)
     check(_lib.lib().fgt_layernorm(_ptr(x0), C0, x0.stride(0), _ptr(x1), C1, 0 if x1 is None else x1.stride(0), rows, eps,
-                                   _ptr(gA), _ptr(bA), _ptr(outA), outA.stride(0), _ptr(gB), _ptr(bB), _ptr(outB),
-                                   0 if outB is None else outB.stride(0), _stream()), "fgt_layernorm")
+                                   _ptr(gA), _ptr(bA), _ptr(tA), ldA, _ptr(gB), _ptr(bB), _ptr(tB), ldB, psA, psB, _stream()),
+          "fgt_layernorm")
     return (outA, outB) if gB is not None else outA
 
 
-def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None):
+def _attn_out(rows, c, device, out_split, d):
+    out = Split.empty((rows, c), device) if out_split else torch.empty(rows, c, dtype=torch.float32, device=device)
+    t, ld, ps = _out_desc(out)
+    d.ldo, d.out_split, d.pso = ld, int(bool(out_split)), ps
+    return out, t
+
+
+def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None, out_split=False):
     """Temporal zone attention reading q/k/v in place from a fused [b*t*nh*nw, 3c] projection buffer."""
     _require_dev(qkv)
-    out = torch.empty(b * t * nh * nw, c, dtype=torch.float32, device=qkv.device)
     d = AttnDesc()
     d.mode, d.b, d.t, d.h, d.w, d.nh, d.nw, d.heads, d.group = 0, b, t, nh, nw, nh, nw, heads, group
     d.ws, d.n_global = 0, 0
     d.ldq = d.ldk = d.ldv = qkv.stride(0)
     d.qoff, d.koff, d.voff = 0, c, 2 * c
     d.ldg_k = d.ldg_v = 0
-    d.ldo = c
+    out, optr = _attn_out(b * t * nh * nw, c, qkv.device, out_split, d)
     d.precision = PREC[precision if precision is not None else DEFAULT_ATTN_PRECISION]
-    check(_lib.lib().fgt_attention(C.byref(d), _ptr(qkv), _ptr(qkv), _ptr(qkv), None, None, _ptr(out), _stream()),
+    check(_lib.lib().fgt_attention(C.byref(d), _ptr(qkv), _ptr(qkv), _ptr(qkv), None, None, _ptr(optr), _stream()),
           "fgt_attention(temporal)")
     return out
 
 
-def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, precision=None):
+def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, precision=None, out_split=False):
     """Window attention + shared global tokens; q/k/v are [bt*nh*nw, c] maps on the padded grid, output cropped."""
     _require_dev(q, k, v, kg, vg)
     c = q.shape[1]
-    out = torch.empty(bt * h * w, c, dtype=torch.float32, device=q.device)
     d = AttnDesc()
     d.mode, d.b, d.t, d.h, d.w, d.nh, d.nw, d.heads, d.group = 1, 1, bt, h, w, nh, nw, heads, 0
     d.ws, d.n_global = ws, n_global
     d.ldq, d.ldk, d.ldv = q.stride(0), k.stride(0), v.stride(0)
     d.qoff = d.koff = d.voff = 0
     d.ldg_k, d.ldg_v = kg.stride(0), vg.stride(0)
-    d.ldo = c
+    out, optr = _attn_out(bt * h * w, c, q.device, out_split, d)
     d.precision = PREC[precision if precision is not None else DEFAULT_ATTN_PRECISION]
-    check(_lib.lib().fgt_attention(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(kg), _ptr(vg), _ptr(out), _stream()),
+    check(_lib.lib().fgt_attention(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(kg), _ptr(vg), _ptr(optr), _stream()),
           "fgt_attention(spatial)")
     return out
 
@@ -391,14 +406,20 @@ def dw3x3_residual(x, bt, h, w, wgt, bias):
     return out
 
 
-def fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize, res=None, out=None):
-    """Overlap-add of [frames*th*tw, k*k*Cc] (tap-major columns) to [frames, Hf, Wf, Cc]."""
-    _require_dev(Y, res, out)
+def fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize, res=None, out=None, relu=False, out_split=False):
+    """Overlap-add of [frames*th*tw, k*k*Cc] (tap-major columns) to [frames, Hf, Wf, Cc]; relu: max(., 0) last;
+    out_split: write the result pre-split (the FFN's second Linear consumes it as a conv over this map)."""
+    _require_dev(Y, res)
     if out is None:
-        out = torch.empty(frames, Hf, Wf, Cc, dtype=torch.float32, device=Y.device)
+        out = Split.empty((frames, Hf, Wf, Cc), Y.device) if out_split else torch.empty(frames, Hf, Wf, Cc, dtype=torch.float32, device=Y.device)
     ldres = 0 if res is None else _as_map(res)[5]
+    if isinstance(out, Split):
+        optr, ldo, ps = out.hi, _as_map(out.hi)[5], out.ps
+    else:
+        _require_dev(out)
+        optr, ldo, ps = out, _as_map(out)[5], 0
     check(_lib.lib().fgt_fold(_ptr(Y), Y.stride(0), frames, th, tw, Cc, k, s, p, Hf, Wf, int(normalize), _ptr(res), ldres,
-                              _ptr(out), _as_map(out)[5], _stream()), "fgt_fold")
+                              _ptr(optr), ldo, int(relu), ps, _stream()), "fgt_fold")
     return out
 
 

@@ -135,10 +135,12 @@ int fgt_split(const float* x, long rows, int C, int ldx, void* out_s, int ld_s, 
  * Writes up to two outputs with different affine parameters from one pass over the row:
  *   outA = norm * gA + bA,  outB = norm * gB + bB  (outB = NULL: skipped).
  * Replaces nn.LayerNorm at FGT/models/model.py:126,128,147 and attention_flow.py:84-85,96 (q_norm/k_norm
- * share statistics for window tokens; v_norm). */
+ * share statistics for window tokens; v_norm).
+ * psA / psB > 0: that output is written as a split tensor for the next GEMM (fgt_conv_desc.in_split): the pointer is the bf16 hi
+ * plane, ld in bf16 elements, the lo plane ps elements further; 0 = fp32. */
 int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, long rows, float eps,
                   const float* gA, const float* bA, float* outA, int ldA,
-                  const float* gB, const float* bB, float* outB, int ldB, void* stream);
+                  const float* gB, const float* bB, float* outB, int ldB, long long psA, long long psB, void* stream);
 
 /* Fused softmax(Q K^T / sqrt(d)) V with streaming (flash) softmax, d = 128, on fp32 MFMA.
  * mode 0 — temporal zone attention (attention_base.py:16-22 called from :61-69,93-101): tokens of all
@@ -159,6 +161,8 @@ typedef struct fgt_attn_desc {
     int ws, n_global;       /* mode 1                                                                 */
     int ldq, qoff, ldk, koff, ldv, voff, ldg_k, ldg_v, ldo;
     int precision;          /* FGT_PREC_FP32 | FGT_PREC_BF16X3 (Q, K, P, V split into hi/lo bf16, 3 MFMAs per product) */
+    int out_split;          /* 1: O is a split tensor (see fgt_conv_desc): pointer to the bf16 hi plane, ldo in bf16 elements */
+    long long pso;          /* plane stride of O in bf16 elements (out_split = 1)                                            */
 } fgt_attn_desc;
 
 int fgt_attention(const fgt_attn_desc* d, const float* Q, const float* K, const float* V,
@@ -180,7 +184,9 @@ int fgt_dw3x3_residual(const float* x, int bt, int h, int w, int C, const float*
  * Replaces F.fold / nn.Fold at ffn_base.py:56-75 (normalize=1: fold(x)/fold(ones)) and
  * FGT/models/model.py:102-110 (normalize=0) fused with the residual add at model.py:279. */
 int fgt_fold(const float* Y, int ldy, int frames, int th, int tw, int C, int k, int s, int p, int Hf, int Wf,
-             int normalize, const float* res, int ldres, float* out, int ldo, void* stream);
+             int normalize, const float* res, int ldres, float* out, int ldo,
+             int relu /* max(.,0) last: the FFN's ReLU in front of its second Linear, ffn_base.py:40 */,
+             long long ps_out /* > 0: `out` is the hi plane of a split tensor (bf16 elements), lo plane ps_out further */, void* stream);
 
 /* NCHW -> channels-last slice: dst[n, y, x, coff + c] = src[n, c, y, x] * scale + shift for c < C;
  * zero_to > C additionally zero-fills channels [C, zero_to).  (input packing: model.py:253-257) */

@@ -26,9 +26,19 @@ class Split:
     def __init__(self, x):
         self.x = x
 
+    @staticmethod
+    def empty(shape, device=None):
+        return Split(torch.empty(tuple(shape)))
+
     @property
     def shape(self):
         return self.x.shape
+
+    def __getitem__(self, idx):
+        return Split(self.x[idx])
+
+    def view(self, *shape):
+        return Split(self.x.view(*shape))
 
 
 def split(x, relu=False, out=None):
@@ -103,27 +113,29 @@ def linear(x, pc, **kw):
     rows = x.shape[0]
     out = kw.pop("out", None)
     x1 = kw.pop("x1", None)
-    y = conv2d(x.unsqueeze(0).unsqueeze(0), pc, x1=None if x1 is None else x1.unsqueeze(0).unsqueeze(0), **kw).reshape(rows, pc.Cout)
+    img = lambda t: None if t is None else (Split(t.x.unsqueeze(0).unsqueeze(0)) if isinstance(t, Split) else t.unsqueeze(0).unsqueeze(0))
+    y = conv2d(img(x), pc, x1=img(x1), **kw).reshape(rows, pc.Cout)
     if out is not None:
         out.copy_(y)
         return out
     return y
 
 
-def layernorm(x0, gA, bA, x1=None, gB=None, bB=None, outA=None, outB=None, eps=1e-5):
+def _emit(val, out, as_split):
+    """Write `val` into `out` (fp32 tensor or Split) if given, else return it (wrapped when as_split)."""
+    if out is None:
+        return Split(val) if as_split else val
+    (out.x if isinstance(out, Split) else out).copy_(val)
+    return out
+
+
+def layernorm(x0, gA, bA, x1=None, gB=None, bB=None, outA=None, outB=None, eps=1e-5, splitA=False, splitB=False):
     cat = x0 if x1 is None else torch.cat([x0, x1], 1)
     C = cat.shape[1]
-    a = F.layer_norm(cat, (C,), gA, bA, eps)
-    if outA is not None:
-        outA.copy_(a)
-        a = outA
+    a = _emit(F.layer_norm(cat, (C,), gA, bA, eps), outA, splitA)
     if gB is None:
         return a
-    b = F.layer_norm(cat, (C,), gB, bB, eps)
-    if outB is not None:
-        outB.copy_(b)
-        b = outB
-    return a, b
+    return a, _emit(F.layer_norm(cat, (C,), gB, bB, eps), outB, splitB)
 
 
 def _sdpa(q, k, v):
@@ -131,17 +143,17 @@ def _sdpa(q, k, v):
     return torch.matmul(F.softmax(s, dim=-1), v)
 
 
-def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None):
+def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None, out_split=False):
     zh, zw, d = nh // group, nw // group, c // heads
 
     def zones(y):
         return y.reshape(b, t, group, zh, group, zw, heads, d).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, group * group, heads, -1, d)
 
     a = _sdpa(zones(qkv[:, :c]), zones(qkv[:, c:2 * c]), zones(qkv[:, 2 * c:3 * c]))
-    return a.view(b, group, group, heads, t, zh, zw, d).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(b * t * nh * nw, c)
+    return _emit(a.view(b, group, group, heads, t, zh, zw, d).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(b * t * nh * nw, c), None, out_split)
 
 
-def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, precision=None):
+def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, precision=None, out_split=False):
     c = q.shape[1]
     gh, gw, d = nh // ws, nw // ws, c // heads
 
@@ -155,7 +167,7 @@ def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, pr
     V = torch.cat([windows(v), vg.reshape(bt, 1, n_global, c).expand(-1, gh * gw, -1, -1)], 2)
     a = _sdpa(split(windows(q)), split(K), split(V))
     a = a.transpose(2, 3).reshape(bt, gh, gw, ws, ws, c).transpose(2, 3).reshape(bt, nh, nw, c)
-    return a[:, :h, :w].reshape(bt * h * w, c)
+    return _emit(a[:, :h, :w].reshape(bt * h * w, c), None, out_split)
 
 
 def dw_pool(x0, x1, bt, nh, nw, k, w, bias, out):
@@ -172,7 +184,7 @@ def dw3x3_residual(x, bt, h, w, wgt, bias):
     return (F.conv2d(m, wgt, bias, 1, 1, 1, C) + m).permute(0, 2, 3, 1).contiguous().reshape(x.shape)
 
 
-def fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize, res=None, out=None):
+def fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize, res=None, out=None, relu=False, out_split=False):
     cols = Y.reshape(frames, th * tw, k * k, Cc).permute(0, 3, 2, 1).reshape(frames, Cc * k * k, th * tw)  # back to (c, tap)
     f = F.fold(cols, (Hf, Wf), k, stride=s, padding=p)
     if normalize:
@@ -180,10 +192,9 @@ def fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize, res=None, out=None):
     f = f.permute(0, 2, 3, 1)
     if res is not None:
         f = res.reshape(frames, Hf, Wf, Cc) + f
-    if out is not None:
-        out.copy_(f)
-        return out
-    return f.contiguous()
+    if relu:
+        f = F.relu(f)
+    return _emit(f.contiguous(), out, out_split)
 
 
 def nchw_to_nhwc(src, dst, coff=0, zero_to=0, scale=1.0, shift=0.0):

@@ -208,3 +208,59 @@ def test_conv_interleaved_two_source_and_out_il(dev):
     with pytest.raises(RuntimeError, match="multiples of 32"):
         ops.conv2d(ops.Split(torch.zeros(1, 8, 8, 80, dtype=torch.bfloat16, device=dev), True),
                    ops.PackedConv(_rand(16, 40, 3, 3, seed=2).to(dev), None), pad=1, precision="bf16x3", tile="64x64")
+
+
+# ---- fused producers of split tensors: LayerNorm, attention, fold (the GEMM operands of the transformer blocks)
+def _same_split(sp, ref32):
+    from fgt_amd import ops
+    want = ops.split(ref32.contiguous())
+    return torch.equal(sp.data[0], want.data[0]) and torch.equal(sp.data[1], want.data[1])
+
+
+def test_layernorm_split_outputs(dev):
+    from fgt_amd import ops
+    rows = 777
+    x0, x1 = _rand(rows, 512, seed=1, scale=2.0).to(dev), _rand(rows, 256, seed=2).to(dev)
+    gA, bA, gB, bB = (_rand(768, seed=s).to(dev) for s in (3, 4, 5, 6))
+    a32, b32 = ops.layernorm(x0, gA, bA, x1=x1, gB=gB, bB=bB)
+    a, b = ops.layernorm(x0, gA, bA, x1=x1, gB=gB, bB=bB, splitA=True, splitB=True)
+    assert _same_split(a, a32) and _same_split(b, b32)
+    # mixed: fp32 A, split B written into a row slice of a longer split buffer (the spatial block's key buffer)
+    big = ops.Split.empty((rows + 60, 768), dev)
+    big.data.zero_()
+    a2 = torch.empty(rows, 768, device=dev)
+    ops.layernorm(x0, gA, bA, x1=x1, gB=gB, bB=bB, outA=a2, outB=big[:rows])
+    assert torch.equal(a2, a32) and _same_split(big[:rows], b32) and float(big.data[:, rows:].float().abs().max()) == 0.0
+    g1, b1 = _rand(512, seed=7).to(dev), _rand(512, seed=8).to(dev)
+    assert _same_split(ops.layernorm(x0, g1, b1, splitA=True), ops.layernorm(x0, g1, b1))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_attention_split_output(prec, dev):
+    from fgt_amd import ops
+    b, t, nh, nw, c = 1, 3, 20, 36, 512
+    qkv = _rand(b * t * nh * nw, 3 * c, seed=1).to(dev)
+    o32 = ops.attention_temporal(qkv, b, t, nh, nw, 4, 2, c, precision=prec)
+    assert _same_split(ops.attention_temporal(qkv, b, t, nh, nw, 4, 2, c, precision=prec, out_split=True), o32)
+    bt, h, w, nh, nw = 2, 22, 35, 24, 40
+    q, k, v = (_rand(bt * nh * nw, c, seed=s).to(dev) for s in (2, 3, 4))
+    kg, vg = _rand(bt * 60, c, seed=5).to(dev), _rand(bt * 60, c, seed=6).to(dev)
+    o32 = ops.attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, 4, 8, 60, precision=prec)
+    assert _same_split(ops.attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, 4, 8, 60, precision=prec, out_split=True), o32)
+
+
+def test_fold_relu_split_output(dev):
+    from fgt_amd import ops
+    frames, th, tw, Cc, k, s, p, Hf, Wf = 3, 20, 36, 40, 7, 3, 3, 60, 108
+    Y = _rand(frames * th * tw, k * k * Cc, seed=1).to(dev)
+    f32 = ops.fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize=True)
+    fr = ops.fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize=True, relu=True)
+    assert torch.equal(fr, f32.clamp_min(0))
+    assert _same_split(ops.fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize=True, relu=True, out_split=True), fr)
+    # ReLU-then-split feeding the 7x7/s3 conv == the conv with ReLU on the gathered fp32 values (the two FFN formulations)
+    w = _rand(512, Cc, k, k, seed=2, scale=0.05)
+    pc = ops.PackedConv(w.to(dev), None)
+    a = ops.conv2d(f32, pc, stride=s, pad=p, in_relu=True, precision="bf16x3")
+    bsp = ops.conv2d(ops.fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize=True, relu=True, out_split=True), pc, stride=s, pad=p,
+                     precision="bf16x3")
+    assert torch.equal(a, bsp)
