@@ -4,12 +4,17 @@
 * `ClipRunner`       — keeps the clip resident in HBM, runs every window through the HIP model, composes and
                        blends on device in ascending window order (the blend is order dependent, :731-740), and
                        returns the composited clip once (one D2H instead of one per window).
-* window sharding    — windows are independent: rank r takes windows r, r+W, ...; the per-window
-                       outputs are exchanged with ONE all-gather (RCCL over xGMI on the GPU box, gloo in the CPU
-                       tests) and every rank applies the ordered blend locally.
+* feature cache      — the per-frame stages (conv encoders + soft split) run once per frame and clip pass instead of once per
+                       window the frame appears in; windows gather their frames' features (exact).
+* window batching    — windows of equal length are independent batch elements of the model: up to `window_batch` of them run
+                       as one forward (bit-identical outputs, larger launches).
+* window sharding    — windows are independent: rank r takes windows r, r+W, ...; frames are block-sharded
+                       for the per-frame stages (one all-gather of the features), the per-window outputs are exchanged with ONE
+                       all-gather (RCCL over xGMI on the GPU box, gloo in the CPU tests) and every rank applies the ordered
+                       blend locally.
 
 The per-rank model call is injectable (`forward=`) so the scheduling / sharding / blend logic is testable on CPU
-with the oracle standing in for the device model (tests/test_scheduler.py, tests/test_dist_cpu.py).
+with the oracle standing in for the device model (tests/test_scheduler.py, tests/test_scheduler_cache.py).
 """
 import torch
 
