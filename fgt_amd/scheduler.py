@@ -113,13 +113,27 @@ class ClipRunner:
         by_t = {}
         for wi in self.mine:
             by_t.setdefault(len(self.sched[wi][0]) + len(self.sched[wi][1]), []).append(wi)
-        self.groups = [ws[i:i + self.window_batch] for _, ws in sorted(by_t.items()) for i in range(0, len(ws), self.window_batch)]
+        self.groups = []
+        for t, ws in sorted(by_t.items()):
+            nb = min(self.window_batch, self._max_batch(t))
+            self.groups += [ws[i:i + nb] for i in range(0, len(ws), nb)]
         self._group_ids, self._group_keep = [], []
         for ws in self.groups:
             t = len(self.sched[ws[0]][0]) + len(self.sched[ws[0]][1])
             self._group_ids.append(torch.cat([self._ids[wi] for wi in ws]))
             self._group_keep.append(torch.tensor([j * t + i for j, wi in enumerate(ws) for i in range(len(self.sched[wi][0]))],
                                                  dtype=torch.int64, device=self.dev))
+
+    def _max_batch(self, t):
+        """Largest window batch whose spatial attention still fits one launch: fgt_attention maps one (frame, window, head)
+        problem to a grid.y index (<= 65535)."""
+        cfg = getattr(getattr(self.model, "net", None), "cfg", None)
+        if not cfg:
+            return 1
+        tok = lambda n, i: (n // 4 + 2 * cfg["p"][i] - cfg["k"][i]) // cfg["s"][i] + 1
+        th, tw, ws = tok(self.H, 0), tok(self.W, 1), cfg["ws"]
+        per_frame = -(-th // ws) * -(-tw // ws) * cfg["heads"]
+        return max(1, 65535 // (t * per_frame))
 
     def run_window(self, wi):
         ids = self._ids[wi]
