@@ -194,7 +194,7 @@ def main():
         fps = args.frames * args.steps / dt * (world if weak else 1)
         clip_flops = sum(fgt_flops(len(a) + len(b)) for a, b in runner.sched) if (args.height, args.width) == (240, 432) else None
         out = {
-            "metric": "inpainted frames/sec at 432x240x80 clip (FGT stage: 16 sliding-window forwards + compose/blend)",
+            "metric": f"inpainted frames/sec at {args.width}x{args.height}x{args.frames} clip (FGT stage: {len(runner.sched)} sliding-window forwards + compose/blend)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
