@@ -44,7 +44,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N == 0, "add the immediate");
 }
 
-template <int BM, int BN, int WM, int WN, int MINW, int NS, bool PP>
+template <int BM, int BN, int WM, int WN, int MINW, int NS, bool PP, bool IL = false>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const ConvP p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -56,6 +56,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     static_assert(GA % NW == 0 && A_IT >= 1 && (2 * GB) % NW == 0 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile / wavefront geometry");
     static_assert(NS >= 2 && NS <= 4, "LDS ring depth");
     static_assert(!PP || (NS >= 3 && NW % 2 == 0), "ping-pong needs a ring of >= 3 stages and an even wavefront count");
+    static_assert(!IL || (NS == 2 && !PP && TM >= 2), "interleaved schedule: double buffer, >= 2 row blocks per wavefront");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const fgt_conv_desc& d = p.d;
@@ -153,6 +154,33 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
         const unsigned long a = reinterpret_cast<unsigned long>(ptr);
         return reinterpret_cast<const void*>(zpi + ((a - zpi) & (ok ? ~0ul : 0ul)));
     };
+    auto advance_A = [&]() {
+        k_cur += BK;
+        ci += BK;
+        if (ci >= seg_end) {
+            while (ci >= Cg) {
+                ci -= Cg;
+                if (++kx == d.kw) { kx = 0; ++ky; }
+            }
+            retap();
+        }
+    };
+    // single DMA pieces (interleaved schedule): piece j < 2*A_IT is (A group j/2, plane j%2), the rest are the B pieces
+    auto issue_piece = [&](int j, int slot) {
+        char* st = lds + slot * STAGE_B;
+        if (j < 2 * A_IT) {
+            const int it = j >> 1, plane = j & 1;
+            const bool ok = (k_cur < p.K) && ((a_okmask >> it) & 1u);
+            const __bf16* src = a_base[it] + ((ci << il_sh) - il_sub) + (plane ? a_ps : 0);
+            glds16(sel(src, ok), st + (wave + it * NW) * 1024 + plane * BM * 64);
+        } else {
+            const int it = j - 2 * A_IT;
+            const int piece = wave + it * NW, plane = piece / GB, grp = piece % GB;    // wave-uniform
+            const bool bok = BN <= 128 || wrow[it] != nullptr;
+            glds16(sel(wrow[it], bok), st + 2 * BM * 64 + plane * BN * 64 + grp * 1024);
+            if (bok) wrow[it] += w_adv;
+        }
+    };
     auto issue_tile = [&](int slot) {
         char* st = lds + slot * STAGE_B;
         const bool kval = k_cur < p.K;
@@ -172,15 +200,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
             glds16(sel(wrow[it], bok), dst);
             if (bok) wrow[it] += w_adv;
         }
-        k_cur += BK;
-        ci += BK;
-        if (ci >= seg_end) {
-            while (ci >= Cg) {
-                ci -= Cg;
-                if (++kx == d.kw) { kx = 0; ++ky; }
-            }
-            retap();
-        }
+        advance_A();
     };
 
     f32x16 acc[TM][TN];
@@ -241,7 +261,70 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
         }
     };
 
-    if constexpr (!PP) {
+    if constexpr (IL) {
+        // Interleaved schedule (one workgroup per CU, large tile): the K-step's DMA pieces and fragment reads are spread through
+        // its MFMAs instead of being issued as bursts.  A-fragments live in ONE register set that is refilled row block by row block
+        // for the next k-half as soon as the row block's MFMAs of the current half are issued; B-fragments are double buffered.
+        // Per (row block i, k-half ks): 3*TN MFMAs in the product order of conv_igemm.hip, then one fragment refill and one DMA.
+        bf16x8 ah[TM], al[TM], bh[2][TN], bl[2][TN];
+        auto readA = [&](int i, int ks) {
+            const __bf16* base = reinterpret_cast<const __bf16*>(smem + slot * STAGE);
+            const __bf16* Ahi = base + (wm * WTM + i * 32 + l31) * LDB + swz(l31, ks * 2 + lh);
+            ah[i] = *reinterpret_cast<const bf16x8*>(Ahi);
+            al[i] = *reinterpret_cast<const bf16x8*>(Ahi + BM * LDB);
+        };
+        auto readB = [&](int ks) {
+            const __bf16* base = reinterpret_cast<const __bf16*>(smem + slot * STAGE);
+            const __bf16* Bhi = base + 2 * BM * LDB + (wn * WTN + l31) * LDB + swz(l31, ks * 2 + lh);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[ks][j] = *reinterpret_cast<const bf16x8*>(Bhi + j * 32 * LDB);
+                bl[ks][j] = *reinterpret_cast<const bf16x8*>(Bhi + BN * LDB + j * 32 * LDB);
+            }
+        };
+        auto mm = [&](int i, int ks) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[ks][j], acc[i][j], 0, 0, 0);
+        };
+        constexpr int GROUPS = 2 * TM;                       // (ks, i) groups per K-step
+        constexpr int PPG = (DPT + GROUPS - 1) / GROUPS;     // DMA pieces issued behind each MFMA group
+        for (int kt = 0; kt < p.nk; ++kt) {
+            const bool more = kt + 1 < p.nk;
+            readB(0);
+            readA(0, 0);
+            readA(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gi = 0; gi < GROUPS; ++gi) {
+                const int ks = gi / TM, i = gi % TM;
+                mm(i, ks);
+                __builtin_amdgcn_sched_barrier(0);
+                // refill: the A row block two groups ahead (same k-half, or row block 0/1 of the next half), B of the next half
+                const int gn = gi + 2;
+                if (gn < GROUPS) {
+                    if (gn == TM) readB(1);
+                    readA(gn % TM, gn / TM);
+                }
+                if (more) {
+#pragma unroll
+                    for (int j = gi * PPG; j < (gi + 1) * PPG && j < DPT; ++j) {
+                        issue_piece(j, slot_in);
+                        if (j == 2 * A_IT - 1) advance_A();
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            slot ^= 1;
+            slot_in ^= 1;
+        }
+    } else if constexpr (!PP) {
         for (int kt = 0; kt < p.nk; ++kt) {
             if (kt + AHEAD < p.nk) issue_tile(slot_in);
             bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
@@ -291,14 +374,14 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
 }
 
-template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2, bool PP = false>
+template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2, bool PP = false, bool IL = false>
 int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr size_t smem = (size_t)NS * (BM + BN) * LDB * sizeof(float);
     static_assert(smem <= 160 * 1024, "LDS ring does not fit");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
             fgt_set_error("hipFuncSetAttribute(conv_split %dx%d): %s", BM, BN, hipGetErrorString(e));
@@ -311,7 +394,7 @@ int launch(const ConvP& p, hipStream_t s) {
     q.ntiles = cdiv(p.Cout_g, BN);
     q.mchunk = cdiv(q.mtiles, 8);
     dim3 grid(q.xcd_swizzle ? 8 * q.mchunk * q.ntiles : q.mtiles * q.ntiles, p.d.groups);
-    hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP>), grid, dim3(NT), smem, s, q);
+    hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL>), grid, dim3(NT), smem, s, q);
     return fgt_check_launch("conv_split");
 }
 
@@ -332,6 +415,8 @@ int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_128x128x8_S4: return launch<128, 128, 2, 4, 4, 4>(p, s);        // one workgroup per CU, 4-stage ring (128 KB)
         case FGT_TILE_256x128x8_PP: return launch<256, 128, 4, 2, 2, 3, true>(p, s);  // + ping-pong wavefront groups
         case FGT_TILE_128x128x8_PP: return launch<128, 128, 2, 4, 4, 4, true>(p, s);
+        case FGT_TILE_256x256x8_IL: return launch<256, 256, 2, 4, 2, 2, false, true>(p, s);   // one workgroup per CU, interleaved schedule
+        case FGT_TILE_256x128x8_IL: return launch<256, 128, 4, 2, 2, 2, false, true>(p, s);
         default: fgt_set_error("fgt_conv2d: unknown tile %d", tile); return FGT_EINVAL;
     }
 }

@@ -31,8 +31,11 @@ LAYERS = {  # name: (N, H, W, C0, C1, Cout, groups, k, stride, pad)
     "b4 qkv  512->1536": (1, 1, 48960, 512, 0, 1536, 1, 1, 1, 0),
     "b4 proj 512->512": (1, 1, 48960, 512, 0, 512, 1, 1, 1, 0),
     "b4 k    768->512": (1, 1, 69360, 768, 0, 512, 1, 1, 1, 0),
+    "b8 ffn1 512->1960": (1, 1, 97920, 512, 0, 1960, 1, 1, 1, 0),
+    "b8 qkv  512->1536": (1, 1, 97920, 512, 0, 1536, 1, 1, 1, 0),
+    "b8 proj 512->512": (1, 1, 97920, 512, 0, 512, 1, 1, 1, 0),
 }
-TILES = ["128x128", "256x128", "128x128x8", "256x128x16", "256x64x8", "256x128x8s3", "128x128x8s4", "256x128x8pp", "128x128x8pp"]
+TILES = ["128x128", "256x128", "128x128x8", "256x128x16", "256x64x8", "256x128x8s3", "256x128x8pp", "256x128x8il", "256x256x8il"]
 
 
 def bench(fn, reps):
@@ -70,7 +73,7 @@ def main():
         cells = []
         for t in TILES:
             o1, o2 = torch.empty_like(out), torch.empty_like(out)
-            if t.endswith(("s3", "s4", "pp")):        # split inputs only
+            if t.endswith(("s3", "s4", "pp", "il")):        # split inputs only
                 ops.conv2d(x, pc, x1=x1, stride=s, pad=p, act="lrelu", tile="128x128", precision="bf16x3", out=o1)
                 ms_a = float("inf")
             else:
