@@ -76,6 +76,68 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         }
         __syncthreads();
         const int mbase = bm0 + ps * EP_BM;
+        // Fast path (every layer of the hot path): float4 columns.  A thread keeps the same 4 output channels in every iteration
+        // (NT is a multiple of BN/4), so scale / bias are loaded once; all LDS reads and aux loads of the tile pass are issued before
+        // the first store (the loop below it used to run one dependent load chain per float4: 271 us of an 802-us K = 512 GEMM).
+        constexpr int C4 = BN / 4;
+        if (vec_ok && NT % C4 == 0) {
+            constexpr int RPI = NT / C4 > 0 ? NT / C4 : 1;           // tile rows covered per iteration
+            constexpr int ITER = (EP_BM + RPI - 1) / RPI;
+            const int c4 = tid % C4, r0 = tid / C4;
+            const int n = bn0 + c4 * 4;
+            const bool col_ok = n < p.Cout_g;                        // Cout_g % 4 == 0: the whole float4 is in or out
+            const int co = g * p.Cout_g + n;
+            const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 sc = (p.cscale && col_ok) ? *reinterpret_cast<const float4*>(p.cscale + co) : one;
+            const float4 bi = (p.cbias && col_ok) ? *reinterpret_cast<const float4*>(p.cbias + co) : zero;
+            constexpr int UN = ITER < 4 ? ITER : 4;                  // iterations whose loads are in flight together
+#pragma unroll
+            for (int c0 = 0; c0 < ITER; c0 += UN) {
+                float4 cv[UN], a1[UN], a2[UN];
+                bool ok[UN];
+#pragma unroll
+                for (int u0 = 0; u0 < UN; ++u0) {
+                    const int row = r0 + (c0 + u0) * RPI;
+                    const int m = mbase + row;
+                    ok[u0] = col_ok && (c0 + u0) < ITER && row < EP_BM && m < p.M;
+                    cv[u0] = *reinterpret_cast<const float4*>(Cs + min(row, EP_BM - 1) * BN + c4 * 4);
+                    // (out-of-range lanes read the zero page: the select is on the address, the loads stay back to back)
+                    a1[u0] = zero;
+                    a2[u0] = zero;
+                    if (d.epi != FGT_EPI_NONE)
+                        a1[u0] = *reinterpret_cast<const float4*>(ok[u0] ? p.aux1 + (long)m * d.ld_aux1 + co : p.zero_page);
+                    if (d.epi == FGT_EPI_GRU)
+                        a2[u0] = *reinterpret_cast<const float4*>(ok[u0] ? p.aux2 + (long)m * d.ld_aux2 + co : p.zero_page);
+                }
+#pragma unroll
+                for (int u0 = 0; u0 < UN; ++u0) {
+                    const int m = mbase + r0 + (c0 + u0) * RPI;
+                    float v[4] = {cv[u0].x * sc.x + bi.x, cv[u0].y * sc.y + bi.y, cv[u0].z * sc.z + bi.z, cv[u0].w * sc.w + bi.w};
+                    const float x1[4] = {a1[u0].x, a1[u0].y, a1[u0].z, a1[u0].w};
+                    const float x2[4] = {a2[u0].x, a2[u0].y, a2[u0].z, a2[u0].w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        float x = fgt_act(v[u], d.act, d.slope) * d.out_scale;
+                        if (d.epi == FGT_EPI_MUL) x *= x1[u];
+                        else if (d.epi == FGT_EPI_ADD) x = fgt_act(x + x1[u], d.act2, d.slope);
+                        else if (d.epi == FGT_EPI_GRU) x = (1.f - x1[u]) * x2[u] + x1[u] * x;
+                        v[u] = x;
+                    }
+                    if (ok[u0]) {
+                        if (want_f32) *reinterpret_cast<float4*>(p.out + (long)m * d.ldo + d.ooff + co) = make_float4(v[0], v[1], v[2], v[3]);
+                        if (want_split) {
+                            uint2 hi, lo;
+                            split4(make_float4(v[0], v[1], v[2], v[3]), hi, lo);
+                            const int cs = d.ooff_s + co;       // pso == 32: interleaved layout, channel c -> (c/32)*64 + c%32, lo 32 further
+                            __bf16* o = p.out_s + (long)m * d.ldo_s + (p.pso == 32 ? ((cs >> 5) << 6) + (cs & 31) : cs);
+                            *reinterpret_cast<uint2*>(o) = hi;
+                            *reinterpret_cast<uint2*>(o + p.pso) = lo;
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         for (int idx = tid; idx < EP_BM * (BN / 4); idx += NT) {
             const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
             const int m = mbase + row;

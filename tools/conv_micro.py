@@ -17,6 +17,9 @@ LAYERS = {  # name: (N, H, W, Cin, C1, Cout, groups, k, stride, pad)
     "enc10": (17, 60, 108, 256, 384, 512, 2, 3, 1, 1),       # grouped two-source (324.9 GFLOP)
     "ffn1": (1, 1, 12240, 512, 0, 1960, 1, 1, 1, 0),         # FFN Linear 512 -> 1960
     "dec3": (17, 120, 216, 64, 0, 64, 1, 3, 1, 1),           # decoder layer3 with x2 upsample (run without here)
+    "qkv8": (1, 1, 97920, 512, 0, 1536, 1, 1, 1, 0),          # fused QKV projection of 8 batched windows
+    "qkv8_k32": (1, 1, 97920, 32, 0, 1536, 1, 1, 1, 0),       # same output, ONE K-step: prologue + epilogue cost of the tile grid
+    "qkv8_k128": (1, 1, 97920, 128, 0, 1536, 1, 1, 1, 0),
 }
 
 
