@@ -415,7 +415,6 @@ int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_128x128x8_S4: return launch<128, 128, 2, 4, 4, 4>(p, s);        // one workgroup per CU, 4-stage ring (128 KB)
         case FGT_TILE_256x128x8_PP: return launch<256, 128, 4, 2, 2, 3, true>(p, s);  // + ping-pong wavefront groups
         case FGT_TILE_128x128x8_PP: return launch<128, 128, 2, 4, 4, 4, true>(p, s);
-        case FGT_TILE_256x256x8_IL: return launch<256, 256, 2, 4, 2, 2, false, true>(p, s);   // one workgroup per CU, interleaved schedule
         case FGT_TILE_256x128x8_IL: return launch<256, 128, 4, 2, 2, 2, false, true>(p, s);
         default: fgt_set_error("fgt_conv2d: unknown tile %d", tile); return FGT_EINVAL;
     }

@@ -61,46 +61,47 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
     const bool vec_ok = (p.Cout_g % 4 == 0) && !d.out_nchw && (d.ldo % 4 == 0) && (d.ooff % 4 == 0) &&
                         (d.epi == FGT_EPI_NONE || d.ld_aux1 % 4 == 0) && (d.epi != FGT_EPI_GRU || d.ld_aux2 % 4 == 0);
     const bool want_f32 = d.out_split != 1, want_split = d.out_split != 0;
+
+    // ---- fast path (every layer of the hot path: float4-aligned channels-last output): WAVE-PRIVATE staging.  Each wavefront
+    // transposes its own accumulators, one 32-row block at a time, through its own 32 x WTN patch of LDS and streams the rows out
+    // as float4 (a row of the patch is WTN consecutive channels = one or two full 128-byte lines).  No workgroup barrier: the
+    // wavefronts of a tile finish independently, and the next workgroup's K loop overlaps this one's stores.  Scale / bias are
+    // per-lane constants (a lane keeps its 4 channels), the LDS reads and aux loads of a row block are issued before its stores.
+    // (The workgroup-wide version of this epilogue took 271 us of an 802-us K = 512 GEMM.)
+    constexpr int PATCH = 32 * WTN;                                    // floats per wavefront
+    if (vec_ok && (WM * WN) * PATCH <= 2 * STAGE) {
+        float* Ws = smem + wave * PATCH;
+        constexpr int LPR = WTN / 4;                                   // lanes per row (8 or 16)
+        constexpr int RPI = 64 / LPR;                                  // rows per wave-instruction (8 or 4)
+        constexpr int ITER = 32 / RPI;                                 // 4 or 8
+        const int c4 = lane % LPR, r0 = lane / LPR;
+        const int n = bn0 + wn * WTN + c4 * 4;
+        const bool col_ok = n < p.Cout_g;                              // Cout_g % 4 == 0: the whole float4 is in or out
+        const int co = g * p.Cout_g + n;
+        const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 sc = (p.cscale && col_ok) ? *reinterpret_cast<const float4*>(p.cscale + co) : one;
+        const float4 bi = (p.cbias && col_ok) ? *reinterpret_cast<const float4*>(p.cbias + co) : zero;
 #pragma unroll
-    for (int ps = 0; ps < EP_PASSES; ++ps) {
-        if (ps > 0) __syncthreads();
-        if (wm / WM_PER_PASS == ps) {
-            const int wml = wm % WM_PER_PASS;
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        Cs[(wml * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * BN + wn * WTN + j * 32 + l31] = acc[i][j][e];
-        }
-        __syncthreads();
-        const int mbase = bm0 + ps * EP_BM;
-        // Fast path (every layer of the hot path): float4 columns.  A thread keeps the same 4 output channels in every iteration
-        // (NT is a multiple of BN/4), so scale / bias are loaded once; all LDS reads and aux loads of the tile pass are issued before
-        // the first store (the loop below it used to run one dependent load chain per float4: 271 us of an 802-us K = 512 GEMM).
-        constexpr int C4 = BN / 4;
-        if (vec_ok && NT % C4 == 0) {
-            constexpr int RPI = NT / C4 > 0 ? NT / C4 : 1;           // tile rows covered per iteration
-            constexpr int ITER = (EP_BM + RPI - 1) / RPI;
-            const int c4 = tid % C4, r0 = tid / C4;
-            const int n = bn0 + c4 * 4;
-            const bool col_ok = n < p.Cout_g;                        // Cout_g % 4 == 0: the whole float4 is in or out
-            const int co = g * p.Cout_g + n;
-            const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 sc = (p.cscale && col_ok) ? *reinterpret_cast<const float4*>(p.cscale + co) : one;
-            const float4 bi = (p.cbias && col_ok) ? *reinterpret_cast<const float4*>(p.cbias + co) : zero;
-            constexpr int UN = ITER < 4 ? ITER : 4;                  // iterations whose loads are in flight together
+                for (int e = 0; e < 16; ++e) Ws[((e & 3) + 8 * (e >> 2) + 4 * lh) * WTN + j * 32 + l31] = acc[i][j][e];
+            __builtin_amdgcn_wave_barrier();                           // the patch is exchanged between lanes of this wavefront only
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int mrow = bm0 + wm * WTM + i * 32 + r0;
+            // loads of UN row groups in flight together (the 128-accumulator-register tiles have little room: 2 at a time)
+            constexpr int UN = (TM * TN >= 8) ? 2 : ITER;
 #pragma unroll
             for (int c0 = 0; c0 < ITER; c0 += UN) {
                 float4 cv[UN], a1[UN], a2[UN];
                 bool ok[UN];
 #pragma unroll
                 for (int u0 = 0; u0 < UN; ++u0) {
-                    const int row = r0 + (c0 + u0) * RPI;
-                    const int m = mbase + row;
-                    ok[u0] = col_ok && (c0 + u0) < ITER && row < EP_BM && m < p.M;
-                    cv[u0] = *reinterpret_cast<const float4*>(Cs + min(row, EP_BM - 1) * BN + c4 * 4);
+                    const int it = c0 + u0;
+                    const int m = mrow + it * RPI;
+                    ok[u0] = col_ok && m < p.M;
+                    cv[u0] = *reinterpret_cast<const float4*>(Ws + (r0 + it * RPI) * WTN + c4 * 4);
                     // (out-of-range lanes read the zero page: the select is on the address, the loads stay back to back)
                     a1[u0] = zero;
                     a2[u0] = zero;
@@ -111,7 +112,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 }
 #pragma unroll
                 for (int u0 = 0; u0 < UN; ++u0) {
-                    const int m = mbase + r0 + (c0 + u0) * RPI;
+                    const int m = mrow + (c0 + u0) * RPI;
                     float v[4] = {cv[u0].x * sc.x + bi.x, cv[u0].y * sc.y + bi.y, cv[u0].z * sc.z + bi.z, cv[u0].w * sc.w + bi.w};
                     const float x1[4] = {a1[u0].x, a1[u0].y, a1[u0].z, a1[u0].w};
                     const float x2[4] = {a2[u0].x, a2[u0].y, a2[u0].z, a2[u0].w};
@@ -136,8 +137,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                     }
                 }
             }
-            continue;
+            __builtin_amdgcn_wave_barrier();                           // the patch is rewritten by the next row block
         }
+        return;
+    }
+
+    // ---- general path (odd channel counts, NCHW output): workgroup-wide staging
+#pragma unroll
+    for (int ps = 0; ps < EP_PASSES; ++ps) {
+        if (ps > 0) __syncthreads();
+        if (wm / WM_PER_PASS == ps) {
+            const int wml = wm % WM_PER_PASS;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        Cs[(wml * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * BN + wn * WTN + j * 32 + l31] = acc[i][j][e];
+        }
+        __syncthreads();
+        const int mbase = bm0 + ps * EP_BM;
         for (int idx = tid; idx < EP_BM * (BN / 4); idx += NT) {
             const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
             const int m = mbase + row;

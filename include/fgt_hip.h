@@ -121,7 +121,7 @@ typedef struct fgt_conv_desc {
 #define FGT_TILE_128x128x8_S4 12  /* split inputs only: 128x128 on 8 wavefronts, 4-stage ring */
 #define FGT_TILE_256x128x8_PP 13  /* split inputs only: 256x128, 3-stage ring, two ping-pong wavefront groups (R / M phases) */
 #define FGT_TILE_128x128x8_PP 14  /* split inputs only: 128x128, 4-stage ring, ping-pong */
-#define FGT_TILE_256x256x8_IL 15  /* split inputs only: 256x256 on 8 wavefronts of 128x64, DMA pieces / fragment reads interleaved with the MFMAs */
+/* 15: retired (256x256 on 8 wavefronts of 128x64 with the interleaved schedule: 220 VGPRs, +0...5 % on N >= 512 GEMMs, slower epilogue) */
 #define FGT_TILE_256x128x8_IL 16  /* split inputs only: 256x128 on 8 wavefronts of 64x64, interleaved schedule */
 
 int fgt_conv2d(const fgt_conv_desc* d, const void* x0, const void* x1, const float* w_packed,

@@ -35,7 +35,7 @@ LAYERS = {  # name: (N, H, W, C0, C1, Cout, groups, k, stride, pad)
     "b8 qkv  512->1536": (1, 1, 97920, 512, 0, 1536, 1, 1, 1, 0),
     "b8 proj 512->512": (1, 1, 97920, 512, 0, 512, 1, 1, 1, 0),
 }
-TILES = ["128x128", "256x128", "128x128x8", "256x128x16", "256x64x8", "256x128x8s3", "256x128x8pp", "256x128x8il", "256x256x8il"]
+TILES = ["128x128", "256x128", "128x128x8", "256x128x16", "256x64x8", "256x128x8s3", "256x128x8pp", "256x128x8il"]
 
 
 def bench(fn, reps):
