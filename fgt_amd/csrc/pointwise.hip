@@ -111,20 +111,32 @@ __global__ void __launch_bounds__(256) dw3x3_res_kernel(const float* x, int bt, 
         long pix = idx / c4n;
         const int px = (int)(pix % w); long r = pix / w;
         const int py = (int)(r % h); const int f = (int)(r / h);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int a = 0; a < 3; ++a) {
-            const int yy = py + a - 1;
-            if (yy < 0 || yy >= h) continue;
+        // the 9 taps unrolled: clamped (always in-range) loads issued back to back, out-of-image taps get a zero WEIGHT
+        // (acc + 0 * v == acc exactly), the 36 weights of the 4 channels are one contiguous run read as 9 float4
+        float4 v[9];
+        float m[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
             for (int b = 0; b < 3; ++b) {
-                const int xx = px + b - 1;
-                if (xx < 0 || xx >= w) continue;
-                const float4 v = *reinterpret_cast<const float4*>(x + (((long)f * h + yy) * w + xx) * C + c);
-                const int wi = a * 3 + b;
-                acc[0] += v.x * wgt[(c + 0) * 9 + wi];
-                acc[1] += v.y * wgt[(c + 1) * 9 + wi];
-                acc[2] += v.z * wgt[(c + 2) * 9 + wi];
-                acc[3] += v.w * wgt[(c + 3) * 9 + wi];
+                const int yy = py + a - 1, xx = px + b - 1;
+                m[a * 3 + b] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? 1.f : 0.f;
+                const int yc = min(max(yy, 0), h - 1), xc = min(max(xx, 0), w - 1);
+                v[a * 3 + b] = *reinterpret_cast<const float4*>(x + (((long)f * h + yc) * w + xc) * C + c);
             }
+        float wv[36];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(wgt + c * 9 + q * 4);
+            wv[q * 4 + 0] = t.x; wv[q * 4 + 1] = t.y; wv[q * 4 + 2] = t.z; wv[q * 4 + 3] = t.w;
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            acc[0] += v[t].x * (wv[0 * 9 + t] * m[t]);
+            acc[1] += v[t].y * (wv[1 * 9 + t] * m[t]);
+            acc[2] += v[t].z * (wv[2 * 9 + t] * m[t]);
+            acc[3] += v[t].w * (wv[3 * 9 + t] * m[t]);
         }
         const float4 ctr = *reinterpret_cast<const float4*>(x + pix * C + c);
         *reinterpret_cast<float4*>(out + pix * C + c) =
@@ -337,6 +349,7 @@ extern "C" int fgt_dw_pool(const float* x0, int C0, int ld0, const float* x1, in
 extern "C" int fgt_dw3x3_residual(const float* x, int bt, int h, int w, int C, const float* wgt, const float* bias, float* out,
                                   void* stream) {
     FGT_REQUIRE(x && wgt && bias && out && C % 4 == 0, "fgt_dw3x3_residual: bad arguments");
+    FGT_REQUIRE(((uintptr_t)wgt & 15) == 0, "fgt_dw3x3_residual: weights must be 16-byte aligned");
     const long total = (long)bt * h * w * (C / 4);
     hipLaunchKernelGGL(dw3x3_res_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, bt, h, w, C, wgt, bias, out);
     return fgt_check_launch("dw3x3_residual");
