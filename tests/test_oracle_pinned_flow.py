@@ -118,3 +118,30 @@ def test_complete_flows_batched_matches_reference_loop(fake):
         o = LO.lafc_forward(sd, cfg, diffused[:, :, ind], masks[:, :, ind])[0]
         ref = o * masks[:, :, ind][:, :, 1] + flows[:, :, ind][:, :, 1] * (1 - masks[:, :, ind][:, :, 1])
         assert rel_err(got[i:i + 1], ref) < 2e-5
+
+
+def test_complete_flows_runs_the_diffusion_fill_itself(fake, monkeypatch):
+    """complete_flows(diffused=None) == diffusion() (tool/video_inpainting.py:42-51, restated in oracle/fill_oracle.py) + the LAFC loop:
+    the flow-completion stage from raw flows, as `complete_flow` (:341-386) runs it."""
+    import numpy as np
+    from fgt_amd import flow_pipeline
+    from oracle import fill_oracle as FO
+    monkeypatch.setattr(flow_pipeline, "ops", fake_ops)
+    cfg = lafc_model.DEFAULT_CONFIG
+    sd = _sd("lafc_vanilla_state_keys.json")
+    m = lafc_model.Model(dict(cfg)).eval()
+    m.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(5)
+    t, H, W = 5, 32, 48
+    flows = torch.randn(1, 2, t, H, W, generator=g)
+    masks = torch.zeros(1, 1, t, H, W)
+    for i in range(t):
+        masks[0, 0, i, 8 + i:20 + i, 10:30] = 1
+    # the reference's layout: flows [t,H,W,2], masks [t,H,W,1]
+    ref_d = FO.diffusion(flows[0].permute(1, 2, 3, 0).numpy(), masks[0].permute(1, 2, 3, 0).numpy())
+    d = flow_pipeline.diffusion(flows, masks)
+    assert d.shape == flows.shape
+    assert np.abs(d[0].permute(1, 2, 3, 0).numpy() - ref_d).max() < 1e-5
+    a = flow_pipeline.complete_flows(m, flows, masks, None, batch=2)
+    b = flow_pipeline.complete_flows(m, flows, masks, d, batch=2)
+    assert torch.equal(a, b)
