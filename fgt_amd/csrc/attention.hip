@@ -374,6 +374,10 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_bf16x3_kernel(const AttnP p) 
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, qh[st], s, 0, 0, 0);
             }
         }
+        // The softmax bookkeeping is VALU work beside 48 MFMAs per tile (PMC: 8.1 VALU per MFMA, wavefronts 26 % VALU-active):
+        // exp2 is the bare v_exp_f32 (arguments <= 0; results below 2^-126 flush to 0, which is what they contribute) instead of the
+        // library exp2f with its denormal-range rescaling (~5 instructions per call, 17 calls per tile).  (Masking only the last tile, or
+        // skipping the O rescale when no query saw a new maximum, needs a branch that spills registers in the 128-VGPR 8-wave variant.)
         float mx = -INFINITY;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -384,11 +388,11 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_bf16x3_kernel(const AttnP p) 
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const float pe = exp2f(s[e] - m_new);
+            const float pe = __builtin_amdgcn_exp2f(s[e] - m_new);
             s[e] = pe;
             psum += pe;
         }
