@@ -73,3 +73,30 @@ def test_window_sharding_two_ranks_gloo(n):
     ref = O.fgt_clip(None, None, fr, fl, ms, forward=cheap_forward)
     for r in range(world):
         assert torch.equal(res[r], ref), f"rank {r} differs from the single-process result"
+
+
+def test_window_groups_partition_the_rank_windows():
+    """ClipRunner.groups: every window of the rank exactly once, equal lengths inside a group, group size bounded by window_batch and
+    by the attention launch limit (_max_batch: frames x windows x heads <= 65535 grid.y entries)."""
+    import torch
+    from fgt_amd.fgt_model import DEFAULT_CONFIG, Model
+    from fgt_amd.scheduler import ClipRunner
+    m = Model(dict(DEFAULT_CONFIG))
+    for (n, H, W, wb, world) in ((80, 240, 432, 8, 1), (80, 240, 432, 4, 3), (160, 480, 864, 8, 1), (40, 1080, 1920, 8, 2)):
+        fr = torch.zeros(1, n, 3, 8, 8)
+        for rank in range(world):
+            r = ClipRunner(m, fr, torch.zeros(1, n, 2, 8, 8), torch.zeros(1, n, 1, 8, 8), rank=rank, world=world, forward=lambda *a: None,
+                           cache_features=False, window_batch=wb)
+            r.H, r.W = H, W                                     # geometry of the real clip (the tensors above are placeholders)
+            r.__init__(m, fr, torch.zeros(1, n, 2, 8, 8), torch.zeros(1, n, 1, 8, 8), rank=rank, world=world, forward=lambda *a: None,
+                       cache_features=False, window_batch=wb)
+            assert sorted(w for g in r.groups for w in g) == r.mine
+            for g in r.groups:
+                ts = {len(r.sched[w][0]) + len(r.sched[w][1]) for w in g}
+                assert len(ts) == 1 and len(g) <= wb
+    big = ClipRunner.__new__(ClipRunner)
+    big.model, big.H, big.W = m, 1080, 1920
+    assert big._max_batch(26) == 2 and big._max_batch(200) == 1
+    small = ClipRunner.__new__(ClipRunner)
+    small.model, small.H, small.W = m, 240, 432
+    assert small._max_batch(17) == 64
