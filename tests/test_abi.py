@@ -48,3 +48,18 @@ def test_ops_fail_loudly_on_cpu_tensors():
     from fgt_amd import ops
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.layernorm(torch.zeros(4, 8), torch.ones(8), torch.zeros(8))
+
+
+def test_bench_and_smoke_fail_loudly_without_a_gpu():
+    """No CPU fallback anywhere on the product path: bench.py refuses to run, smoke() asserts."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "needs the MI355X" in (r.stderr + r.stdout)
