@@ -41,6 +41,7 @@ _F = C.c_float
 SIGNATURES = {
     "fgt_last_error": [],
     "fgt_abi_version": [],
+    "fgt_init": [_I],
     "fgt_conv2d": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "fgt_split": [_P, _L, _I, _I, _P, _I, C.c_longlong, _I, _P],
     "fgt_layernorm": [_P, _I, _I, _P, _I, _I, _L, _F, _P, _P, _P, _I, _P, _P, _P, _I, C.c_longlong, C.c_longlong, _P],
@@ -60,6 +61,9 @@ SIGNATURES = {
     "fgt_instnorm_apply": [_P, _I, _I, _I, _I, _P, _F, _I, _P, _I, _I, _P, _I, _P],
     "fgt_axpby": [_P, _I, _F, _P, _I, _F, _L, _I, _I, _F, _P, _I, _P],
     "fgt_compose_blend": [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P],
+    "fgt_pack_frames": [_P, _P, _P, _I, _I, _I, _P, _I, _P],
+    "fgt_norm_flows": [_P, _I, _I, _I, _L, _P, _P],
+    "fgt_gather_rows": [_P, _L, _P, _I, _L, _P, _L, _P],
     "fgt_laplace_fill_workspace": [_I, _I, _I],
     "fgt_laplace_fill": [_P, _P, _I, _I, _I, _I, _P, _P, _I, _F, _P],
     "fgt_prof_enable": [_I],
@@ -85,6 +89,16 @@ def lib():
             fn.restype = _RESTYPES.get(name, C.c_int)
         _lib = h
     return _lib
+
+
+_inited = set()
+
+
+def init_device(index):
+    """fgt_init(device) once per device: allocates the library's zero page outside any stream capture."""
+    if index not in _inited:
+        check(lib().fgt_init(int(index)), "fgt_init")
+        _inited.add(index)
 
 
 def check(rc, what):

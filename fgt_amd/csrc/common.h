@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "../../include/fgt_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -35,6 +36,21 @@ __device__ __forceinline__ float fgt_act(float v, int act, float slope) {
         case FGT_ACT_TANH: return tanhf(v);
         default: return v;
     }
+}
+
+// One-time, per-device raise of a kernel's dynamic-LDS limit (function attributes are per device; two racing threads both
+// set the same value, which is harmless).  `done` is a per-kernel-instance bit mask of devices already configured.
+static inline int fgt_set_max_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& done, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    if ((done.load(std::memory_order_acquire) >> dev) & 1ull) return FGT_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        fgt_set_error("hipFuncSetAttribute(%s, %d bytes): %s", what, bytes, hipGetErrorString(e));
+        return FGT_ELAUNCH;
+    }
+    done.fetch_or(1ull << dev, std::memory_order_release);
+    return FGT_OK;
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

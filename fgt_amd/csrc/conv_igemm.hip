@@ -290,16 +290,8 @@ template <int BM, int BN, int WM, int WN, int PREC, int MINW = 2>
 int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr size_t smem = 2ul * (PREC == 0 ? (BM + BN) * LDS_LD : (BM + BN) * LDB) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, PREC, MINW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) {
-            fgt_set_error("hipFuncSetAttribute(conv_igemm %dx%d): %s", BM, BN, hipGetErrorString(e));
-            return FGT_ELAUNCH;
-        }
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, PREC, MINW>), (int)smem, lds_set, "conv_igemm")) return rc;
     ConvP q = p;
     q.mtiles = cdiv(p.M, BM);
     q.ntiles = cdiv(p.Cout_g, BN);

@@ -379,16 +379,8 @@ int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr size_t smem = (size_t)NS * (BM + BN) * LDB * sizeof(float);
     static_assert(smem <= 160 * 1024, "LDS ring does not fit");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) {
-            fgt_set_error("hipFuncSetAttribute(conv_split %dx%d): %s", BM, BN, hipGetErrorString(e));
-            return FGT_ELAUNCH;
-        }
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL>), (int)smem, lds_set, "conv_split")) return rc;
     ConvP q = p;
     q.mtiles = cdiv(p.M, BM);
     q.ntiles = cdiv(p.Cout_g, BN);

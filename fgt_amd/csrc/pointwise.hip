@@ -294,6 +294,47 @@ __global__ void __launch_bounds__(256) compose_kernel(const float* out_nchw, con
     }
 }
 
+// tool/video_inpainting.py:697,719-721 + FGT/models/model.py:253-257 in one pass: frames in [0,1] -> (f*2-1)*(1-m) | m, channels-last
+__global__ void __launch_bounds__(256) pack_frames_kernel(const float* frames01, const float* masks, const int* ids, int n, long HW,
+                                                          float* dst, int ldd) {
+    const long total = (long)n * HW;
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long)gridDim.x * blockDim.x) {
+        const long i = pix / HW, rem = pix - i * HW;
+        const long f = ids ? ids[i] : i;
+        const float m = masks[f * HW + rem];
+        const float* s = frames01 + f * 3 * HW + rem;
+        const float keep = 1.f - m;
+        *reinterpret_cast<float4*>(dst + pix * ldd) = make_float4((s[0] * 2.f - 1.f) * keep, (s[HW] * 2.f - 1.f) * keep,
+                                                                    (s[2 * HW] * 2.f - 1.f) * keep, m);
+    }
+}
+
+// tool/video_inpainting.py:402-407 (+ :705): one workgroup per (output frame, channel); signed maximum over H*W, then x / max
+__global__ void __launch_bounds__(256) norm_flows_kernel(const float* src, int n_src, int C, long HW, float* dst) {
+    __shared__ float red[4];
+    const int f = blockIdx.x / C, c = blockIdx.x - f * C;
+    const float* s = src + ((long)min(f, n_src - 1) * C + c) * HW;
+    float* d = dst + (long)blockIdx.x * HW;
+    float mx = -INFINITY;
+    for (long i = threadIdx.x; i < HW; i += 256) mx = fmaxf(mx, s[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    for (long i = threadIdx.x; i < HW; i += 256) d[i] = s[i] / mx;
+}
+
+// dst[i, :] = src[ids[i], :] for rows of row_len floats (row_len % 4 == 0): the window's frames out of the per-frame feature cache
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* src, long ld_src, const int* ids, int n, long row4, float* dst,
+                                                          long ld_dst) {
+    const long total = (long)n * row4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long i = idx / row4, c = (idx - i * row4) * 4;
+        *reinterpret_cast<float4*>(dst + i * ld_dst + c) = *reinterpret_cast<const float4*>(src + (long)ids[i] * ld_src + c);
+    }
+}
+
 inline int grid_for(long total, int block = 256) {
     long g = (total + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -404,6 +445,30 @@ extern "C" int fgt_compose_blend(const float* out_nchw, const int* ids, const in
     hipLaunchKernelGGL(compose_kernel, dim3(grid_for((long)n * H * W)), dim3(256), 0, (hipStream_t)stream, out_nchw, ids, first, n,
                        frames01, masks, H, W, comp);
     return fgt_check_launch("compose_blend");
+}
+
+extern "C" int fgt_pack_frames(const float* frames01, const float* masks, const int* ids, int n, int H, int W, float* dst, int ldd,
+                               void* stream) {
+    FGT_REQUIRE(frames01 && masks && dst && n > 0 && H > 0 && W > 0, "fgt_pack_frames: bad arguments");
+    FGT_REQUIRE(ldd >= 4 && ldd % 4 == 0 && ((uintptr_t)dst & 15) == 0, "fgt_pack_frames: dst must be float4 aligned with ldd %% 4 == 0");
+    hipLaunchKernelGGL(pack_frames_kernel, dim3(grid_for((long)n * H * W)), dim3(256), 0, (hipStream_t)stream, frames01, masks, ids, n,
+                       (long)H * W, dst, ldd);
+    return fgt_check_launch("pack_frames");
+}
+
+extern "C" int fgt_norm_flows(const float* flows, int n_src, int n_out, int C, long HW, float* out, void* stream) {
+    FGT_REQUIRE(flows && out && n_src > 0 && n_out > 0 && C > 0 && HW > 0, "fgt_norm_flows: bad arguments");
+    hipLaunchKernelGGL(norm_flows_kernel, dim3(n_out * C), dim3(256), 0, (hipStream_t)stream, flows, n_src, C, HW, out);
+    return fgt_check_launch("norm_flows");
+}
+
+extern "C" int fgt_gather_rows(const float* src, long ld_src, const int* ids, int n, long row_len, float* dst, long ld_dst, void* stream) {
+    FGT_REQUIRE(src && ids && dst && n > 0 && row_len > 0, "fgt_gather_rows: bad arguments");
+    FGT_REQUIRE(row_len % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0,
+                "fgt_gather_rows: rows must be float4 aligned");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)n * (row_len / 4))), dim3(256), 0, (hipStream_t)stream, src, ld_src, ids, n,
+                       row_len / 4, dst, ld_dst);
+    return fgt_check_launch("gather_rows");
 }
 
 extern "C" int fgt_split(const float* x, long rows, int C, int ldx, void* out_s, int ld_s, long long ps, int relu, void* stream) {

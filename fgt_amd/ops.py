@@ -61,6 +61,7 @@ def _require_dev(*ts):
         if t is not None:
             if not t.is_cuda:
                 raise RuntimeError("fgt_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
+            _lib.init_device(t.device.index)
             if t.dtype != torch.float32:
                 raise RuntimeError(f"fgt_amd ops compute in fp32, got {t.dtype} (split bf16 operands travel as ops.Split)")
 
@@ -526,6 +527,49 @@ def axpby(a, sa=1.0, b=None, sb=1.0, act=None, out=None, slope=0.2):
         out = torch.empty(rows, Cc, dtype=torch.float32, device=a.device)
     check(_lib.lib().fgt_axpby(_ptr(a2), a2.stride(0), sa, _ptr(b), 0 if b is None else b.stride(0), sb, rows, Cc, ACT[act],
                                slope, _ptr(out), out.stride(0), _stream()), "fgt_axpby")
+    return out
+
+
+def pack_frames(frames01, masks, ids=None, out=None):
+    """fgt_pack_frames: frames01 [N,3,H,W] in [0,1], masks [N,1,H,W] -> [n,H,W,4] = ((f*2-1)*(1-m) | m) for frames ids (int32) or all."""
+    _require_dev(frames01, masks, out)
+    assert frames01.is_contiguous() and masks.is_contiguous() and frames01.shape[1] == 3 and masks.shape[1] == 1
+    N, _, H, W = frames01.shape
+    n = N if ids is None else ids.numel()
+    assert ids is None or (ids.dtype == torch.int32 and ids.is_cuda)
+    if out is None:
+        out = torch.empty(n, H, W, 4, dtype=torch.float32, device=frames01.device)
+    o4, oN, oH, oW, oC, ldo = _as_map(out)
+    assert (oN, oH, oW) == (n, H, W) and oC >= 4
+    check(_lib.lib().fgt_pack_frames(_ptr(frames01), _ptr(masks), C.c_void_p(0 if ids is None else ids.data_ptr()), n, H, W, _ptr(o4), ldo,
+                                     _stream()), "fgt_pack_frames")
+    return out
+
+
+def norm_flows(flows, n_out=None):
+    """fgt_norm_flows on [..., n, C, H, W] (leading dims of size 1 allowed): every (frame, channel) map divided by its signed
+    maximum (tool/video_inpainting.py:402-407); n_out = n + 1 also duplicates the last flow (:705)."""
+    _require_dev(flows)
+    lead = flows.shape[:-4]
+    assert all(d == 1 for d in lead), "norm_flows: one clip at a time"
+    f = flows.reshape(flows.shape[-4:]).contiguous()
+    n, Cc, H, W = f.shape
+    n_out = n if n_out is None else n_out
+    out = torch.empty((n_out, Cc, H, W), dtype=torch.float32, device=f.device)
+    check(_lib.lib().fgt_norm_flows(_ptr(f), n, n_out, Cc, H * W, _ptr(out), _stream()), "fgt_norm_flows")
+    return out.view(*lead, n_out, Cc, H, W)
+
+
+def gather_rows(src, ids, out=None):
+    """out[i] = src[ids[i]] over the leading dimension (ids: int32 device tensor); src[j] must be contiguous."""
+    _require_dev(src, out)
+    assert ids.dtype == torch.int32 and ids.is_cuda and src[0].is_contiguous()
+    n, row = ids.numel(), src[0].numel()
+    if out is None:
+        out = torch.empty((n,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    assert out.shape[0] == n and out[0].is_contiguous() and out[0].numel() == row
+    check(_lib.lib().fgt_gather_rows(_ptr(src), src.stride(0), C.c_void_p(ids.data_ptr()), n, row, _ptr(out), out.stride(0), _stream()),
+          "fgt_gather_rows")
     return out
 
 

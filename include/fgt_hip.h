@@ -2,7 +2,9 @@
  * fgt_hip.h — C ABI of libfgt_hip.so, the MI355X (gfx950) hot path of hitachinsk/FGT.
  *
  * Every entry point takes raw device pointers (fp32 unless noted), plain ints and the HIP stream
- * (as void*) to enqueue on.  Nothing here allocates, synchronises or touches global state.
+ * (as void*) to enqueue on.  No entry point synchronises; the only memory the library owns is one 256-byte zero page per
+ * device (target of out-of-image gathers), allocated by fgt_init(device) — call it once per device before the first launch
+ * and outside stream capture (fgt_amd/_lib.py does so when it loads the library).
  * Return value: 0 on success, a negative FGT_E* code on a rejected argument or a failed launch
  * (never throws across the ABI).  `fgt_last_error()` returns a static description of the last
  * failure on the calling thread.
@@ -41,6 +43,9 @@ extern "C" {
 
 const char* fgt_last_error(void);
 int fgt_abi_version(void);
+/* Allocates (once, thread-safe) the zero page of `device` (-1: the current device).  Every launcher also calls it lazily for
+ * its current device, so forgetting it is only illegal inside a stream capture (hipMalloc cannot be captured). */
+int fgt_init(int device);
 
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
@@ -246,6 +251,22 @@ int fgt_axpby(const float* a, int lda, float sa, const float* b, int ldb, float 
  * frames01 [N,3,H,W], masks [N,1,H,W], comp [N,H,W,3] fp32. */
 int fgt_compose_blend(const float* out_nchw, const int* ids, const int* first, int n, const float* frames01,
                       const float* masks, int H, int W, float* comp, void* stream);
+
+/* Input packing of the clip-level FGT stage in one pass (tool/video_inpainting.py:697 `frames*2-1`, :719-721
+ * `selected_frames * (1 - selected_masks)`, FGT/models/model.py:253-257 `cat(masked_frames, masks)` + NCHW -> channels-last):
+ *   dst[i, y, x, 0:3] = (frames01[f, :, y, x] * 2 - 1) * (1 - masks[f, 0, y, x]),  dst[i, y, x, 3] = masks[f, 0, y, x],
+ * f = ids[i] (device int32) or i when ids == NULL.  frames01 [N,3,H,W], masks [N,1,H,W], dst [n,H,W,ldd >= 4]. */
+int fgt_pack_frames(const float* frames01, const float* masks, const int* ids, int n, int H, int W, float* dst, int ldd,
+                    void* stream);
+
+/* norm_flows (tool/video_inpainting.py:402-407; FGT/networks/network.py:80-84): every (frame, channel) map divided by its SIGNED
+ * maximum over H*W.  flows [n_src, C, HW] -> out [n_out, C, HW]; output frame i reads source frame min(i, n_src - 1), which is
+ * the tool's duplication of the last forward flow to the clip length (:705) when n_out = n_src + 1.  Bit-exact (max, IEEE divide). */
+int fgt_norm_flows(const float* flows, int n_src, int n_out, int C, long HW, float* out, void* stream);
+
+/* Row gather dst[i, 0:row_len] = src[ids[i], 0:row_len] (ids: device int32): a window's frames out of the per-frame feature
+ * buffers — `tensor[:, neighbor_ids + ref_ids]` of tool/video_inpainting.py:718-722 applied to cached features.  row_len % 4 == 0. */
+int fgt_gather_rows(const float* src, long ld_src, const int* ids, int n, long row_len, float* dst, long ld_dst, void* stream);
 
 /* Laplace ("diffusion") fill of the masked pixels of B scalar H x W maps (flow channels), all maps at once, by conjugate
  * gradients on the masked 5-point stencil:  n(p) x(p) - sum_{masked 4-neighbours} x(q) = sum_{unmasked in-image 4-neighbours} I(q),
