@@ -61,6 +61,8 @@ SIGNATURES = {
     "fgt_instnorm_apply": [_P, _I, _I, _I, _I, _P, _F, _I, _P, _I, _I, _P, _I, _P],
     "fgt_axpby": [_P, _I, _F, _P, _I, _F, _L, _I, _I, _F, _P, _I, _P],
     "fgt_compose_blend": [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P],
+    "fgt_compose_blend_u8": [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P],
+    "fgt_quantize_u8": [_P, _L, _P, _P],
     "fgt_pack_frames": [_P, _P, _P, _I, _I, _I, _P, _I, _P],
     "fgt_norm_flows": [_P, _I, _I, _I, _L, _P, _P],
     "fgt_gather_rows": [_P, _L, _P, _I, _L, _P, _L, _P],

@@ -274,8 +274,13 @@ __global__ void __launch_bounds__(256) axpby_kernel(const float* a, int lda, flo
     }
 }
 
-// tool/video_inpainting.py:725-740
-__global__ void __launch_bounds__(256) compose_kernel(const float* out_nchw, const int* ids, const int* first, int n,
+// tool/video_inpainting.py:725-740.  U8 = false: `out` is the model output (fp32 NCHW, (-1,1)); U8 = true: `out` already holds
+// astype(uint8)((x+1)/2*255), the form the window outputs are exchanged in between ranks (a quarter of the bytes; the truncation
+// is the first thing the compose does with the value, :731-733, so it commutes with the exchange).
+__device__ __forceinline__ float trunc_u8(float o) { return (float)(unsigned char)(int)(((o + 1.f) / 2.f) * 255.f); }
+
+template <bool U8>
+__global__ void __launch_bounds__(256) compose_kernel(const void* out_any, const int* ids, const int* first, int n,
                                                       const float* frames01, const float* masks, int H, int W, float* comp) {
     const long HW = (long)H * W, total = (long)n * HW;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -283,14 +288,21 @@ __global__ void __launch_bounds__(256) compose_kernel(const float* out_nchw, con
         const int fid = ids[i];
         const float m = masks[(long)fid * HW + rem];
         for (int c = 0; c < 3; ++c) {
-            const float o = out_nchw[((long)i * 3 + c) * HW + rem];
-            const float filled = ((o + 1.f) / 2.f) * 255.f;
-            const float fu = (float)(unsigned char)(int)filled;                         // astype(uint8): truncation
+            const long o = ((long)i * 3 + c) * HW + rem;
+            const float fu = U8 ? (float)static_cast<const unsigned char*>(out_any)[o]
+                                : trunc_u8(static_cast<const float*>(out_any)[o]);          // astype(uint8): truncation
             const float vu = (float)(unsigned char)(int)(frames01[((long)fid * 3 + c) * HW + rem] * 255.0f);
             const float cv = fu * m + vu * (1.f - m);
             float* dst = comp + ((long)fid * HW + rem) * 3 + c;
             *dst = first[i] ? cv : (*dst * 0.5f + cv * 0.5f);
         }
+    }
+}
+
+__global__ void __launch_bounds__(256) quantize_u8_kernel(const float* __restrict__ x, long n4, unsigned* __restrict__ dst) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        dst[i] = (unsigned)trunc_u8(v.x) | ((unsigned)trunc_u8(v.y) << 8) | ((unsigned)trunc_u8(v.z) << 16) | ((unsigned)trunc_u8(v.w) << 24);
     }
 }
 
@@ -442,9 +454,25 @@ extern "C" int fgt_axpby(const float* a, int lda, float sa, const float* b, int 
 extern "C" int fgt_compose_blend(const float* out_nchw, const int* ids, const int* first, int n, const float* frames01,
                                  const float* masks, int H, int W, float* comp, void* stream) {
     FGT_REQUIRE(out_nchw && ids && first && frames01 && masks && comp && n > 0, "fgt_compose_blend: bad arguments");
-    hipLaunchKernelGGL(compose_kernel, dim3(grid_for((long)n * H * W)), dim3(256), 0, (hipStream_t)stream, out_nchw, ids, first, n,
+    hipLaunchKernelGGL(compose_kernel<false>, dim3(grid_for((long)n * H * W)), dim3(256), 0, (hipStream_t)stream, out_nchw, ids, first, n,
                        frames01, masks, H, W, comp);
     return fgt_check_launch("compose_blend");
+}
+
+extern "C" int fgt_compose_blend_u8(const unsigned char* filled_u8, const int* ids, const int* first, int n, const float* frames01,
+                                    const float* masks, int H, int W, float* comp, void* stream) {
+    FGT_REQUIRE(filled_u8 && ids && first && frames01 && masks && comp && n > 0, "fgt_compose_blend_u8: bad arguments");
+    hipLaunchKernelGGL(compose_kernel<true>, dim3(grid_for((long)n * H * W)), dim3(256), 0, (hipStream_t)stream, filled_u8, ids, first, n,
+                       frames01, masks, H, W, comp);
+    return fgt_check_launch("compose_blend_u8");
+}
+
+extern "C" int fgt_quantize_u8(const float* x, long count, unsigned char* dst, void* stream) {
+    FGT_REQUIRE(x && dst && count > 0 && count % 4 == 0 && (((uintptr_t)x & 15) | ((uintptr_t)dst & 3)) == 0,
+                "fgt_quantize_u8: count must be a multiple of 4 and the pointers 16- / 4-byte aligned");
+    hipLaunchKernelGGL(quantize_u8_kernel, dim3(grid_for(count / 4)), dim3(256), 0, (hipStream_t)stream, x, count / 4,
+                       reinterpret_cast<unsigned*>(dst));
+    return fgt_check_launch("quantize_u8");
 }
 
 extern "C" int fgt_pack_frames(const float* frames01, const float* masks, const int* ids, int n, int H, int W, float* dst, int ldd,

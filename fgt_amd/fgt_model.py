@@ -5,7 +5,7 @@ has the constructor keys, forward signature and state_dict keys of FGT/models/mo
 reference's `Model`), so `tool/video_inpainting.py:217-230,724` can import it unchanged.
 
 The nn.Module tree below only *holds parameters* under the reference's names; no torch operator runs on
-activations.  `forward` drives libfgt_hip.so (fgt_amd/ops.py): fp32-MFMA implicit-GEMM convolutions and
+activations (tensor creation, views and slices only).  `forward` drives libfgt_hip.so (fgt_amd/ops.py): implicit-GEMM convolutions and
 projections, flash attention with the zone/window gathers folded into addressing, fused LN / fold kernels.
 """
 import math
@@ -328,7 +328,13 @@ class FGT(nn.Module):
         return self._ffn(y, x, P["ffn"], bt, th, tw, Hf, Wf)
 
     def _spatial(self, x, f, P, bt, th, tw, Hf, Wf):
-        """FGT/models/model.py:144-149 + attention_flow.py:57-113, global tokens projected once per frame."""
+        """FGT/models/model.py:144-149: x + attention, then x + FFN(LN(x))."""
+        x = self._spatial_attention(x, f, P, bt, th, tw)
+        y = ops.layernorm(x, *P["n"], splitA=self._split_chain())
+        return self._ffn(y, x, P["ffn"], bt, th, tw, Hf, Wf)
+
+    def _spatial_attention(self, x, f, P, bt, th, tw):
+        """x + SWMHSA(x, f)  (model.py:145 + attention_flow.py:57-113), global tokens projected once per frame."""
         cfg = self.cfg
         ws, gd, c, cf = cfg["ws"], cfg["gd"], cfg["c"], cfg["cf"]
         pad_r, pad_b = (ws - tw % ws) % ws, (ws - th % ws) % ws
@@ -357,29 +363,42 @@ class FGT(nn.Module):
         kk = ops.linear(kin, P["k"])
         vv = ops.linear(vin, P["v"])
         a = ops.attention_spatial(q, kk[:rows], vv[:rows], kk[rows:], vv[rows:], bt, th, tw, nh, nw, cfg["heads"], ws, ng, out_split=sc)
-        x = ops.linear(a, P["out"], epi="add", aux1=x)
-        y = ops.layernorm(x, *P["n"], splitA=sc)
-        return self._ffn(y, x, P["ffn"], bt, th, tw, Hf, Wf)
+        return ops.linear(a, P["out"], epi="add", aux1=x)
 
     # ---- per-frame stages (exposed separately so the clip scheduler can cache them) -------------
-    def encode_frames(self, masked_frames, flows, masks):
-        """model.py:253-262: returns (enc_feats [bt,Hf,Wf,2cnum], tokens [bt*n,c], flow tokens [bt*n,cf], th, tw)."""
+    def token_grid(self, H, W):
+        """(th, tw) of an H x W input: soft split of the H/4 x W/4 feature map (model.py:218-228 for the configured resolution)."""
+        cfg = self.cfg
+        return tuple((n // 4 + 2 * cfg["p"][i] - cfg["k"][i]) // cfg["s"][i] + 1 for i, n in enumerate((H, W)))
+
+    def encode_frames(self, masked_frames=None, flows=None, masks=None, packed_in=None, out=None):
+        """model.py:253-262: returns (enc_feats [bt,Hf,Wf,2cnum], tokens [bt*n,c], flow tokens [bt*n,cf], th, tw).
+        packed_in = (x_in [bt,H,W,4], f_in [bt,H,W,4]): channels-last inputs already packed on device (ops.pack_frames /
+        ops.nchw_to_nhwc; the clip scheduler's path) instead of the three NCHW tensors of the nn.Module API;
+        out = (enc, tok, ftok): preallocated destinations (slices of the clip's feature buffers) written in place."""
         P = self.packed()
         cfg = self.cfg
-        b, t, _, H, W = masked_frames.shape
-        if H % 4 or W % 4:
-            raise ValueError(f"FGT needs H, W divisible by 4, got {H}x{W}")
-        bt = b * t
-        dev = masked_frames.device
-        cin = ops.ceil_to(self.in_channels, 4)
-        x_in = torch.empty(bt, H, W, cin, dtype=torch.float32, device=dev)
-        ops.nchw_to_nhwc(masked_frames.reshape(bt, 3, H, W).float(), x_in, coff=0,
-                         zero_to=cin if not self.passmask else 0)
-        if self.passmask:
-            ops.nchw_to_nhwc(masks.reshape(bt, 1, H, W).float(), x_in, coff=3, zero_to=cin - 3)
-        fin = ops.ceil_to(cfg["flow_in"], 4)
-        f_in = torch.empty(bt, H, W, fin, dtype=torch.float32, device=dev)
-        ops.nchw_to_nhwc(flows.reshape(bt, cfg["flow_in"], H, W).float(), f_in, coff=0, zero_to=fin)
+        if packed_in is None:
+            b, t, _, H, W = masked_frames.shape
+            if H % 4 or W % 4:
+                raise ValueError(f"FGT needs H, W divisible by 4, got {H}x{W}")
+            bt = b * t
+            dev = masked_frames.device
+            cin = ops.ceil_to(self.in_channels, 4)
+            x_in = torch.empty(bt, H, W, cin, dtype=torch.float32, device=dev)
+            ops.nchw_to_nhwc(masked_frames.reshape(bt, 3, H, W).float(), x_in, coff=0,
+                             zero_to=cin if not self.passmask else 0)
+            if self.passmask:
+                ops.nchw_to_nhwc(masks.reshape(bt, 1, H, W).float(), x_in, coff=3, zero_to=cin - 3)
+            fin = ops.ceil_to(cfg["flow_in"], 4)
+            f_in = torch.empty(bt, H, W, fin, dtype=torch.float32, device=dev)
+            ops.nchw_to_nhwc(flows.reshape(bt, cfg["flow_in"], H, W).float(), f_in, coff=0, zero_to=fin)
+        else:
+            x_in, f_in = packed_in
+            bt, H, W, _ = x_in.shape
+            assert self.passmask and self.in_channels == 4, "packed inputs carry (masked frame | mask)"
+        th, tw = self.token_grid(H, W)
+        o_enc, o_tok, o_ftok = out if out is not None else (None, None, None)
         E = P["enc"]
         strides = [sp[2] for sp in EncoderParams.SPEC]
         sc = "only" if self._split_chain() else None
@@ -389,10 +408,11 @@ class FGT(nn.Module):
             if i == 4:
                 x0 = e                                                         # model.py:58-59
             osp = ("both" if sc else None) if i == 8 else sc                   # the last layer also feeds fold()'s fp32 residual
+            dst = o_enc if i == 8 else None
             if i <= 4:
-                e = ops.conv2d(e, E[i], stride=strides[i], pad=1, act="lrelu", out_split=osp)
+                e = ops.conv2d(e, E[i], stride=strides[i], pad=1, act="lrelu", out_split=osp, out=dst)
             else:
-                e = ops.conv2d(x0, E[i], x1=e, stride=1, pad=1, act="lrelu", out_split=osp)    # grouped concat, model.py:60-65
+                e = ops.conv2d(x0, E[i], x1=e, stride=1, pad=1, act="lrelu", out_split=osp, out=dst)    # grouped concat, model.py:60-65
         enc, enc_in = e if sc else (e, e)
         FE = P["fenc"]
         fe = self._block(f_in, FE[0], stride=1, pad=2, pad_mode="replicate", out_split=sc)    # ReplicationPad2d(2) + 5x5 conv
@@ -400,16 +420,16 @@ class FGT(nn.Module):
         fe = self._block(fe, FE[2], stride=1, pad=1, out_split=sc)
         fe = self._block(fe, FE[3], stride=2, pad=1, out_split=sc)
         s, p = cfg["s"][0], cfg["p"][0]
-        tok = ops.conv2d(enc_in, P["p2v"], stride=s, pad=p)
-        ftok = ops.conv2d(fe, P["fp2v"], stride=s, pad=p)
-        th, tw = tok.shape[1], tok.shape[2]
+        tok = ops.conv2d(enc_in, P["p2v"], stride=s, pad=p, out=None if o_tok is None else o_tok.view(bt, th, tw, -1))
+        ftok = ops.conv2d(fe, P["fp2v"], stride=s, pad=p, out=None if o_ftok is None else o_ftok.view(bt, th, tw, -1))
+        assert (tok.shape[1], tok.shape[2]) == (th, tw)
         return enc, tok.view(bt * th * tw, -1), ftok.view(bt * th * tw, -1), th, tw
 
     def transform_decode(self, enc, x, f, b, t, th, tw, n_out=None, keep=None):
         """model.py:272-283 given per-frame features.  Soft composition + decoder run only for the frames whose output is
         consumed — the tool discards the decoded reference frames (tool/video_inpainting.py:727: only
         `range(len(neighbor_ids))` is read) and both stages are per-frame, so the kept frames are unchanged:
-        `n_out` (b == 1): the first n_out frames; `keep` (any b): an int64 device tensor of frame indices in [0, b*t)."""
+        `n_out` (b == 1): the first n_out frames; `keep` (any b): an int32 device tensor of frame indices in [0, b*t)."""
         P = self.packed()
         cfg = self.cfg
         bt = b * t
@@ -423,8 +443,8 @@ class FGT(nn.Module):
             x = self._spatial(x, f, ps, bt, th, tw, Hf, Wf)
         if keep is not None:
             assert n_out is None
-            x = x.view(bt, th * tw, -1).index_select(0, keep).view(keep.numel() * th * tw, -1)
-            enc = enc.index_select(0, keep)
+            x = ops.gather_rows(x.view(bt, th * tw, -1), keep).view(keep.numel() * th * tw, -1)
+            enc = ops.gather_rows(enc, keep)
             bt = keep.numel()
         elif n_out is not None and n_out < bt:
             assert b == 1, "n_out needs a single clip (frames of one batch element are contiguous); use keep= for b > 1"

@@ -5,6 +5,12 @@ costs 5-15 us each, which bounds the step once the kernels are fast.  `GraphedCa
 stream (weight packing, tile autotuning — both need to happen outside capture), captures it into a hipGraph on static
 input/output buffers and replays it.  Every libfgt_hip.so entry point only enqueues on the current stream, allocates
 nothing and never synchronises, so it is capture-safe; scratch tensors come from torch's graph-private pool.
+
+A captured graph bakes in everything that is not a static input: the packed-weight images' addresses and contents' version,
+the arithmetic mode (`ops.DEFAULT_*_PRECISION`) and the weight-image layout.  `GraphCache` therefore keys its graphs on
+(input shapes, `state_key()`), where `state_key` is supplied by the owner (the model's (data_ptr, version) tuple) and
+`ops.mode_key()` is always included: a `load_state_dict`, an in-place weight update or a precision switch re-captures instead
+of silently replaying the old weights.
 """
 import torch
 
@@ -40,13 +46,19 @@ class GraphedCall:
 
 
 class GraphCache:
-    """One GraphedCall per input-shape signature."""
+    """One GraphedCall per (input-shape signature, weights / arithmetic state).  Graphs of a stale state are dropped."""
 
-    def __init__(self, fn):
+    def __init__(self, fn, state_key=None):
         self.fn = fn
+        self.state_key = state_key or (lambda: ())
         self.cache = {}
+        self._state = None
 
     def __call__(self, *inputs):
+        state = (ops.mode_key(), self.state_key())
+        if state != self._state:                     # weights repacked / precision switched: every captured graph is stale
+            self.cache.clear()
+            self._state = state
         key = tuple((tuple(x.shape), x.dtype) for x in inputs)
         g = self.cache.get(key)
         if g is None:

@@ -150,7 +150,8 @@ class P3DNet(nn.Module):
             if self.use_graph and edges is None and flows.is_cuda:
                 from .graph import GraphCache
                 if self._graphs is None:
-                    self._graphs = GraphCache(lambda a, b: self._forward(a, b, None))
+                    self._graphs = GraphCache(lambda a, b: self._forward(a, b, None),
+                                              state_key=lambda: tuple((p.data_ptr(), p._version) for p in self.parameters()))
                 return tuple(o.clone() for o in self._graphs(flows.float(), masks.float()))
             return self._forward(flows, masks, edges)
 

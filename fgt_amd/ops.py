@@ -26,6 +26,11 @@ TILE_CANDIDATES = ("128x128", "64x64", "128x64", "256x128", "128x32", "128x128x8
 _tile_cache = {}
 
 
+def mode_key():
+    """Everything outside the tensors that changes what a launch sequence computes: graph caches key on it (fgt_amd/graph.py)."""
+    return (DEFAULT_CONV_PRECISION, DEFAULT_ATTN_PRECISION, WEIGHTS_INTERLEAVED)
+
+
 def tuning_table():
     return {repr(k): v for k, v in _tile_cache.items()}
 
@@ -579,6 +584,27 @@ def compose_blend(out_nchw, ids, first, frames01, masks, comp):
     H, W = out_nchw.shape[-2:]
     check(_lib.lib().fgt_compose_blend(_ptr(out_nchw.contiguous()), C.c_void_p(ids.data_ptr()), C.c_void_p(first.data_ptr()), n,
                                        _ptr(frames01), _ptr(masks), H, W, _ptr(comp), _stream()), "fgt_compose_blend")
+    return comp
+
+
+def quantize_u8(x, out=None):
+    """fgt_quantize_u8: fp32 values in (-1,1) -> uint8 astype(uint8)((x+1)/2*255) (tool/video_inpainting.py:725-726,731)."""
+    _require_dev(x)
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() == x.numel()
+    check(_lib.lib().fgt_quantize_u8(_ptr(x), x.numel(), C.c_void_p(out.data_ptr()), _stream()), "fgt_quantize_u8")
+    return out
+
+
+def compose_blend_u8(filled_u8, ids, first, frames01, masks, comp):
+    _require_dev(frames01, masks, comp)
+    assert filled_u8.dtype == torch.uint8 and filled_u8.is_cuda and filled_u8.is_contiguous()
+    n = ids.numel()
+    H, W = filled_u8.shape[-2:]
+    check(_lib.lib().fgt_compose_blend_u8(C.c_void_p(filled_u8.data_ptr()), C.c_void_p(ids.data_ptr()), C.c_void_p(first.data_ptr()), n,
+                                          _ptr(frames01), _ptr(masks), H, W, _ptr(comp), _stream()), "fgt_compose_blend_u8")
     return comp
 
 

@@ -179,7 +179,8 @@ class RAFT(nn.Module):
                 from .graph import GraphCache
                 key = (iters, bool(test_mode))
                 if key not in self._graphs:
-                    self._graphs[key] = GraphCache(lambda a, b: self._forward(a, b, iters, None, test_mode))
+                    self._graphs[key] = GraphCache(lambda a, b: self._forward(a, b, iters, None, test_mode),
+                                                   state_key=lambda: tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers())))
                 out = self._graphs[key](image1.float(), image2.float())
                 return tuple(o.clone() for o in out) if isinstance(out, tuple) else [o.clone() for o in out]
             return self._forward(image1, image2, iters, flow_init, test_mode)

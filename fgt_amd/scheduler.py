@@ -1,6 +1,7 @@
 """Clip-level host logic of the FGT stage (tool/video_inpainting.py:687-748) for the MI355X path.
 
 * `window_schedule`  — the reference's sliding window + reference-frame selection (:103-117, :710-717).
+* `prepare_flows`    — norm_flows + duplication of the last forward flow (:402-407, :703-707) on device.
 * `ClipRunner`       — keeps the clip resident in HBM, runs every window through the HIP model, composes and
                        blends on device in ascending window order (the blend is order dependent, :731-740), and
                        returns the composited clip once (one D2H instead of one per window).
@@ -8,10 +9,13 @@
                        window the frame appears in; windows gather their frames' features (exact).
 * window batching    — windows of equal length are independent batch elements of the model: up to `window_batch` of them run
                        as one forward (bit-identical outputs, larger launches).
-* window sharding    — windows are independent: rank r takes windows r, r+W, ...; frames are block-sharded
-                       for the per-frame stages (one all-gather of the features), the per-window outputs are exchanged with ONE
-                       all-gather (RCCL over xGMI on the GPU box, gloo in the CPU tests) and every rank applies the ordered
-                       blend locally.
+* window sharding    — windows are independent.  `assign_windows` gives every rank a cost-balanced set in which
+                       equal-length windows are co-located (so they batch); frames are block-sharded for the per-frame stages and
+                       their features all-gathered chunk by chunk while the next chunk is being encoded; the per-window outputs
+                       are exchanged ALREADY TRUNCATED to uint8 (the first thing the compose does with them) in one all-gather of
+                       preallocated buffers, and every rank applies the ordered blend locally.  RCCL over xGMI on the GPU box,
+                       gloo in the CPU tests.  Nothing on the GPU path of a step allocates exchange buffers or runs a torch
+                       operator on activations: packing, gathers, truncation and compose are libfgt_hip.so kernels.
 
 The per-rank model call is injectable (`forward=`) so the scheduling / sharding / blend logic is testable on CPU
 with the oracle standing in for the device model (tests/test_scheduler.py, tests/test_scheduler_cache.py).
@@ -41,45 +45,97 @@ def window_schedule(n_frames, neighbor_stride=5, ref_length=10, num_ref=-1):
     return sched
 
 
-def shard_windows(n_windows, rank, world):
-    """Round-robin assignment: consecutive windows have near-equal cost (t = 17/18), so this balances ranks."""
-    return list(range(rank, n_windows, world))
+def prepare_flows(forward_flows):
+    """tool/video_inpainting.py:703-707: `videoFlowF` [N-1,2,H,W] (completed forward flows, device fp32) -> the model's flow input
+    [1,N,2,H,W]: last flow duplicated to the clip length, every (frame, channel) map divided by its signed maximum."""
+    return ops.norm_flows(forward_flows, n_out=forward_flows.shape[0] + 1).unsqueeze(0)
 
 
-def all_gather(out, buf, group=None):
-    """all_gather_into_tensor; RCCL works on device buffers directly.  The gloo backend (CPU tests, and the 2-ranks-on-one-GPU
-    rehearsal of the sharded path on a single-GPU box) cannot gather device tensors, so it is staged through host memory."""
+def window_cost(t, n_nb):
+    """Relative cost of one window on the feature-cache path (GFLOP at 240x432): the transformer blocks on all
+    t frames (4 x (TMHSA 1.51 + SWMHSA 4.19) + 8 x FFN 2.89 per frame, temporal attention 1.0618 t^2) and soft composition +
+    decoder on the n_nb consumed frames (4.62 + 19.47)."""
+    return 45.9 * t + 1.0618 * t * t + 24.1 * n_nb
+
+
+def assign_windows(sched, world):
+    """Partition the window indices over `world` ranks: [[window ids of rank 0], ...], each ascending.
+    Equal-length windows are packed together (a rank runs them as ONE batched forward), packs are placed longest-first on
+    the least-loaded rank (LPT).  80 frames / 8 ranks: 4 x (17,17), 3 x (18,18), (18,13): makespan 36 frame-units against
+    275/8 = 34.4 ideal, every rank but one batches its two windows."""
+    n = len(sched)
+    quota = -(-n // world)
+    by_t = {}
+    for wi, (nb, ref) in enumerate(sched):
+        by_t.setdefault(len(nb) + len(ref), []).append(wi)
+    packs = []
+    for t, ws in by_t.items():
+        for i in range(0, len(ws), quota):
+            pack = ws[i:i + quota]
+            packs.append((sum(window_cost(t, len(sched[w][0])) for w in pack), pack))
+    packs.sort(key=lambda p: (-p[0], p[1][0]))
+    load, out = [0.0] * world, [[] for _ in range(world)]
+    for cost, pack in packs:
+        r = min(range(world), key=lambda i: (load[i], i))
+        load[r] += cost
+        out[r] += pack
+    return [sorted(ws) for ws in out]
+
+
+def ideal_speedup(sched, world):
+    """Upper bound of the sharded window phase's speed-up given the assignment (total cost / most loaded rank)."""
+    cost = lambda ws: sum(window_cost(len(sched[w][0]) + len(sched[w][1]), len(sched[w][0])) for w in ws)
+    parts = assign_windows(sched, world)
+    return cost(range(len(sched))) / max(cost(p) for p in parts)
+
+
+def needs_host_staging(is_cuda, backend):
+    """RCCL ("nccl" IS RCCL on ROCm) gathers device buffers directly over xGMI; gloo cannot touch device memory."""
+    return bool(is_cuda) and backend != "nccl"
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def all_gather(out, buf, group=None, async_op=False):
+    """all_gather_into_tensor.  Returns a work handle (`.wait()` makes the current stream wait for the result).
+    The gloo backend (CPU tests, and the 2-ranks-on-one-GPU rehearsal of the sharded path on a single-GPU box) cannot gather
+    device tensors, so there the call is staged through host memory (synchronously)."""
     import torch.distributed as dist
-    if buf.is_cuda and dist.get_backend(group) != "nccl":
+    if needs_host_staging(buf.is_cuda, dist.get_backend(group)):
         host = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(host, buf.cpu(), group=group)
         out.copy_(host)
-    else:
-        dist.all_gather_into_tensor(out, buf, group=group)
-    return out
+        return _Done()
+    work = dist.all_gather_into_tensor(out, buf, group=group, async_op=async_op)
+    return work if async_op else _Done()
 
 
 def compose_torch(out, nb, frames01, masks, comp, visited):
-    """Reference compose/blend restated with torch ops (CPU path used only by the CPU tests)."""
-    filled = ((out + 1) / 2).permute(0, 2, 3, 1) * 255
+    """Reference compose/blend restated with torch ops (CPU path used only by the CPU tests).  `out`: model output (fp32) or
+    its uint8 truncation."""
+    filled = out.permute(0, 2, 3, 1).float() if out.dtype == torch.uint8 else (((out + 1) / 2).permute(0, 2, 3, 1) * 255).to(torch.uint8).float()
     for i, idx in enumerate(nb):
         valid = (frames01[0, idx].permute(1, 2, 0) * 255.0).to(torch.uint8).float()
         m = masks[0, idx].permute(1, 2, 0)
-        c = filled[i].to(torch.uint8).float() * m + valid * (1 - m)
+        c = filled[i] * m + valid * (1 - m)
         comp[idx] = c if not visited[idx] else comp[idx] * 0.5 + c * 0.5
         visited[idx] = True
 
 
 class ClipRunner:
     def __init__(self, model, frames01, flows_normed, masks, neighbor_stride=5, ref_length=10, num_ref=-1,
-                 rank=0, world=1, forward=None, group=None, cache_features=None, encode_chunk=20, use_graphs=None, window_batch=8):
+                 rank=0, world=1, forward=None, group=None, cache_features=None, encode_chunk=20, use_graphs=False, window_batch=8):
         self.model = model
         self.frames01, self.flows, self.masks = frames01, flows_normed, masks
         self.n = frames01.shape[1]
         self.H, self.W = frames01.shape[-2:]
         self.sched = window_schedule(self.n, neighbor_stride, ref_length, num_ref)
         self.rank, self.world, self.group = rank, world, group
-        self.mine = shard_windows(len(self.sched), rank, world)
+        self.assign = assign_windows(self.sched, world)
+        self.mine = self.assign[rank]
         self.forward = forward or (lambda mf, fl, ms: model(mf, fl, ms))
         self.dev = frames01.device
         self.on_gpu = self.dev.type == "cuda"
@@ -92,17 +148,17 @@ class ClipRunner:
             self._first.append(torch.tensor([0 if i in seen else 1 for i in nb], dtype=torch.int32, device=self.dev))
             seen.update(nb)
         self._nb = [torch.tensor(nb, dtype=torch.int32, device=self.dev) for nb, _ in self.sched]
-        self.normed = frames01 * 2 - 1                       # tool/video_inpainting.py:697
+        self._normed = None
         # Exact dedup: the conv encoders / soft split depend only on the frame, yet the reference
         # recomputes them for every window a frame appears in (275 frame passes for 80 frames).  With the cache each
-        # frame is encoded once per clip pass (frames sharded over ranks + one all-gather), windows only run the
+        # frame is encoded once per clip pass (frames sharded over ranks + all-gathers), windows only run the
         # transformer + decoder.  Needs a model exposing encode_frames / transform_decode (fgt_amd.fgt_model.FGT).
         net = getattr(model, "net", None)
         can_cache = forward is None and hasattr(net, "encode_frames")
         self.cache_features = can_cache if cache_features is None else (cache_features and can_cache)
-        self.encode_chunk = encode_chunk
-        # hipGraph replay of the per-window launch sequence (one graph per window length t), only with the feature cache
-        self.use_graphs = (self.on_gpu and self.cache_features) if use_graphs is None else (use_graphs and self.on_gpu and self.cache_features)
+        self.encode_chunk = max(1, int(encode_chunk))
+        # hipGraph replay of the per-window launch sequence (one graph per window length t), only with the feature cache; opt-in
+        self.use_graphs = bool(use_graphs) and self.on_gpu and self.cache_features
         self._graphs = None
         # Window batching (feature-cache path): windows of equal length t are independent batch elements of the reference model
         # (b > 1: every stage is per frame or per (b, zone)), so up to `window_batch` of this rank's windows go through the
@@ -117,13 +173,33 @@ class ClipRunner:
         for t, ws in sorted(by_t.items()):
             nb = min(self.window_batch, self._max_batch(t))
             self.groups += [ws[i:i + nb] for i in range(0, len(ws), nb)]
+        # ---- frame sharding of the per-frame stages: rank r encodes frames [r*per, (r+1)*per) in `n_chunks` chunks of `ck`;
+        # feature row of frame f in the gathered buffers = _row_of[f] (identity for world == 1).  Ranks whose block is (partly)
+        # past the clip encode nothing there and contribute zero rows, so the collectives stay matched on every rank.
+        self.per = -(-self.n // world)
+        if world > 1:
+            self.n_chunks = 2 if self.per >= 2 else 1             # two chunks: all-gather of chunk 0 overlaps the encode of chunk 1
+            self.ck = -(-self.per // self.n_chunks)
+        else:
+            self.n_chunks, self.ck = -(-self.n // self.encode_chunk), self.encode_chunk
+        self._row_of = list(range(self.n))
+        if world > 1:
+            for f in range(self.n):
+                r, o = divmod(f, self.per)
+                j, i = divmod(o, self.ck)
+                self._row_of[f] = j * world * self.ck + r * self.ck + i
+        self.rows = world * self.ck * self.n_chunks if world > 1 else self.n
         self._group_ids, self._group_keep = [], []
         for ws in self.groups:
             t = len(self.sched[ws[0]][0]) + len(self.sched[ws[0]][1])
-            self._group_ids.append(torch.cat([self._ids[wi] for wi in ws]))
+            self._group_ids.append(torch.tensor([self._row_of[f] for wi in ws for f in self.sched[wi][0] + self.sched[wi][1]],
+                                                dtype=torch.int32, device=self.dev))
             self._group_keep.append(torch.tensor([j * t + i for j, wi in enumerate(ws) for i in range(len(self.sched[wi][0]))],
-                                                 dtype=torch.int64, device=self.dev))
+                                                 dtype=torch.int32, device=self.dev))
+        self._feat = None          # persistent feature buffers (enc, tok, ftok, th, tw) + local chunk buffers
+        self._xchg = None          # persistent uint8 exchange buffers
 
+    # ---------------------------------------------------------------------------------------------------------------------
     def _max_batch(self, t):
         """Largest window batch whose spatial attention still fits one launch: fgt_attention maps one (frame, window, head)
         problem to a grid.y index (<= 65535)."""
@@ -136,41 +212,64 @@ class ClipRunner:
         return max(1, 65535 // (t * per_frame))
 
     def run_window(self, wi):
+        """One window exactly like the tool calls the model (:718-724): torch indexing on the caller's side of the nn.Module API."""
+        if self._normed is None:
+            self._normed = self.frames01 * 2 - 1                 # tool/video_inpainting.py:697
         ids = self._ids[wi]
         m = self.masks[:, ids]
-        mf = self.normed[:, ids] * (1 - m)                   # :721
+        mf = self._normed[:, ids] * (1 - m)                      # :721
         return self.forward(mf, self.flows[:, ids], m)[: len(self.sched[wi][0])]
 
-    def encode_clip(self):
-        """Per-frame stages for the whole clip: (enc [N,Hf,Wf,C], tokens [N,n,c], flow tokens [N,n,cf], th, tw)."""
+    # ---------------------------------------------------------------------------------------------------------------------
+    def _feature_buffers(self):
+        if self._feat is None:
+            net = self.model.net
+            Hf, Wf = self.H // 4, self.W // 4
+            th, tw = net.token_grid(self.H, self.W)
+            C, c, cf = net.cfg["cnum"] * 2, net.cfg["c"], net.cfg["cf"]
+            new = lambda rows, *s: torch.zeros(rows, *s, dtype=torch.float32, device=self.dev)
+            full = (new(self.rows, Hf, Wf, C), new(self.rows, th * tw, c), new(self.rows, th * tw, cf))
+            local = [tuple(new(self.ck, *b.shape[1:]) for b in full) for _ in range(self.n_chunks)] if self.world > 1 else None
+            self._feat = (full, local, th, tw)
+        return self._feat
+
+    def _encode_chunk(self, s0, s1, dst):
+        """Per-frame stages for frames [s0, s1) written into dst = (enc, tok, ftok) row slices."""
         net = self.model.net
-        per = (self.n + self.world - 1) // self.world
-        lo, hi = min(self.n, self.rank * per), min(self.n, (self.rank + 1) * per)
-        masked = self.normed * (1 - self.masks)
-        parts, th, tw = [], 0, 0
-        for s0 in range(lo, hi, self.encode_chunk):
-            s1 = min(hi, s0 + self.encode_chunk)
-            enc, tok, ftok, th, tw = net.encode_frames(masked[:, s0:s1], self.flows[:, s0:s1], self.masks[:, s0:s1])
-            k = s1 - s0
-            parts.append(torch.cat([enc.reshape(k, -1), tok.reshape(k, -1), ftok.reshape(k, -1)], 1))
+        k = s1 - s0
+        if self.on_gpu:
+            x_in = ops.pack_frames(self.frames01[0, s0:s1], self.masks[0, s0:s1])
+            f_in = torch.empty(k, self.H, self.W, 4, dtype=torch.float32, device=self.dev)
+            ops.nchw_to_nhwc(self.flows[0, s0:s1], f_in, coff=0, zero_to=4)
+            net.encode_frames(packed_in=(x_in, f_in), out=tuple(d[:k] for d in dst))
+        else:       # CPU tests over tests/fake_ops.py: the nn.Module-style call, results copied into the buffers
+            m = self.masks[:, s0:s1]
+            enc, tok, ftok, _, _ = net.encode_frames((self.frames01[:, s0:s1] * 2 - 1) * (1 - m), self.flows[:, s0:s1], m)
+            for d, v in zip(dst, (enc, tok, ftok)):
+                d[:k].copy_(v.reshape(k, *d.shape[1:]))
+
+    def encode_clip(self):
+        """Per-frame stages for the whole clip into the persistent feature buffers:
+        (enc [rows,Hf,Wf,C], tokens [rows,n,c], flow tokens [rows,n,cf], th, tw); frame f lives in row _row_of[f]."""
+        full, local, th, tw = self._feature_buffers()
         if self.world == 1:
-            flat = torch.cat(parts, 0)
-        else:
-            import torch.distributed as dist
-            if not parts:
-                raise RuntimeError("window sharding needs at least one frame per rank")
-            mine = torch.cat(parts, 0)
-            buf = torch.zeros(per, mine.shape[1], dtype=mine.dtype, device=mine.device)
-            buf[: mine.shape[0]] = mine
-            flat = torch.empty(self.world * per, mine.shape[1], dtype=mine.dtype, device=mine.device)
-            all_gather(flat, buf, self.group)                              # the "boundary feature" all-gather (RCCL / gloo)
-            flat = flat[: self.n]
-        Hf, Wf = self.H // 4, self.W // 4
-        n_tok = th * tw
-        C = net.cfg["cnum"] * 2
-        c, cf = net.cfg["c"], net.cfg["cf"]
-        o1, o2 = Hf * Wf * C, Hf * Wf * C + n_tok * c
-        return flat[:, :o1].reshape(self.n, Hf, Wf, C), flat[:, o1:o2].reshape(self.n, n_tok, c), flat[:, o2:].reshape(self.n, n_tok, cf), th, tw
+            for s0 in range(0, self.n, self.ck):
+                s1 = min(self.n, s0 + self.ck)
+                self._encode_chunk(s0, s1, tuple(b[s0:s1] for b in full))
+            return full + (th, tw)
+        lo = self.rank * self.per
+        works = []
+        for j in range(self.n_chunks):
+            s0 = min(self.n, lo + j * self.ck)
+            s1 = min(self.n, lo + (j + 1) * self.ck, lo + self.per)
+            if s1 > s0:
+                self._encode_chunk(s0, s1, local[j])
+            g0 = j * self.world * self.ck
+            for b, l in zip(full, local[j]):                    # "boundary feature" all-gathers (RCCL / gloo), asynchronous:
+                works.append(all_gather(b[g0:g0 + self.world * self.ck], l, self.group, async_op=True))    # chunk j travels while chunk j+1 is encoded
+        for w in works:
+            w.wait()
+        return full + (th, tw)
 
     def run_group_cached(self, gi, feats):
         """Transformer + decoder for one group of equal-length windows as a single batched forward; returns {window: out}."""
@@ -178,14 +277,18 @@ class ClipRunner:
         ws, ids, keep = self.groups[gi], self._group_ids[gi], self._group_keep[gi]
         b, bt = len(ws), ids.numel()
         t = bt // b
-        e, x, f = enc.index_select(0, ids), tok.index_select(0, ids).reshape(bt * th * tw, -1), ftok.index_select(0, ids).reshape(bt * th * tw, -1)
+        if self.on_gpu:
+            e, x, f = ops.gather_rows(enc, ids), ops.gather_rows(tok, ids).view(bt * th * tw, -1), ops.gather_rows(ftok, ids).view(bt * th * tw, -1)
+        else:
+            il = ids.long()
+            e, x, f = enc[il], tok[il].reshape(bt * th * tw, -1), ftok[il].reshape(bt * th * tw, -1)
         net = self.model.net
         if self.use_graphs:
             if self._graphs is None:
                 from .graph import GraphCache
-                # b travels as the SHAPE of a dummy tensor: graphs are cached per input-shape signature
+                # b travels as the SHAPE of a dummy tensor: graphs are cached per input-shape signature (+ weights / arithmetic mode)
                 self._graphs = GraphCache(lambda e_, x_, f_, k_, b_: net.transform_decode(e_, x_, f_, b_.shape[0], e_.shape[0] // b_.shape[0],
-                                                                                       th, tw, keep=k_))
+                                                                                       th, tw, keep=k_), state_key=net._cache_key)
             out = self._graphs(e, x, f, keep, torch.empty(b, device=self.dev)).clone()   # the static buffer is reused by the next group of this shape
         else:
             out = net.transform_decode(e, x, f, b, t, th, tw, keep=keep)
@@ -212,8 +315,9 @@ class ClipRunner:
         if self.on_gpu:
             f01 = self.frames01[0].contiguous()
             mk = self.masks[0].contiguous()
+            blend = ops.compose_blend_u8 if self.world > 1 else ops.compose_blend
             for wi in range(len(self.sched)):
-                ops.compose_blend(outs[wi], self._nb[wi], self._first[wi], f01, mk, comp)
+                blend(outs[wi], self._nb[wi], self._first[wi], f01, mk, comp)
         else:
             visited = [False] * self.n
             for wi in range(len(self.sched)):
@@ -221,17 +325,23 @@ class ClipRunner:
         return comp
 
     def _exchange(self, outs):
-        """One all-gather of the padded per-window outputs; every rank ends up with every window."""
-        import torch.distributed as dist
-        per_rank = (len(self.sched) + self.world - 1) // self.world
-        buf = torch.zeros(per_rank, self.max_nb, 3, self.H, self.W, dtype=torch.float32, device=self.dev)
+        """One all-gather of the per-window outputs, truncated to uint8 on the producing rank (tool/video_inpainting.py:731: the
+        compose starts with astype(uint8), so the composite is unchanged and the exchange carries 1 byte per value instead of 4);
+        send / receive buffers are allocated once.  Every rank ends up with every window: {window: uint8 [n_nb,3,H,W]}."""
+        slots = max(len(a) for a in self.assign)
+        if self._xchg is None:
+            self._xchg = (torch.zeros(slots, self.max_nb, 3, self.H, self.W, dtype=torch.uint8, device=self.dev),
+                          torch.empty(self.world * slots, self.max_nb, 3, self.H, self.W, dtype=torch.uint8, device=self.dev))
+        send, recv = self._xchg
         for slot, wi in enumerate(self.mine):
             o = outs[wi]
-            buf[slot, : o.shape[0]] = o
-        gathered = torch.empty(self.world * per_rank, self.max_nb, 3, self.H, self.W, dtype=torch.float32, device=self.dev)
-        all_gather(gathered, buf, self.group)
+            if self.on_gpu:
+                ops.quantize_u8(o, out=send[slot, : o.shape[0]])
+            else:
+                send[slot, : o.shape[0]] = (((o + 1) / 2) * 255).to(torch.uint8)
+        all_gather(recv, send, self.group).wait()
         full = {}
         for r in range(self.world):
-            for slot, wi in enumerate(shard_windows(len(self.sched), r, self.world)):
-                full[wi] = gathered[r * per_rank + slot, : len(self.sched[wi][0])]
+            for slot, wi in enumerate(self.assign[r]):
+                full[wi] = recv[r * slots + slot, : len(self.sched[wi][0])]
         return full

@@ -252,6 +252,14 @@ int fgt_axpby(const float* a, int lda, float sa, const float* b, int ldb, float 
 int fgt_compose_blend(const float* out_nchw, const int* ids, const int* first, int n, const float* frames01,
                       const float* masks, int H, int W, float* comp, void* stream);
 
+/* The same compose fed with already truncated values: filled_u8 [n,3,H,W] = astype(uint8)((x+1)/2*255), produced by
+ * fgt_quantize_u8 on the rank that ran the window.  Window outputs travel between ranks in this form (1 byte per value instead
+ * of 4): the truncation is the first thing tool/video_inpainting.py:731-733 does with the value, so the composite is unchanged. */
+int fgt_compose_blend_u8(const unsigned char* filled_u8, const int* ids, const int* first, int n, const float* frames01,
+                         const float* masks, int H, int W, float* comp, void* stream);
+/* dst[i] = (unsigned char)(int)((x[i] + 1) / 2 * 255) for `count` values in (-1, 1) (count % 4 == 0). */
+int fgt_quantize_u8(const float* x, long count, unsigned char* dst, void* stream);
+
 /* Input packing of the clip-level FGT stage in one pass (tool/video_inpainting.py:697 `frames*2-1`, :719-721
  * `selected_frames * (1 - selected_masks)`, FGT/models/model.py:253-257 `cat(masked_frames, masks)` + NCHW -> channels-last):
  *   dst[i, y, x, 0:3] = (frames01[f, :, y, x] * 2 - 1) * (1 - masks[f, 0, y, x]),  dst[i, y, x, 3] = masks[f, 0, y, x],

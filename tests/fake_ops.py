@@ -285,3 +285,30 @@ def convex_upsample(flow, mask):
     mk = torch.softmax(mk.reshape(B, 1, 9, 8, 8, H, W), dim=2)
     up = F.unfold(8 * fl, [3, 3], padding=1).view(B, 2, 9, 1, 1, H, W)
     return torch.sum(mk * up, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(B, 2, 8 * H, 8 * W)
+
+
+def gather_rows(src, ids, out=None):
+    r = src[ids.long()]
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def pack_frames(frames01, masks, ids=None, out=None):
+    if ids is not None:
+        frames01, masks = frames01[ids.long()], masks[ids.long()]
+    r = torch.cat([(frames01 * 2 - 1) * (1 - masks), masks], 1).permute(0, 2, 3, 1).contiguous()
+    if out is not None:
+        out[..., :4].copy_(r)
+        return out
+    return r
+
+
+def norm_flows(flows, n_out=None):
+    n = flows.shape[-4]
+    if n_out is not None and n_out > n:
+        idx = list(range(n)) + [n - 1] * (n_out - n)
+        flows = flows[..., idx, :, :, :]
+    m = flows.flatten(-2).max(dim=-1, keepdim=True)[0]
+    return flows / m.unsqueeze(-1)

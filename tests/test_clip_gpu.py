@@ -1,0 +1,84 @@
+"""Clip-level parity on the MI355X: `ClipRunner` (per-frame feature cache + window batching + decode-only-consumed + device
+compose/blend — the path bench.py times) against `oracle.fgt_clip`, the CPU restatement of tool/video_inpainting.py:687-740
+running the oracle model window by window exactly like the tool.
+
+The composited clip is piecewise constant in the model output (uint8 truncation, :731-733), so a 1e-7 difference in a value that
+sits on an integer boundary of (x+1)/2*255 flips that pixel by one step (0.5 / 0.25 after the 0.5/0.5 blends).  The tests
+therefore assert: every difference <= 1 uint8 step, and the fraction of differing values below a bound derived from the
+arithmetic's error (fp32 MFMA: ~2e-7 * 127.5 per value; bf16x3: ~1e-5 * 127.5) — and print the measured rates.
+HIP-vs-HIP comparisons (cache on/off, batching, graph replay) are bit-exact and asserted with torch.equal."""
+import pytest
+import torch
+
+from fgt_amd.synth import synth_clip, synth_state_dict
+from oracle import fgt_oracle as O
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def _model(dev):
+    from fgt_amd.fgt_model import DEFAULT_CONFIG, Model
+    m = Model(dict(DEFAULT_CONFIG)).eval()
+    sd = synth_state_dict(m.state_dict(), seed=0)
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev), sd, dict(DEFAULT_CONFIG)
+
+
+@pytest.fixture(scope="module")
+def clip46(dev):
+    m, sd, cfg = _model(dev)
+    fr, fl, ms = synth_clip(46, 64, 96, seed=5)
+    ref = O.fgt_clip(sd, cfg, fr, fl, ms)                      # the tool's loop over the CPU oracle model (10 windows)
+    return m, (fr.to(dev), fl.to(dev), ms.to(dev)), ref
+
+
+@pytest.mark.parametrize("prec,max_rate", [("fp32", 3e-4), ("bf16x3", 2e-2)])
+def test_cliprunner_cache_batch8_matches_oracle_clip(prec, max_rate, clip46, monkeypatch):
+    from fgt_amd import ops
+    from fgt_amd.scheduler import ClipRunner
+    monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", prec)
+    monkeypatch.setattr(ops, "DEFAULT_ATTN_PRECISION", prec)
+    m, (fr, fl, ms), ref = clip46
+    r = ClipRunner(m, fr, fl, ms, cache_features=True, window_batch=8, use_graphs=False)
+    assert r.cache_features and max(len(g) for g in r.groups) >= 2
+    got = r.run().cpu()
+    d = (got - ref).abs()
+    rate = (d > 0).float().mean().item()
+    print(f"[parity] ClipRunner(cache, batch 8, {prec}) vs oracle.fgt_clip: max diff {d.max().item()} uint8 steps, "
+          f"differing values {rate:.3e} of {d.numel()}, PSNR {O.psnr(got.to(torch.uint8).float(), ref.to(torch.uint8).float()):.1f} dB")
+    assert d.max().item() <= 1.0
+    assert rate < max_rate
+    # every HIP variant of the same arithmetic is bit-identical: no cache (the reference's work), batch 1, graph replay
+    assert torch.equal(ClipRunner(m, fr, fl, ms, cache_features=False).run().cpu(), got)
+    assert torch.equal(ClipRunner(m, fr, fl, ms, cache_features=True, window_batch=1, use_graphs=False).run().cpu(), got)
+    g = ClipRunner(m, fr, fl, ms, cache_features=True, window_batch=8, use_graphs=True)
+    assert torch.equal(g.run().cpu(), got) and torch.equal(g.run().cpu(), got)
+
+
+def test_cliprunner_other_schedule_matches_oracle_clip(dev):
+    """num_ref != -1 branch of get_ref_index (tool/video_inpainting.py:110-116) + another stride through the whole path."""
+    from fgt_amd.scheduler import ClipRunner
+    m, sd, cfg = _model(dev)
+    fr, fl, ms = synth_clip(17, 48, 80, seed=9)               # 12x20 token grid: padded temporal zones and spatial windows
+    ref = O.fgt_clip(sd, cfg, fr, fl, ms, neighbor_stride=3, ref_length=4, num_ref=2)
+    got = ClipRunner(m, fr.to(dev), fl.to(dev), ms.to(dev), neighbor_stride=3, ref_length=4, num_ref=2).run().cpu()
+    d = (got - ref).abs()
+    print(f"[parity] ClipRunner(stride 3, num_ref 2) vs oracle.fgt_clip: max {d.max().item()}, rate {(d > 0).float().mean().item():.3e}")
+    assert d.max().item() <= 1.0 and (d > 0).float().mean().item() < 3e-4
+
+
+def test_graph_cache_follows_weight_updates(dev):
+    """A captured hipGraph bakes in the packed-weight pointers and the arithmetic mode: the cache key must include both
+    (ADVICE r1).  After load_state_dict with other weights a graphed runner must give the NEW eager result."""
+    from fgt_amd.scheduler import ClipRunner
+    m, sd, cfg = _model(dev)
+    fr, fl, ms = (x.to(dev) for x in synth_clip(12, 64, 96, seed=2))
+    r = ClipRunner(m, fr, fl, ms, use_graphs=True)
+    a = r.run().clone()
+    assert torch.equal(r.run(), a)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=1), strict=True)
+    b = r.run().clone()
+    want = ClipRunner(m, fr, fl, ms, use_graphs=False).run()
+    assert not torch.equal(a, b), "graph replayed the old weights"
+    assert torch.equal(b, want)

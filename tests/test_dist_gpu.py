@@ -50,4 +50,4 @@ def test_two_ranks_on_one_gpu_match_single_rank():
     for name, other in (("2 ranks", res[0]), ("no feature cache", uncached)):
         d = (other - single).abs()
         print(f"[parity] clip {name} vs single rank: max diff {d.max().item()} (uint8 steps), differing px {(d > 0).float().mean().item():.2e}")
-        assert d.max().item() <= 1.0 and (d > 0).float().mean().item() < 1e-3
+        assert torch.equal(other, single)      # HIP vs HIP: per-row results do not depend on batch / sharding (oracle parity: test_clip_gpu.py)

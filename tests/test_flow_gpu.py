@@ -127,3 +127,28 @@ def test_flow_pipeline_batched_pairs_match_per_pair_calls_gpu(dev):
         b = m(frames[i + 1:i + 2], frames[i:i + 1], iters=6, test_mode=True)[1]
         assert report(f"flow pipeline fwd[{i}] vs per-pair call", fw[i:i + 1], a)[1] < 1e-4
         assert report(f"flow pipeline bwd[{i}] vs per-pair call", bw[i:i + 1], b)[1] < 1e-4
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_raft_tool_setting_864x480_twenty_iterations_vs_oracle(prec, dev, monkeypatch):
+    """The tool-faithful RAFT call: frames resized to 2x (tool/video_inpainting.py:263 via :447-450 -> 864x480 for a 432x240 clip),
+    iters = 20, test_mode.  Twenty GRU iterations feed the flow back through the correlation lookup, so round-off is amplified
+    iteration by iteration; the growth is measured (1 / 5 / 10 / 20 iterations, printed) and bounded relative to the flow range."""
+    from fgt_amd import ops
+    monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", prec)
+    sd = _sd("raft_state_keys.json")
+    m = raft_model.RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(18)
+    base = F.interpolate(torch.rand(1, 3, 61, 109, generator=g), size=(488, 872), mode="bilinear", align_corners=False) * 255
+    i1, i2 = base[:, :, 4:484, 4:868].contiguous(), base[:, :, 2:482, 7:871].contiguous()
+    errs = {}
+    for it in (1, 5, 10, 20):
+        ref = RO.raft_forward(sd, i1, i2, iters=it)
+        lo, up = m(i1.to(dev), i2.to(dev), iters=it, test_mode=True)
+        errs[it] = (rel_err(lo, ref[0]), rel_err(up, ref[1]), ref[1].abs().max().item())
+    print(f"[parity] RAFT 864x480 {prec}: rel. error of (flow_low, flow_up) and max |flow_up| by iteration count: "
+          + ", ".join(f"{it}: ({a:.2e}, {b:.2e}, {mx:.1f} px)" for it, (a, b, mx) in errs.items()))
+    assert errs[1][1] < (1e-4 if prec == "fp32" else 5e-4)
+    assert errs[20][0] < 2e-2 and errs[20][1] < 2e-2

@@ -391,3 +391,63 @@ def test_conv3x3_lds_tiled_small_cout(Cin, Cout, act, epi, nchw_out, two_src, de
     out = ops.conv2d(x0, pc, stride=1, pad=1, act=act, epi=epi, aux1=None if aux is None else aux.to(dev), out_nchw=nchw_out, **kw)
     got = out.cpu() if nchw_out else nchw(out.cpu())
     assert report(f"tiled 3x3 {Cin}->{Cout}", got, y)[1] < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Long temporal zones: the launcher switches to attn_bf16x3_kernel<8, true> (8 wavefronts per K/V tile, register prefetch) at
+# n_q >= 2048 — every window of the 432x240x80 bench clip (t = 13 / 17 / 18 on the 20x36 grid: L = 2340 / 3060 / 3240) and the
+# 864x480x160 config (t = 26 on 40x72: L = 18720).  Reference: fp64 softmax(QK^T/sqrt(d))V per (zone, head) — on the CPU for
+# t = 13, with torch fp64 on the GPU for the larger ones (an [L, L] fp64 score matrix per problem; independent of libfgt_hip).
+def _temporal_ref64(qkv, b, t, nh, nw, heads, G, c, device):
+    zh, zw, dh = nh // G, nw // G, c // heads
+    x = qkv.to(device).double().view(b, t, G, zh, G, zw, 3, heads, dh)
+    out = torch.empty(b, t, G, zh, G, zw, heads, dh, dtype=torch.float32)
+    for bi in range(b):
+        for zi in range(G):
+            for zj in range(G):
+                for hd in range(heads):
+                    q, k, v = (x[bi, :, zi, :, zj, :, j, hd].reshape(-1, dh) for j in range(3))
+                    s = (q @ k.T) / math.sqrt(dh)
+                    o = torch.softmax(s, dim=-1) @ v
+                    out[bi, :, zi, :, zj, :, hd] = o.view(t, zh, zw, dh).float().cpu()
+                    del s
+    return out.reshape(b * t * nh * nw, c)
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("b,t,nh,nw", [(1, 13, 20, 36), (1, 18, 20, 36), (2, 17, 20, 36), (1, 26, 40, 72)])
+def test_attention_temporal_long_zones(b, t, nh, nw, prec, tol, dev):
+    """attention_base.py:16-22 at the zone lengths the benchmark runs: both precisions, incl. split output."""
+    from fgt_amd import ops
+    heads, G, c = 4, 2, 512
+    L = t * (nh // G) * (nw // G)
+    assert L >= 2048                                  # the 8-wavefront bf16x3 instance / the 4-wavefront fp32 one with many key tiles
+    qkv = _rand(b * t * nh * nw, 3 * c, seed=100 + t)
+    qkv[:, :2 * c] *= 1.5                             # logits ~ N(0, 2.25 * sqrt(128)/sqrt(128)): peaky rows, running max moves often
+    ref = _temporal_ref64(qkv, b, t, nh, nw, heads, G, c, "cpu" if t == 13 else dev)
+    dq = qkv.to(dev)
+    out = ops.attention_temporal(dq, b, t, nh, nw, heads, G, c, precision=prec)
+    assert report(f"attn temporal long {prec} b{b} t{t} {nh}x{nw} (L={L})", out.cpu(), ref)[1] < tol
+    if prec == "bf16x3":                              # the path the model uses: output handed over pre-split
+        sp = ops.attention_temporal(dq, b, t, nh, nw, heads, G, c, precision=prec, out_split=True)
+        hi, lo = sp.planes()
+        assert torch.equal(hi.float() + lo.float(), (lambda o: o.to(torch.bfloat16).float() + (o - o.to(torch.bfloat16).float()).to(torch.bfloat16).float())(out))
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16x3", 1e-4)])
+def test_attention_spatial_config5_grid(prec, tol, dev):
+    """attention_flow.py:98-110 on the 864x480 token grid (40x72 -> 45 windows of 64 queries x (64 + 180) keys per frame)."""
+    from fgt_amd import ops
+    bt, h, w, heads, ws, gd, c = 3, 40, 72, 4, 8, 4, 512
+    nh, nw = h, w
+    gh, gw, ng = nh // ws, nw // ws, (nh // gd) * (nw // gd)
+    q, k, v = (_rand(bt * nh * nw, c, seed=s) for s in (11, 12, 13))
+    kg, vg = _rand(bt * ng, c, seed=14), _rand(bt * ng, c, seed=15)
+    windows = lambda y: y.view(bt, gh, ws, gw, ws, c).transpose(2, 3).reshape(bt, gh * gw, ws * ws, c)
+    split = lambda y: y.reshape(bt, gh * gw, -1, heads, c // heads).permute(0, 1, 3, 2, 4)
+    K = torch.cat([windows(k), kg.view(bt, 1, ng, c).expand(-1, gh * gw, -1, -1)], 2)
+    V = torch.cat([windows(v), vg.view(bt, 1, ng, c).expand(-1, gh * gw, -1, -1)], 2)
+    a = _sdpa(split(windows(q)).double(), split(K).double(), split(V).double()).float()
+    a = a.transpose(2, 3).reshape(bt, gh, gw, ws, ws, c).transpose(2, 3).reshape(bt * h * w, c)
+    out = ops.attention_spatial(q.to(dev), k.to(dev), v.to(dev), kg.to(dev), vg.to(dev), bt, h, w, nh, nw, heads, ws, ng, precision=prec)
+    assert report(f"attn spatial 40x72 {prec}", out.cpu(), a)[1] < tol

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from fgt_amd.scheduler import ClipRunner, shard_windows, window_schedule
+from fgt_amd.scheduler import ClipRunner, assign_windows, ideal_speedup, needs_host_staging, window_cost, window_schedule
 from oracle import fgt_oracle as O
 
 torch.set_grad_enabled(False)
@@ -35,11 +35,54 @@ def test_schedule_matches_oracle_and_reference_log():
     assert [len(a) + len(b) for a, b in s] == [13, 17, 18, 17, 18, 17, 18, 17, 18, 17, 18, 17, 18, 17, 18, 17]
 
 
-def test_shard_windows_is_a_partition():
-    for world in (1, 2, 3, 4, 8):
-        parts = [shard_windows(16, r, world) for r in range(world)]
-        assert sorted(sum(parts, [])) == list(range(16))
-        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+def test_assign_windows_is_a_balanced_partition_that_co_locates_equal_lengths():
+    for n in (23, 80, 160):
+        sched = window_schedule(n)
+        cost = lambda ws: sum(window_cost(len(sched[w][0]) + len(sched[w][1]), len(sched[w][0])) for w in ws)
+        for world in (1, 2, 3, 4, 8):
+            parts = assign_windows(sched, world)
+            assert sorted(sum(parts, [])) == list(range(len(sched)))
+            assert all(p == sorted(p) for p in parts)
+            if len(sched) >= world:
+                assert max(map(cost, parts)) <= 1.25 * cost(range(len(sched))) / world + max(cost([w]) for w in range(len(sched))) * (len(sched) % world != 0)
+            assert abs(ideal_speedup(sched, world) - cost(range(len(sched))) / max(map(cost, parts))) < 1e-9
+    # the 80-frame bench clip on 8 ranks: 4 x (17,17), 3 x (18,18), (18,13): every rank but one batches its two windows
+    sched = window_schedule(80)
+    t = lambda w: len(sched[w][0]) + len(sched[w][1])
+    parts = assign_windows(sched, 8)
+    assert sorted(sorted(t(w) for w in p) for p in parts) == sorted([[17, 17]] * 4 + [[18, 18]] * 3 + [[13, 18]])
+    assert ideal_speedup(sched, 8) > 7.4
+    parts = assign_windows(sched, 2)
+    assert sorted(sorted(t(w) for w in p) for p in parts) == sorted([[17] * 8, [13] + [18] * 7])
+
+
+def test_rccl_branch_gathers_device_buffers_directly(monkeypatch):
+    """backend "nccl" (= RCCL on ROCm): all_gather_into_tensor gets the device tensors themselves; only gloo stages through the host."""
+    import torch.distributed as dist
+    from fgt_amd import scheduler
+    assert needs_host_staging(True, "gloo") and not needs_host_staging(True, "nccl") and not needs_host_staging(False, "gloo")
+    calls = []
+
+    class FakeDev:                                   # stands in for a device tensor on this CPU-only box
+        is_cuda = True
+        shape, dtype = (2, 3), torch.float32
+
+        def cpu(self):
+            calls.append("cpu")
+            return torch.zeros(2, 3)
+
+        def copy_(self, other):
+            calls.append("copy_")
+
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    monkeypatch.setattr(dist, "all_gather_into_tensor", lambda out, buf, group=None, async_op=False: calls.append(("ag", out, buf, async_op)) or "work")
+    out, buf = FakeDev(), FakeDev()
+    assert scheduler.all_gather(out, buf, async_op=True) == "work"
+    assert calls == [("ag", out, buf, True)]         # no host staging, the handle of the asynchronous collective is returned
+    calls.clear()
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "gloo")
+    scheduler.all_gather(out, buf, async_op=True).wait()
+    assert calls[0] == "cpu" and calls[-1] == "copy_"
 
 
 @pytest.mark.parametrize("n", [6, 23, 40])

@@ -18,7 +18,7 @@ torch.set_grad_enabled(False)
 N, H, W = 12, 32, 48
 
 
-def _setup():
+def _setup(N=N):
     fgt_model.ops = fake_ops
     fgt_model.PackedConv = fake_ops.PackedConv
     m = Model(dict(DEFAULT_CONFIG)).eval()
@@ -61,10 +61,10 @@ def test_window_batching_is_exact():
         fgt_model.ops, fgt_model.PackedConv = real_ops, real_pc
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n=N):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    m, sd, fr, fl, ms = _setup()
+    m, sd, fr, fl, ms = _setup(n)
     q.put((rank, ClipRunner(m, fr, fl, ms, rank=rank, world=world, cache_features=True).run().numpy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -85,4 +85,25 @@ def test_frame_sharded_encode_and_window_sharding_two_ranks():
     finally:
         fgt_model.ops, fgt_model.PackedConv = real_ops, real_pc
     assert torch.equal(res[0], res[1])
+    assert (res[0] - single).abs().max().item() <= 1.0 and ((res[0] - single).abs() > 0).float().mean().item() < 1e-3
+
+
+def test_rank_without_frames_or_windows_keeps_the_collectives_matched():
+    """4 frames on 3 ranks: blocks of 2 frames, rank 2 has no frame and ranks 1-2 no window (one window in the clip).  Every rank
+    still enters every all-gather (zero rows / empty slots) and ends with the same composite — no rank-dependent raise that
+    would leave the others hanging in a collective."""
+    world, port, n = 3, 32500 + (os.getpid() % 2000), 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n)) for r in range(world)]
+    [p.start() for p in procs]
+    res = {r: torch.from_numpy(a) for r, a in (q.get(timeout=300) for _ in range(world))}
+    [p.join(timeout=60) for p in procs]
+    real_ops, real_pc = fgt_model.ops, fgt_model.PackedConv
+    try:
+        m, sd, fr, fl, ms = _setup(n)
+        single = ClipRunner(m, fr, fl, ms, cache_features=True).run()
+    finally:
+        fgt_model.ops, fgt_model.PackedConv = real_ops, real_pc
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
     assert (res[0] - single).abs().max().item() <= 1.0 and ((res[0] - single).abs() > 0).float().mean().item() < 1e-3
