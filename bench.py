@@ -5,20 +5,28 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one pass of the hot path over the clip: all 16 sliding-window Model.forward calls of the reference
-schedule (t = 13,17,18,... sum 275) + uint8 compose + ordered blend, inputs resident in HBM.  With N > 1 ranks:
-  * headline (`--scaling weak`, default): clips are the independent units -- every rank runs the whole path on its own
-    80-frame clip, no data-path collective; value = N * 80 * K / max-over-ranks time;
-  * `strong_scaling_same_clip` (extra object in the same line; headline with `--scaling strong`): ONE clip, frames sharded
-    for the per-frame stages, windows round-robin over the ranks, two RCCL all-gathers (features, window outputs),
-    identical composite on every rank.
-Prints ONE JSON line on rank 0 (contract in the task statement), including `roofline` for the dominant kernel
-(the fp32-MFMA implicit-GEMM conv/GEMM, timed per launch with HIP events on the launch stream) and `cpu_baseline`
-(the oracle = PyTorch CPU restatement of the reference, timed on the host cores on a bounded sample).
+schedule (t = 13,17,18,... sum 275) + uint8 compose + ordered blend, inputs resident in HBM.
+
+N = 1: the headline runs in the bf16x3 arithmetic (fp32 operands split into hi/lo bf16, 3 bf16 MFMAs per product, fp32
+accumulate; inside the north star's 1e-3 bar, parity block in the line); the SAME invocation then times the exact-fp32 mode and
+reports it as `fp32_exact` (value, ms_per_step, its own roofline against the 157.3 TF fp32-MFMA peak).
+N > 1 (`--scaling strong`, default): ONE clip sharded over the ranks — frames block-sharded for the per-frame stages with
+chunked RCCL all-gathers of the features, windows cost-balanced over the ranks with equal lengths co-located, window outputs
+exchanged as uint8 in one all-gather, identical composite on every rank.  The weak variant (one independent clip
+per rank, no data-path collective) is timed first and reported beside it as `weak_scaling_clip_per_rank`; if the sharded
+section fails or times out the weak number becomes the headline and the line says so (`scaling`, `strong_error`).
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  `roofline` is the kernel with the largest share of the step
+(per-launch HIP events on the launch stream over the timed region); `rooflines` lists all three MFMA kernels of the path
+(conv/GEMM, temporal attention, spatial attention); `cpu_baseline` is the oracle (PyTorch CPU restatement of the reference)
+timed on the host cores on a bounded sample, median of 3 runs.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
+import threading
 import time
 
 import torch
@@ -28,6 +36,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
+KERNELS = {"conv": "conv_split_kernel / conv_igemm_kernel (implicit-GEMM conv + every Linear; all fgt_conv2d MFMA launches)",
+           "attn_temporal": "attn_bf16x3_kernel<8,true> / attn_kernel<4> (temporal zone attention, fgt_attention mode 0)",
+           "attn_spatial": "attn_bf16x3_kernel<2,false> / attn_kernel<2> (spatial window + global-token attention, fgt_attention mode 1)"}
 
 
 def fgt_flops(t):
@@ -35,21 +46,21 @@ def fgt_flops(t):
     return (147.03 * t + 1.0618 * t * t) * 1e9
 
 
-def conv_traffic(prec):
-    """HBM bytes per conv_igemm launch from the rocprofv3 PMC passes over this same command (FETCH_SIZE and WRITE_SIZE
-    in separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), committed as profiles/conv_traffic.json by
-    tools/gpu_check.sh.  PMC counters cannot be read from inside the process, so this is the last profiled value."""
-    p = os.path.join(ROOT, "profiles", "conv_traffic.json")
+def kernel_traffic(prec):
+    """HBM bytes per launch of the MFMA kernels from the rocprofv3 PMC passes over this same command with the tile table
+    pre-seeded (FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), committed as
+    profiles/kernel_traffic.json by tools/gpu_check.sh + tools/pmc_traffic.py.  PMC counters cannot be read from inside the
+    process, so this is the last profiled value of this configuration (file carries the commit and command it came from)."""
+    p = os.path.join(ROOT, "profiles", "kernel_traffic.json")
     if not os.path.exists(p):
-        return None
-    t = json.load(open(p))
-    return t.get(prec, {}).get("hbm_bytes_per_launch")
+        return {}
+    return json.load(open(p)).get(prec, {})
 
 
-def cpu_baseline(cfg, sd, frames, flows, masks, sched, model=None):
+def cpu_baseline(cfg, sd, frames, flows, masks, sched, model=None, runs=3):
     """Oracle (PyTorch-CPU port of the reference path) on a bounded sample of the same workload: the first window
-    (t = 13) of the schedule, after choosing the intra-op thread count that runs a 2-frame probe fastest (a 256-thread
-    pool on a 256-core host is ~8x slower than 32 threads for these conv sizes)."""
+    (t = 13) of the schedule, `runs` timed runs (median) after choosing the intra-op thread count that runs a 2-frame probe
+    fastest (a 256-thread pool on a 256-core host is ~8x slower than 32 threads for these conv sizes)."""
     from oracle import fgt_oracle as O
     nb, ref = sched[0]
     ids = nb + ref
@@ -67,9 +78,12 @@ def cpu_baseline(cfg, sd, frames, flows, masks, sched, model=None):
         if best_dt is None or dt < best_dt:
             best, best_dt = th, dt
     torch.set_num_threads(best)
-    t0 = time.perf_counter()
-    ref = O.fgt_forward(sd, cfg, mf, fl, m)
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        ref = O.fgt_forward(sd, cfg, mf, fl, m)
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
     total = sum(fgt_flops(len(a) + len(b)) for a, b in sched)
     est_clip_s = dt * total / fgt_flops(len(ids))
     parity = None
@@ -79,12 +93,12 @@ def cpu_baseline(cfg, sd, frames, flows, masks, sched, model=None):
         u8 = lambda x: ((x + 1) / 2 * 255).clamp(0, 255).to(torch.uint8).float()
         parity = {"window": 0, "frames": len(ids), "max_abs_diff": float((got - ref).abs().max()),
                   "ref_max_abs": float(ref.abs().max()), "psnr_db_uint8": round(O.psnr(u8(got), u8(ref)), 2),
-                  "note": "HIP path (bench precision) vs CPU oracle on window 0; PSNR per FGT/metrics/psnr.py:5-9 on clip((x+1)/2*255) uint8 frames (100 = identical)"}
+                  "note": "HIP path (headline precision) vs CPU oracle on window 0; PSNR per FGT/metrics/psnr.py:5-9 on clip((x+1)/2*255) uint8 frames (100 = identical)"}
     return parity, {"value": round(frames.shape[1] / est_clip_s, 4), "unit": "frames/s", "cores": best, "host_cores": ncpu,
-            "kind": "port",
-            "sample": f"oracle fgt_forward on window 0 (t={len(ids)}) at {frames.shape[-1]}x{frames.shape[-2]} in {dt:.2f} s with {best} threads "
-                      f"(fastest of a 2-frame probe); clip time extrapolated by F(t)=147.03t+1.0618t^2 GFLOP over the "
-                      f"{len(sched)}-window reference schedule ({total / 1e12:.1f} TFLOP)"}
+                    "kind": "port", "runs_s": [round(x, 3) for x in times],
+                    "sample": f"oracle fgt_forward on window 0 (t={len(ids)}) at {frames.shape[-1]}x{frames.shape[-2]}: median of {runs} runs = {dt:.2f} s "
+                              f"with {best} threads (fastest of a 2-frame probe); clip time extrapolated by F(t)=147.03t+1.0618t^2 GFLOP over the "
+                              f"{len(sched)}-window reference schedule ({total / 1e12:.1f} TFLOP)"}
 
 
 def main():
@@ -96,16 +110,17 @@ def main():
     ap.add_argument("--height", type=int, default=240)
     ap.add_argument("--width", type=int, default=432)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event timing of the conv kernel")
+    ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event timing of the MFMA kernels")
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
-                    help="arithmetic of the conv/GEMM and attention kernels: exact fp32 MFMA, or fp32 operands split into hi/lo "
-                         "bf16 with 3 bf16 MFMAs per product and fp32 accumulation (FGT max |diff| vs reference 1.6e-6, bar 1e-3)")
+                    help="arithmetic of the headline: exact fp32 MFMA, or fp32 operands split into hi/lo bf16 with 3 bf16 MFMAs per "
+                         "product and fp32 accumulation (FGT max |diff| vs reference 1.6e-6, bar 1e-3)")
+    ap.add_argument("--no-fp32-exact", action="store_true", help="N = 1: do not also time the exact-fp32 mode (the `fp32_exact` object)")
     ap.add_argument("--no-cache", action="store_true", help="recompute the per-frame encoders in every window like the reference")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N>1: weak = one clip per rank (headline default); strong = one clip sharded by frames/windows over the ranks")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N>1 headline: strong = one clip sharded by frames/windows over the ranks (default); weak = one clip per rank")
     ap.add_argument("--window-batch", type=int, default=8, help="equal-length windows per transformer+decoder forward (bit-identical results)")
     ap.add_argument("--encode-chunk", type=int, default=20, help="frames per call of the per-frame stages (conv encoders + soft split)")
-    ap.add_argument("--graphs", action="store_true", help="replay each window's launch sequence as a hipGraph (the roofline block is "
+    ap.add_argument("--graphs", action="store_true", help="replay each window's launch sequence as a hipGraph (the roofline blocks are "
                                                           "then measured on one extra eager step after the timed region)")
     args = ap.parse_args()
 
@@ -121,6 +136,7 @@ def main():
     local = 0 if share else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -132,22 +148,14 @@ def main():
 
     from fgt_amd import ops
     from fgt_amd.fgt_model import DEFAULT_CONFIG, Model
-    from fgt_amd.scheduler import ClipRunner
+    from fgt_amd.scheduler import ClipRunner, ideal_speedup
     from fgt_amd.synth import synth_clip, synth_state_dict
 
-    ops.DEFAULT_CONV_PRECISION = ops.DEFAULT_ATTN_PRECISION = args.precision
-    prec = args.precision
     cfg = dict(DEFAULT_CONFIG, input_resolution=(240, 432))
     model = Model(cfg).eval()
     sd = synth_state_dict(model.state_dict(), seed=0)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
-    weak = world > 1 and args.scaling == "weak"
-    frames, flows, masks = synth_clip(args.frames, args.height, args.width, seed=1234 + (rank if weak else 0), device=dev)
-    if weak:        # clip-level data parallelism: this rank's own clip, the whole schedule, no collective on the data path
-        runner = ClipRunner(model, frames, flows, masks, rank=0, world=1, cache_features=not args.no_cache, use_graphs=args.graphs, window_batch=args.window_batch, encode_chunk=args.encode_chunk)
-    else:
-        runner = ClipRunner(model, frames, flows, masks, rank=rank, world=world, cache_features=not args.no_cache, use_graphs=args.graphs, window_batch=args.window_batch, encode_chunk=args.encode_chunk)
 
     def barrier():
         torch.cuda.synchronize()
@@ -155,114 +163,172 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    runner.run()                      # untimed preparation pass: weight packing + per-shape tile autotuning (setup, not a step)
-    barrier()
-    if rank == 0 and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
-        ops.save_tuning(os.path.join(ROOT, "gpurun_out", "tuning.json"))
-    for _ in range(args.warmup):
-        runner.run()
-    barrier()
-    if not args.no_prof:
-        ops.prof_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        comp = runner.run()
-    host_dt = time.perf_counter() - t0      # time the host needed to enqueue everything (launch-bound if close to dt)
-    barrier()
-    dt = time.perf_counter() - t0
-    if not args.no_prof:
-        if args.graphs:     # graph replays bypass the per-launch events: measure the same kernels on one eager step
-            ops.prof_collect()
-            runner.use_graphs = False
-            runner.run()
-            torch.cuda.synchronize()
-            runner.use_graphs = True
-        ops.prof_enable(False)
-        k_ms, k_flops, k_launches = ops.prof_collect()
-        if args.graphs:
-            k_ms, k_flops, k_launches = k_ms * args.steps, k_flops * args.steps, k_launches * args.steps
     def max_over_ranks(x):
         tt = torch.tensor([x], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return tt.item()
 
-    dt = max_over_ranks(dt)
+    def make_runner(sharded, seed):
+        fr, fl, ms = synth_clip(args.frames, args.height, args.width, seed=seed, device=dev)
+        r = ClipRunner(model, fr, fl, ms, rank=rank if sharded else 0, world=world if sharded else 1, cache_features=not args.no_cache,
+                       use_graphs=args.graphs, window_batch=args.window_batch, encode_chunk=args.encode_chunk)
+        return r, (fr, fl, ms)
 
-    out = None
-    if rank == 0:
-        fps = args.frames * args.steps / dt * (world if weak else 1)
-        clip_flops = sum(fgt_flops(len(a) + len(b)) for a, b in runner.sched) if (args.height, args.width) == (240, 432) else None
-        out = {
-            "metric": f"inpainted frames/sec at {args.width}x{args.height}x{args.frames} clip (FGT stage: {len(runner.sched)} sliding-window forwards + compose/blend)",
+    def timed(runner, prec, prof):
+        """prepare pass + W warm-up + K timed steps in arithmetic `prec`; returns (seconds max over ranks, host enqueue s, comp, prof dict)."""
+        ops.DEFAULT_CONV_PRECISION = ops.DEFAULT_ATTN_PRECISION = prec
+        runner.run()                  # untimed preparation pass: weight packing + per-shape tile autotuning (setup, not a step)
+        barrier()
+        for _ in range(args.warmup):
+            runner.run()
+        barrier()
+        if prof:
+            ops.prof_collect("all")
+            ops.prof_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            comp = runner.run()
+        host_dt = time.perf_counter() - t0      # time the host needed to enqueue everything (launch-bound if close to dt)
+        barrier()
+        dt = time.perf_counter() - t0
+        kinds, scale = {}, 1
+        if prof:
+            if args.graphs:     # graph replays bypass the per-launch events: measure the same kernels on one eager step
+                ops.prof_collect("all")
+                runner.use_graphs = False
+                runner.run()
+                torch.cuda.synchronize()
+                runner.use_graphs = True
+                scale = args.steps
+            ops.prof_enable(False)
+            for k in KERNELS:
+                ms, fl, n = ops.prof_collect(k)
+                kinds[k] = (ms * scale, fl * scale, n * scale)
+        return max_over_ranks(dt), host_dt, comp, kinds
+
+    def rooflines(kinds, prec, dt):
+        passes = 1 if prec == "fp32" else 3          # MFMA flops issued per algorithmic flop
+        peak = PEAK_FP32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        traffic = kernel_traffic(prec)
+        out = []
+        for k, (ms, fl, n) in kinds.items():
+            if ms <= 0 or n == 0:
+                continue
+            ach = passes * fl / (ms * 1e-3) / 1e12
+            out.append({"bound": "mfma", "kernel": KERNELS[k], "kind": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": traffic.get(k, {}).get("hbm_bytes_per_launch"),
+                        "algorithmic_tflops": round(fl / (ms * 1e-3) / 1e12, 2), "mfma_passes_per_product": passes,
+                        "launches": n, "avg_launch_us": round(1e3 * ms / n, 2), "kernel_ms_per_step": round(ms / args.steps, 3),
+                        "share_of_step": round(ms / (1e3 * dt), 3)})
+        out.sort(key=lambda r: -r["share_of_step"])
+        return out
+
+    def assemble(res, weak, strong_error=None):
+        dt, runner = res["dt"], res["runner"]
+        mult = world if (weak and world > 1) else 1
+        fps = args.frames * args.steps / dt * mult
+        sched = runner.sched
+        clip_flops = sum(fgt_flops(len(a) + len(b)) for a, b in sched) if (args.height, args.width) == (240, 432) else None
+        line = {
+            "metric": f"inpainted frames/sec at {args.width}x{args.height}x{args.frames} clip (FGT stage: {len(sched)} sliding-window forwards + compose/blend)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
             "dtype": "f32" if prec == "fp32" else "f32 (conv/GEMM/attention products as 3 bf16 MFMAs on hi/lo splits, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"full FGT forward, random (N(0,0.02)) weights, {args.width}x{args.height}x{args.frames} clip, "
-                                   f"reference window schedule (neighbor_stride 5, step 10; sum t = {sum(len(a) + len(b) for a, b in runner.sched)})",
-                       "windows": len(runner.sched), "sharding": (f"one clip per rank x {world} ranks, no data-path collective" if weak else
-                                    f"windows round-robin over {world} rank(s)"),
+                                   f"reference window schedule (neighbor_stride 5, step 10; sum t = {sum(len(a) + len(b) for a, b in sched)})",
+                       "windows": len(sched),
+                       "sharding": ("single GPU" if world == 1 else f"one clip per rank x {world} ranks, no data-path collective" if weak else
+                                    f"one clip: frames block-sharded for the per-frame stages (chunked all-gather of features), windows cost-balanced over "
+                                    f"{world} ranks with equal lengths co-located, uint8 all-gather of window outputs"),
                        "conv_precision": prec, "per_frame_feature_cache": bool(runner.cache_features), "hip_graphs": bool(args.graphs),
                        "window_batch": runner.window_batch},
+            "host_enqueue_ms_per_step": round(1e3 * res["host_dt"] / args.steps, 3),
         }
-        out["host_enqueue_ms_per_step"] = round(1e3 * host_dt / args.steps, 3)
         if clip_flops:
-            out["effective_tflops"] = round(clip_flops * args.steps * (world if weak else 1) / dt / 1e12, 2)
-        if not args.no_prof and k_ms > 0:
-            passes = 1 if prec == "fp32" else 3          # MFMA flops issued per algorithmic flop
-            peak = PEAK_FP32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
-            ach = passes * k_flops / (k_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": f"conv_igemm_kernel / conv_split_kernel ({prec} implicit-GEMM conv + all Linear layers; every fgt_conv2d launch)",
-                               "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(ach / peak, 4), "traffic": conv_traffic(prec),
-                               "algorithmic_tflops": round(k_flops / (k_ms * 1e-3) / 1e12, 2), "mfma_passes_per_product": passes,
-                               "launches": k_launches, "kernel_ms_per_step": round(k_ms / args.steps, 3),
-                               "share_of_step": round(k_ms / (1e3 * dt), 3)}
-        if not args.no_cpu_baseline and world == 1:      # CPU baseline: rank 0 at N = 1 only
-            out["parity_vs_cpu_oracle"], out["cpu_baseline"] = cpu_baseline(cfg, sd, frames, flows, masks, runner.sched, model)
-        # sanity on the produced clip (finite, in range) so a broken run cannot report a number silently
-        c = comp.float()
-        out["output_checksum"] = round(float(c.double().mean()), 6)      # rank 0's clip (seed 1234): identical for every N and both scalings
-        out["output_sane"] = bool(torch.isfinite(c).all() and c.min().item() >= 0 and c.max().item() <= 255)
+            line["effective_tflops"] = round(clip_flops * args.steps * mult / dt / 1e12, 2)
+        rl = rooflines(res["kinds"], prec, dt)
+        if rl:
+            line["roofline"] = dict(rl[0], note="kernel with the largest share of the step (rank 0's launches of the timed region)")
+            line["rooflines"] = rl
+        if strong_error:
+            line["strong_error"] = strong_error
+        c = res["comp"].float()
+        line["output_checksum"] = round(float(c.double().mean()), 6)      # rank 0's clip (seed 1234): identical for every N and both scalings
+        line["output_sane"] = bool(torch.isfinite(c).all() and c.min().item() >= 0 and c.max().item() <= 255)
+        return line
 
-    # N > 1, weak headline: also time the SAME K steps on ONE clip sharded over the ranks (frames -> all-gather -> windows ->
-    # all-gather -> compose) and report it beside the headline.  A watchdog delivers the headline line even if this extra
-    # section were to hang in a collective (it has only ever been rehearsed on one GPU; the driver owns the 8-GPU node).
-    if weak:
-        import threading
+    prec = args.precision
+    n_sched = None
+    out = None
+    weak_res = strong_res = None
 
+    # ---------------------------------------------------------------- N = 1 (and the weak, clip-per-rank variant at N > 1)
+    runner, clip = make_runner(False, 1234 + (rank if world > 1 else 0))
+    n_sched = runner.sched
+    dt, host_dt, comp, kinds = timed(runner, prec, prof=not args.no_prof)
+    weak_res = dict(dt=dt, host_dt=host_dt, comp=comp, kinds=kinds, runner=runner, clip=clip)
+
+    # ---------------------------------------------------------------- N > 1: ONE clip sharded over the ranks (watchdog-guarded)
+    strong_err = None
+    if world > 1:
         def give_up():
             if rank == 0:
-                out["strong_scaling_same_clip"] = {"error": "timed out after 300 s"}
-                print(json.dumps(out), flush=True)
+                line = assemble(weak_res, weak=True, strong_error="sharded section timed out after 300 s")
+                print(json.dumps(line), flush=True)
             os._exit(0)
 
         dog = threading.Timer(300.0, give_up)
         dog.daemon = True
-        dog.start()
         try:
-            f2, fl2, m2 = synth_clip(args.frames, args.height, args.width, seed=1234, device=dev)
-            r2 = ClipRunner(model, f2, fl2, m2, rank=rank, world=world, cache_features=not args.no_cache, use_graphs=args.graphs, window_batch=args.window_batch, encode_chunk=args.encode_chunk)
-            r2.run()
-            for _ in range(args.warmup):
-                r2.run()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                c2 = r2.run()
-            barrier()
-            dt2 = max_over_ranks(time.perf_counter() - t0)
-            strong = {"value": round(args.frames * args.steps / dt2, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dt2 / args.steps, 3),
-                      "scaling": "strong", "sharding": f"one {args.frames}-frame clip: frames block-sharded for the per-frame stages, "
-                      f"{len(r2.sched)} windows round-robin over {world} ranks, 2 all-gathers",
-                      "output_checksum": round(float(c2.double().mean()), 6)}
-        except Exception as e:      # the headline stands on its own; report instead of losing the line
-            strong = {"error": f"{type(e).__name__}: {e}"[:300]}
+            r2, clip2 = make_runner(True, 1234)
+            dog.start()
+            dt2, host2, comp2, kinds2 = timed(r2, prec, prof=not args.no_prof)
+            strong_res = dict(dt=dt2, host_dt=host2, comp=comp2, kinds=kinds2, runner=r2, clip=clip2)
+        except Exception as e:      # the weak number stands on its own; report instead of losing the line
+            strong_err = f"{type(e).__name__}: {e}"[:300]
         dog.cancel()
-        if rank == 0:
-            out["strong_scaling_same_clip"] = strong
+
+    if rank == 0:
+        headline_weak = world == 1 or args.scaling == "weak" or strong_res is None
+        out = assemble(weak_res if headline_weak else strong_res, weak=headline_weak, strong_error=strong_err)
+        if world > 1:
+            bound = ideal_speedup(n_sched, world)
+            per = -(-args.frames // world)
+            side = lambda res, weak: {"value": round(args.frames * args.steps / res["dt"] * (world if weak else 1), 3), "unit": "frames/s",
+                                      "ms_per_step": round(1e3 * res["dt"] / args.steps, 3), "scaling": "weak" if weak else "strong",
+                                      "output_checksum": round(float(res["comp"].double().mean()), 6)}
+            if strong_res is not None and not headline_weak:
+                out["weak_scaling_clip_per_rank"] = side(weak_res, True)
+            elif strong_res is not None:
+                out["strong_scaling_same_clip"] = side(strong_res, False)
+            out["strong_scaling_ideal"] = {"window_phase_speedup_bound": round(bound, 3), "frame_phase_speedup_bound": round(args.frames / per, 3),
+                                           "note": f"{len(n_sched)} windows over {world} ranks: total window cost / most loaded rank (scheduler.assign_windows); "
+                                                   f"per-frame stages {args.frames} frames / {per} per rank"}
+
+    # ---------------------------------------------------------------- N = 1 extras: exact-fp32 mode, CPU baseline + parity
+    if world == 1 and rank == 0:
+        runner = weak_res["runner"]
+        frames, flows, masks = weak_res["clip"]
+        if not args.no_cpu_baseline:      # CPU baseline: rank 0 at N = 1 only (headline precision still selected)
+            ops.DEFAULT_CONV_PRECISION = ops.DEFAULT_ATTN_PRECISION = prec
+            out["parity_vs_cpu_oracle"], out["cpu_baseline"] = cpu_baseline(cfg, sd, frames, flows, masks, runner.sched, model)
+        if prec != "fp32" and not args.no_fp32_exact:
+            dt32, host32, comp32, kinds32 = timed(runner, "fp32", prof=not args.no_prof)
+            rl = rooflines(kinds32, "fp32", dt32)
+            d8 = (comp32.float() - weak_res["comp"].float()).abs()
+            out["fp32_exact"] = {"value": round(args.frames * args.steps / dt32, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dt32 / args.steps, 3),
+                                 "dtype": "f32 (v_mfma_f32_32x32x2_f32: bit-exact fmaf chains)", "steps": args.steps, "warmup": args.warmup,
+                                 "roofline": rl[0] if rl else None, "rooflines": rl,
+                                 "effective_tflops": round(sum(fgt_flops(len(a) + len(b)) for a, b in runner.sched) * args.steps / dt32 / 1e12, 2)
+                                 if (args.height, args.width) == (240, 432) else None,
+                                 "composite_vs_headline": {"max_uint8_steps": float(d8.max()), "differing_values": float((d8 > 0).float().mean())}}
+            ops.DEFAULT_CONV_PRECISION = ops.DEFAULT_ATTN_PRECISION = prec
+        if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            ops.save_tuning(os.path.join(ROOT, "gpurun_out", "tuning.json"))
+
     if rank == 0:
         print(json.dumps(out))
         assert out["output_sane"], "composited clip has NaN/inf or out-of-range values"

@@ -22,7 +22,7 @@ class ConvDesc(C.Structure):
                [("slope", C.c_float)] + \
                [(n, C.c_int) for n in ("epi", "act2", "ld_aux1", "ld_aux2")] + \
                [("out_scale", C.c_float)] + \
-               [(n, C.c_int) for n in ("Kpad", "Npad", "tile", "precision", "in_split", "out_split", "ldo_s", "ooff_s", "w_il", "reserved0")] + \
+               [(n, C.c_int) for n in ("Kpad", "Npad", "tile", "precision", "in_split", "out_split", "ldo_s", "ooff_s", "w_il", "k_alg")] + \
                [(n, C.c_longlong) for n in ("ps0", "ps1", "pso")]
 
 
@@ -70,6 +70,7 @@ SIGNATURES = {
     "fgt_laplace_fill": [_P, _P, _I, _I, _I, _I, _P, _P, _I, _F, _P],
     "fgt_prof_enable": [_I],
     "fgt_prof_collect": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)],
+    "fgt_prof_collect_kind": [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)],
 }
 _RESTYPES = {"fgt_last_error": C.c_char_p, "fgt_prof_enable": None, "fgt_laplace_fill_workspace": C.c_long}
 

@@ -499,6 +499,8 @@ extern "C" int fgt_attention(const fgt_attn_desc* dd, const float* Q, const floa
     hipStream_t s = (hipStream_t)stream;
     FGT_REQUIRE(d.precision == 0 || d.precision == 1, "fgt_attention: unknown precision %d", d.precision);
     FGT_REQUIRE(d.out_split == 0 || (d.out_split == 1 && d.pso > 0 && d.pso % 4 == 0), "fgt_attention: bad out_split / pso");
+    const int prof = fgt_prof_begin(d.mode == 0 ? FGT_PROF_ATTN_TEMPORAL : FGT_PROF_ATTN_SPATIAL,
+                                    4.0 * (double)p.n_q * p.n_k * HD * problems, s);
     if (p.n_q <= 64) {
         dim3 grid(cdiv(p.n_q, 64), problems);
         if (d.precision == 0) hipLaunchKernelGGL((attn_kernel<2>), grid, dim3(128), 0, s, p);
@@ -511,5 +513,6 @@ extern "C" int fgt_attention(const fgt_attn_desc* dd, const float* Q, const floa
             hipLaunchKernelGGL((attn_bf16x3_kernel<8, true>), grid8, dim3(512), 0, s, p);
         } else hipLaunchKernelGGL((attn_bf16x3_kernel<4, true>), grid, dim3(256), 0, s, p);
     }
+    fgt_prof_end(prof, s);
     return fgt_check_launch("attn_kernel");
 }

@@ -316,36 +316,7 @@ int launch_tile(int tile, const ConvP& p, hipStream_t s) {
     }
 }
 
-// ---- optional per-launch timing (bench roofline block) -------------------------------------------
-struct ProfRec { hipEvent_t a, b; double flops; };
-bool g_prof_on = false;
-std::vector<ProfRec> g_prof;
-std::vector<hipEvent_t> g_event_pool;
-
-hipEvent_t get_event() {
-    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
-    hipEvent_t e; hipEventCreate(&e); return e;
-}
-
 }  // namespace
-
-extern "C" void fgt_prof_enable(int on) { g_prof_on = on != 0; }
-
-extern "C" int fgt_prof_collect(double* total_ms, double* total_flops, long* launches) {
-    double ms = 0, fl = 0;
-    for (auto& r : g_prof) {
-        hipEventSynchronize(r.b);
-        float t = 0.f;
-        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) { fgt_set_error("hipEventElapsedTime failed"); return FGT_ELAUNCH; }
-        ms += t; fl += r.flops;
-        g_event_pool.push_back(r.a); g_event_pool.push_back(r.b);
-    }
-    if (total_ms) *total_ms = ms;
-    if (total_flops) *total_flops = fl;
-    if (launches) *launches = (long)g_prof.size();
-    g_prof.clear();
-    return FGT_OK;
-}
 
 extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* x1v, const float* w_packed,
                           const float* cscale, const float* cbias, const float* aux1, const float* aux2,
@@ -421,23 +392,16 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    ProfRec rec{};
     const bool direct = d.tile == 0 && d.precision == 0 && d.out_split == 0 && fgt_conv_direct_eligible(p);
-    const bool prof = g_prof_on && !direct;   // the roofline block is about the MFMA kernel only
-    if (prof) {
-        rec.a = get_event(); rec.b = get_event();
-        rec.flops = 2.0 * (double)M * p.Cout_g * p.K * d.groups;
-        hipEventRecord(rec.a, s);
-    }
+    // roofline accounting is about the MFMA kernels only; algorithmic flops use the UNPADDED K (flow 2 -> 4, RGB 3 -> 4 channel
+    // padding is not work the reference does): desc.k_alg = kh*kw*Cin_real/groups, 0 = the padded K
+    const int prof = direct ? -1 : fgt_prof_begin(FGT_PROF_CONV, 2.0 * (double)M * p.Cout_g * (d.k_alg > 0 ? d.k_alg : p.K) * d.groups, s);
     FGT_REQUIRE(d.precision == 0 || d.precision == 1, "fgt_conv2d: unknown precision %d", d.precision);
     int rc;
     if (direct) rc = fgt_conv_direct(p, s);   // Cout <= 4: VALU direct conv (fp32)
     else if (d.in_split) rc = fgt_conv_split_launch(tile, p, s);
     else if (tile >= FGT_TILE_256x128x8_S3) { fgt_set_error("fgt_conv2d: tile %d needs split inputs", tile); rc = FGT_EINVAL; }
     else rc = d.precision == 0 ? launch_tile<0>(tile, p, s) : launch_tile<1>(tile, p, s);
-    if (prof) {
-        hipEventRecord(rec.b, s);
-        g_prof.push_back(rec);
-    }
+    fgt_prof_end(prof, s);
     return rc;
 }

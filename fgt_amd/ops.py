@@ -175,6 +175,7 @@ class PackedConv:
         self.Cout, self.groups, self.kh, self.kw = Cout, groups, kh, kw
         Cg_p = ceil_to(Cg, 4) if pad_cin_to4 else Cg
         self.Cg = Cg_p
+        self.k_alg = kh * kw * Cg                    # algorithmic K (before channel padding): roofline accounting
         self.Cin = Cg_p * groups
         K = kh * kw * Cg_p
         self.K = K
@@ -260,6 +261,7 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     d.ld_aux2 = 0 if aux2 is None else _as_map(aux2)[5]
     d.out_scale = float(out_scale)
     d.Kpad, d.Npad, d.tile = pc.Kpad, pc.Npad, TILE[tile]
+    d.k_alg = getattr(pc, "k_alg", 0)
     d.precision = PREC[precision if precision is not None else DEFAULT_CONV_PRECISION]
     if pc.Cout // pc.groups <= 4 and d.tile == 0 and not in_split and not osp:
         d.precision = 0                      # Cout <= 4 layers run the fp32 VALU direct-conv kernels
@@ -636,7 +638,11 @@ def prof_is_enabled():
     return _prof_on
 
 
-def prof_collect():
+PROF_KINDS = {"conv": 0, "attn_temporal": 1, "attn_spatial": 2, "all": -1}
+
+
+def prof_collect(kind="conv"):
+    """(total ms, total algorithmic flops, launches) of the launches of `kind` recorded since the last collect."""
     ms, fl, n = C.c_double(), C.c_double(), C.c_long()
-    check(_lib.lib().fgt_prof_collect(C.byref(ms), C.byref(fl), C.byref(n)), "fgt_prof_collect")
+    check(_lib.lib().fgt_prof_collect_kind(PROF_KINDS[kind], C.byref(ms), C.byref(fl), C.byref(n)), "fgt_prof_collect_kind")
     return ms.value, fl.value, n.value

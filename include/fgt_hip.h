@@ -105,7 +105,8 @@ typedef struct fgt_conv_desc {
     int ldo_s, ooff_s;      /* row stride / first channel of out_s (bf16 elements; out_split with pso == 32 writes the
                              * interleaved layout of in_split = 2: ldo_s >= 2*Cout, needs Cout/groups % 32 == 0)          */
     int w_il;               /* 1: w_packed is [groups][Npad][Kpad/32][hi 32 | lo 32] (interleaved) instead of two planes   */
-    int reserved0;
+    int k_alg;              /* profiling only: kh*kw*Cin/groups BEFORE zero-padding of the input channels (flow 2 -> 4, RGB 3 -> 4),
+                             * the K that fgt_prof_* credits as algorithmic work; 0 = use the padded K                        */
     long long ps0, ps1, pso;/* plane strides (bf16 elements) of x0, x1, out_s                                            */
 } fgt_conv_desc;
 
@@ -287,11 +288,17 @@ long fgt_laplace_fill_workspace(int B, int H, int W);
 int fgt_laplace_fill(const float* I, const unsigned char* mask, int B, int n_masks, int H, int W, float* out, void* workspace,
                      int iters, float tol, void* stream);
 
-/* ---- per-kernel timing of fgt_conv2d launches with HIP events on the launch stream (bench roofline) ----
- * fgt_prof_enable(1) makes every fgt_conv2d launch record an event pair and accumulate its algorithmic
- * flops (2*M*Cout_g*K*groups); fgt_prof_collect synchronises the events and returns totals. */
+/* ---- per-kernel timing with HIP events on the launch stream (bench.py's roofline blocks) ----
+ * fgt_prof_enable(1) makes every fgt_conv2d (MFMA kernels) and fgt_attention launch record an event pair and its ALGORITHMIC
+ * flops: conv/GEMM 2*M*Cout_g*K*groups (K before channel padding, fgt_conv_desc.k_alg); attention 4*n_q*n_k*128 per
+ * (problem, head) — the two contractions of attention_base.py:16-22 as torch's flop counter counts them.
+ * fgt_prof_collect_kind synchronises the events of one kind and returns (and clears) its totals; kind -1 = all. */
+#define FGT_PROF_CONV 0
+#define FGT_PROF_ATTN_TEMPORAL 1
+#define FGT_PROF_ATTN_SPATIAL 2
 void fgt_prof_enable(int on);
-int fgt_prof_collect(double* total_ms, double* total_flops, long* launches);
+int fgt_prof_collect_kind(int kind, double* total_ms, double* total_flops, long* launches);
+int fgt_prof_collect(double* total_ms, double* total_flops, long* launches); /* = kind FGT_PROF_CONV */
 
 #ifdef __cplusplus
 }

@@ -1,36 +1,77 @@
 #!/usr/bin/env python
-"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py into per-launch HBM traffic of conv_igemm.
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py into per-launch HBM traffic of the MFMA kernels.
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <precision> <out.json>
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <precision> <out.json> [<command note>]
+
+Per kernel KIND (the grouping bench.py's `rooflines` use: conv = conv_split + conv_igemm, attn_temporal, attn_spatial) and per
+kernel TEMPLATE instance.  The profiled command must run with FGT_TUNING_FILE pre-seeded so that no autotuner candidate launch
+is in the trace: every launch counted is a launch of a clip pass.  FETCH_SIZE x2: gfx950 tallies 128-B requests at 64 B
+(MI355X_MICROARCH.md §HBM); both counters are in KiB.
 """
 import csv
 import glob
 import json
 import os
+import re
+import subprocess
 import sys
+from collections import defaultdict
 
 
-def avg(d, counter):
-    n, tot = 0, 0.0
+def kind_of(name):
+    if "conv_split_kernel" in name or "conv_igemm_kernel" in name:
+        return "conv"
+    if "attn_" in name:
+        # spatial windows run the 2-wavefront instances (64 queries), temporal zones the 4- / 8-wavefront ones
+        return "attn_spatial" if re.search(r"attn_(bf16x3_)?kernel<2", name) else "attn_temporal"
+    return None
+
+
+def collect(d, counter):
+    per = defaultdict(lambda: [0, 0.0])
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if ("conv_igemm" in r.get("Kernel_Name", "") or "conv_split" in r.get("Kernel_Name", "")) and r["Counter_Name"] == counter:
-                n += 1
-                tot += float(r["Counter_Value"])
-    return n, tot
+            if r["Counter_Name"] != counter:
+                continue
+            name = r.get("Kernel_Name", "")
+            if kind_of(name) is None:
+                continue
+            short = re.sub(r"\(.*$", "", name).replace("(anonymous namespace)::", "")
+            a = per[short]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return per
 
 
 def main():
     fd, wd, prec, out = sys.argv[1:5]
-    nf, f = avg(fd, "FETCH_SIZE")
-    nw, w = avg(wd, "WRITE_SIZE")
+    note = sys.argv[5] if len(sys.argv) > 5 else "bench.py --steps 1 --warmup 0 --no-prof --no-cpu-baseline --no-fp32-exact (prepare pass + 1 step, tiles pre-seeded)"
+    F, W = collect(fd, "FETCH_SIZE"), collect(wd, "WRITE_SIZE")
+    kinds = defaultdict(lambda: {"launches": 0, "fetch_KiB": 0.0, "write_KiB": 0.0})
+    templates = {}
+    for name in sorted(set(F) | set(W)):
+        nf, f = F.get(name, [0, 0.0])
+        nw, w = W.get(name, [0, 0.0])
+        n = max(nf, nw, 1)
+        templates[name] = {"launches": nf, "hbm_bytes_per_launch": round((2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024)}
+        k = kinds[kind_of(name)]
+        k["launches"] += nf
+        k["fetch_KiB"] += f
+        k["write_KiB"] += w * (nf / max(nw, 1))
     res = json.load(open(out)) if os.path.exists(out) else {}
-    res[prec] = {"launches": nf, "fetch_KiB_per_launch_raw": f / max(nf, 1), "write_KiB_per_launch": w / max(nw, 1),
-                 "hbm_bytes_per_launch": round((2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024),
-                 "note": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KiB -> bytes, averaged over the "
-                         "conv_igemm_kernel + conv_split_kernel launches of `bench.py --steps 1 --warmup 0`"}
+    try:
+        head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        head = ""
+    entry = {"command": note, "git_head": head, "templates": templates,
+             "note": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KiB -> bytes, per launch"}
+    for k, v in kinds.items():
+        n = max(v["launches"], 1)
+        entry[k] = {"launches": v["launches"], "fetch_KiB_per_launch_raw": v["fetch_KiB"] / n, "write_KiB_per_launch": v["write_KiB"] / n,
+                    "hbm_bytes_per_launch": round((2.0 * v["fetch_KiB"] + v["write_KiB"]) / n * 1024)}
+    res[prec] = entry
     json.dump(res, open(out, "w"), indent=1)
-    print(res[prec])
+    print({k: entry[k] for k in kinds})
 
 
 if __name__ == "__main__":
