@@ -343,6 +343,10 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_bf16x3_kernel(const AttnP p) 
         key_pointers(p, pr, choff, 0, tid, kptr, vptr);
         __syncthreads();
         gload();
+        // every wavefront must have READ tile 0's row pointers before the first loop iteration overwrites the table with tile 1's
+        // (without this barrier wavefront 0 could run ahead: found by tests/test_ops_gpu.py::test_attention_temporal_long_zones,
+        //  the 8-wavefront instance mixed rows of tile 1 into tile 0)
+        __syncthreads();
     }
     for (int k0 = 0; k0 < p.n_k; k0 += KT) {
         if constexpr (PF) {

@@ -44,7 +44,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N == 0, "add the immediate");
 }
 
-template <int BM, int BN, int WM, int WN, int MINW, int NS, bool PP, bool IL = false>
+template <int BM, int BN, int WM, int WN, int MINW, int NS, bool PP, bool IL = false, int P8 = 0>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const ConvP p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -57,6 +57,8 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     static_assert(NS >= 2 && NS <= 4, "LDS ring depth");
     static_assert(!PP || (NS >= 3 && NW % 2 == 0), "ping-pong needs a ring of >= 3 stages and an even wavefront count");
     static_assert(!IL || (NS == 2 && !PP && TM >= 2), "interleaved schedule: double buffer, >= 2 row blocks per wavefront");
+    static_assert(!P8 || (NS == 2 && !PP && !IL && NW == 8 && BM == 256 && TM % 2 == 0 && TN % 2 == 0 && A_IT == 2 && (B_IT == 2 || B_IT == 4)),
+                  "8-phase schedule: 256-row tile on 8 wavefronts, double buffer");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const fgt_conv_desc& d = p.d;
@@ -324,6 +326,139 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
             slot ^= 1;
             slot_in ^= 1;
         }
+    } else if constexpr (P8 != 0) {
+        // ---- 8-phase staggered schedule (two K tiles = 8 phases; cdna_hip_programming.md "256^2 8-phase template", re-derived for the
+        // hi/lo-split implicit GEMM).  One workgroup per CU, 8 wavefronts = two groups G0 (waves 0-3) / G1 (waves 4-7), one wavefront of
+        // each group per SIMD.  A K tile is 4 phases, one per quadrant of the wavefront's output tile (row half ih x column half jh):
+        //     L(q): fragment reads for the quadrant + 2 LDS-DMA pieces of tile kt+1   | s_barrier |
+        //     C(q): (TM/2)*(TN/2)*6 MFMAs under s_setprio 1                           | s_barrier |
+        // G1 runs ONE barrier behind G0, so in every barrier interval one wavefront of each SIMD issues loads / DMAs while its partner
+        // owns the matrix pipe (the DMA issue cost, ~100-185 cycles per piece, and the LDS reads hide under the partner's MFMAs instead
+        // of idling the pipe for all 8 wavefronts at once).  Quadrant order (0,0) (0,1) (1,1) (1,0): A half ih stays in registers for two
+        // phases, both B halves stay for the tile -> reads per phase 12 / 4 / 8 / 0 (256x256).
+        // Staging of tile kt+1 (other LDS stage) during tile kt, by "half tiles" (HB0, HB1: B rows 0-127 / 128-255; HA0, HA1: A rows):
+        //     L(0): HB0   L(1): HB1   L(2): HA0   L(3): HA1        (every wavefront contributes its pieces of the same half tile)
+        // Intervals are numbered by barrier count, tile kt starts at 8kt: G0 has L(q) in 8kt+2q, C(q) in 8kt+2q+1; G1 one later.
+        //   reads of tile kt:   HB in 8kt+0..3, HA0 (G0 only: its rows) in 8kt+0 and +4, HA1 (G1 only) in 8kt+1 and +5; a read issued in
+        //                       interval n is complete (lgkmcnt(0) at the head of C) before its wavefront leaves interval n+1;
+        //   WAR: stage of tile kt+1 held tile kt-1, last read in interval 8kt-3  ->  every DMA below (>= 8kt) is safe;
+        //   RAW: G0 reads HB, HA0 of tile kt+1 in 8kt+8, G1 reads HB, HA1 in 8kt+9.  Counted waits in FRONT of the barriers that end
+        //        intervals 8kt+7 and 8kt+8 (never in the phase that reads):
+        //            end of 8kt+7:  G0 (end of C(3)) vmcnt(n3)   G1 (end of L(3)) vmcnt(n3)    -> all but the HA1 pieces have landed
+        //            end of 8kt+8:  G0 (end of L(0) of tile kt+1) vmcnt(n0) [0 when nothing was staged]   G1 (end of C(3)) vmcnt(0)
+        //        (n_q = pieces a wavefront issues in L(q); G1's vmcnt(0) waits for pieces issued a whole interval earlier).
+        constexpr int HM = TM / 2, HN = TN / 2;
+        constexpr int N0 = 2, N3 = 2;                       // pieces issued in L(0) (B hi + lo of HB0, or of the whole B tile) and L(3) (HA1 hi + lo)
+        const bool g1 = wave >= 4;
+        bf16x8 ah[HM][2], al[HM][2], bh[TN][2], bl[TN][2];  // [block][k half]
+        auto readA8 = [&](int ih) {
+            const __bf16* base = reinterpret_cast<const __bf16*>(smem + slot * STAGE);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const __bf16* Ahi = base + (wm * WTM + ih * HM * 32 + l31) * LDB + swz(l31, ks * 2 + lh);
+#pragma unroll
+                for (int i = 0; i < HM; ++i) {
+                    ah[i][ks] = *reinterpret_cast<const bf16x8*>(Ahi + i * 32 * LDB);
+                    al[i][ks] = *reinterpret_cast<const bf16x8*>(Ahi + BM * LDB + i * 32 * LDB);
+                }
+            }
+        };
+        auto readB8 = [&](int jh) {
+            const __bf16* base = reinterpret_cast<const __bf16*>(smem + slot * STAGE);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const __bf16* Bhi = base + 2 * BM * LDB + (wn * WTN + jh * HN * 32 + l31) * LDB + swz(l31, ks * 2 + lh);
+#pragma unroll
+                for (int j = 0; j < HN; ++j) {
+                    bh[jh * HN + j][ks] = *reinterpret_cast<const bf16x8*>(Bhi + j * 32 * LDB);
+                    bl[jh * HN + j][ks] = *reinterpret_cast<const bf16x8*>(Bhi + BN * LDB + j * 32 * LDB);
+                }
+            }
+        };
+        // same per-accumulator product order as conv_igemm.hip (per k half: lo*hi, hi*lo, hi*hi): bit-identical results
+        auto mm8 = [&](int ih, int jh) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < HM; ++i)
+#pragma unroll
+                    for (int j = 0; j < HN; ++j)
+                        acc[ih * HM + i][jh * HN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i][ks], bh[jh * HN + j][ks], acc[ih * HM + i][jh * HN + j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < HM; ++i)
+#pragma unroll
+                    for (int j = 0; j < HN; ++j)
+                        acc[ih * HM + i][jh * HN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i][ks], bl[jh * HN + j][ks], acc[ih * HM + i][jh * HN + j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < HM; ++i)
+#pragma unroll
+                    for (int j = 0; j < HN; ++j)
+                        acc[ih * HM + i][jh * HN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i][ks], bh[jh * HN + j][ks], acc[ih * HM + i][jh * HN + j], 0, 0, 0);
+            }
+        };
+        // DMA pieces of issue_piece(): j = 2*it + plane for the A row group it (0: HA0, 1: HA1); j = 4 + it for the B pieces, where
+        // B_IT = 4 (BN = 256): it = 0 / 2 -> hi / lo of HB0, it = 1 / 3 -> hi / lo of HB1;  B_IT = 2 (BN = 128): it = 0 / 1 -> hi / lo.
+        auto stage8 = [&](int q) {
+            if (q == 0) {
+                issue_piece(4, slot_in);
+                issue_piece(B_IT == 4 ? 6 : 5, slot_in);
+            } else if (q == 1) {
+                if constexpr (B_IT == 4) { issue_piece(5, slot_in); issue_piece(7, slot_in); }
+            } else if (q == 2) {
+                issue_piece(0, slot_in); issue_piece(1, slot_in);
+            } else {
+                issue_piece(2, slot_in); issue_piece(3, slot_in);
+                advance_A();
+            }
+        };
+        auto compute8 = [&](int ih, int jh) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (P8 & 2) __builtin_amdgcn_s_setprio(1);
+            mm8(ih, jh);
+            if constexpr (P8 & 2) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (g1) __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < p.nk; ++kt) {
+            const bool st = kt + 1 < p.nk;                  // tile kt+1 exists: stage it during this tile
+            // ---- phase 0: quadrant (0,0)
+            if (st) stage8(0);
+            readA8(0);
+            readB8(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!g1) { if (st) wait_vmcnt<N0>(); else wait_vmcnt<0>(); }
+            __builtin_amdgcn_s_barrier();
+            compute8(0, 0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 1: quadrant (0,1)
+            if (st) stage8(1);
+            readB8(1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            compute8(0, 1);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 2: quadrant (1,1)
+            if (st) stage8(2);
+            readA8(1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            compute8(1, 1);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 3: quadrant (1,0)
+            if (st) stage8(3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g1) { if (st) wait_vmcnt<N3>(); else wait_vmcnt<0>(); }
+            __builtin_amdgcn_s_barrier();
+            compute8(1, 0);
+            if (g1) wait_vmcnt<0>();
+            else if (st) wait_vmcnt<N3>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            slot ^= 1;
+            slot_in ^= 1;
+        }
+        if (!g1) __builtin_amdgcn_s_barrier();
     } else if constexpr (!PP) {
         for (int kt = 0; kt < p.nk; ++kt) {
             if (kt + AHEAD < p.nk) issue_tile(slot_in);
@@ -374,19 +509,19 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
 }
 
-template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2, bool PP = false, bool IL = false>
+template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2, bool PP = false, bool IL = false, int P8 = 0>
 int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr size_t smem = (size_t)NS * (BM + BN) * LDB * sizeof(float);
     static_assert(smem <= 160 * 1024, "LDS ring does not fit");
     static std::atomic<unsigned long long> lds_set{0};
-    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL>), (int)smem, lds_set, "conv_split")) return rc;
+    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL, P8>), (int)smem, lds_set, "conv_split")) return rc;
     ConvP q = p;
     q.mtiles = cdiv(p.M, BM);
     q.ntiles = cdiv(p.Cout_g, BN);
     q.mchunk = cdiv(q.mtiles, 8);
     dim3 grid(q.xcd_swizzle ? 8 * q.mchunk * q.ntiles : q.mtiles * q.ntiles, p.d.groups);
-    hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL>), grid, dim3(NT), smem, s, q);
+    hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL, P8>), grid, dim3(NT), smem, s, q);
     return fgt_check_launch("conv_split");
 }
 
@@ -408,6 +543,9 @@ int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_256x128x8_PP: return launch<256, 128, 4, 2, 2, 3, true>(p, s);  // + ping-pong wavefront groups
         case FGT_TILE_128x128x8_PP: return launch<128, 128, 2, 4, 4, 4, true>(p, s);
         case FGT_TILE_256x128x8_IL: return launch<256, 128, 4, 2, 2, 2, false, true>(p, s);
+        case FGT_TILE_256x256_P8: return launch<256, 256, 2, 4, 2, 2, false, false, 3>(p, s);     // 8-phase staggered schedule, setprio around the MFMAs
+        case FGT_TILE_256x128_P8: return launch<256, 128, 4, 2, 2, 2, false, false, 3>(p, s);
+        case FGT_TILE_256x256_P8N: return launch<256, 256, 2, 4, 2, 2, false, false, 1>(p, s);    // the same without s_setprio (A/B)
         default: fgt_set_error("fgt_conv2d: unknown tile %d", tile); return FGT_EINVAL;
     }
 }

@@ -150,5 +150,6 @@ def test_raft_tool_setting_864x480_twenty_iterations_vs_oracle(prec, dev, monkey
         errs[it] = (rel_err(lo, ref[0]), rel_err(up, ref[1]), ref[1].abs().max().item())
     print(f"[parity] RAFT 864x480 {prec}: rel. error of (flow_low, flow_up) and max |flow_up| by iteration count: "
           + ", ".join(f"{it}: ({a:.2e}, {b:.2e}, {mx:.1f} px)" for it, (a, b, mx) in errs.items()))
-    assert errs[1][1] < (1e-4 if prec == "fp32" else 5e-4)
-    assert errs[20][0] < 2e-2 and errs[20][1] < 2e-2
+    assert errs[1][1] < (5e-5 if prec == "fp32" else 2e-4)
+    tol20 = 3e-3 if prec == "fp32" else 1.2e-2      # measured (profiles/r02_run1_pytest_gpu.log): 7.4e-4 / 3.0e-3 on flows of 610 px
+    assert errs[20][0] < tol20 and errs[20][1] < tol20

@@ -36,7 +36,7 @@ def collect(d, counter):
             name = r.get("Kernel_Name", "")
             if kind_of(name) is None:
                 continue
-            short = re.sub(r"\(.*$", "", name).replace("(anonymous namespace)::", "")
+            short = re.sub(r"\(.*$", "", name.replace("(anonymous namespace)::", "").replace("void ", ""))
             a = per[short]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
