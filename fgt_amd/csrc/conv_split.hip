@@ -347,9 +347,19 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
         //            end of 8kt+7:  G0 (end of C(3)) vmcnt(n3)   G1 (end of L(3)) vmcnt(n3)    -> all but the HA1 pieces have landed
         //            end of 8kt+8:  G0 (end of L(0) of tile kt+1) vmcnt(n0) [0 when nothing was staged]   G1 (end of C(3)) vmcnt(0)
         //        (n_q = pieces a wavefront issues in L(q); G1's vmcnt(0) waits for pieces issued a whole interval earlier).
+        // Measured (profiles/r02_run3_split_sweep_p8*.txt): bit-identical, and NOT faster than the 128x128 8-wavefront tile — 318 vs 310 TF
+        // algorithmic on the 640->512 g2 3x3 layer, slower on K = 512 GEMMs (16 K tiles: prologue / epilogue weigh more).  Timing-only
+        // ablations of this loop on that layer: no DMA 439 TF (the ceiling of the phase structure, 53 % of the nominal bf16 peak), DMA +
+        // fragment reads without MFMAs 508, reads + barriers alone 1101; staggered = lock-step within 3 %.  The DMA stream alone needs 86 %
+        // of the MFMA-only time and runs at 64 KB in flight per CU / ~2 us = 31 GB/s per CU (8 TB/s chip-wide): it is LATENCY-bound by
+        // the one-tile prefetch depth that 160 KB of LDS allows at this tile size, and overlaps only about half with the MFMA phases.
+        // Kept as explicit tiles (parity-tested); the autotuner does not consider them.
         constexpr int HM = TM / 2, HN = TN / 2;
         constexpr int N0 = 2, N3 = 2;                       // pieces issued in L(0) (B hi + lo of HB0, or of the whole B tile) and L(3) (HA1 hi + lo)
-        const bool g1 = wave >= 4;
+        constexpr bool LOCK = (P8 & 4) != 0;                // A/B variant: both groups in lock step (same phases, no stagger)
+        constexpr bool NO_DMA = (P8 & 8) != 0;              // timing-only ablations (wrong results): no staging inside the loop,
+        constexpr bool NO_MMA = (P8 & 16) != 0;             //   no MFMAs (fragment reads kept alive),
+        const bool g1 = !LOCK && wave >= 4;
         bf16x8 ah[HM][2], al[HM][2], bh[TN][2], bl[TN][2];  // [block][k half]
         auto readA8 = [&](int ih) {
             const __bf16* base = reinterpret_cast<const __bf16*>(smem + slot * STAGE);
@@ -415,13 +425,23 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (P8 & 2) __builtin_amdgcn_s_setprio(1);
-            mm8(ih, jh);
+            if constexpr (!NO_MMA) mm8(ih, jh);
+            else {
+#pragma unroll
+                for (int i = 0; i < HM; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) asm volatile("" ::"v"(ah[i][ks]), "v"(al[i][ks]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) asm volatile("" ::"v"(bh[j][ks]), "v"(bl[j][ks]));
+            }
             if constexpr (P8 & 2) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         };
         if (g1) __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < p.nk; ++kt) {
-            const bool st = kt + 1 < p.nk;                  // tile kt+1 exists: stage it during this tile
+            const bool st = !NO_DMA && kt + 1 < p.nk;       // tile kt+1 exists: stage it during this tile
             // ---- phase 0: quadrant (0,0)
             if (st) stage8(0);
             readA8(0);
@@ -451,7 +471,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
             if (g1) { if (st) wait_vmcnt<N3>(); else wait_vmcnt<0>(); }
             __builtin_amdgcn_s_barrier();
             compute8(1, 0);
-            if (g1) wait_vmcnt<0>();
+            if (g1 || LOCK) wait_vmcnt<0>();                 // (lock step: the HA1 pieces are read by rows 128-255 in the very next interval)
             else if (st) wait_vmcnt<N3>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
@@ -546,6 +566,11 @@ int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_256x256_P8: return launch<256, 256, 2, 4, 2, 2, false, false, 3>(p, s);     // 8-phase staggered schedule, setprio around the MFMAs
         case FGT_TILE_256x128_P8: return launch<256, 128, 4, 2, 2, 2, false, false, 3>(p, s);
         case FGT_TILE_256x256_P8N: return launch<256, 256, 2, 4, 2, 2, false, false, 1>(p, s);    // the same without s_setprio (A/B)
+        case FGT_TILE_256x256_P8L: return launch<256, 256, 2, 4, 2, 2, false, false, 7>(p, s);    // the same phases in lock step (A/B)
+        case 22: return launch<256, 256, 2, 4, 2, 2, false, false, 3 + 8>(p, s);                   // timing only: no DMA in the loop
+        case 23: return launch<256, 256, 2, 4, 2, 2, false, false, 3 + 16>(p, s);                  // timing only: no MFMAs
+        case 24: return launch<256, 256, 2, 4, 2, 2, false, false, 3 + 8 + 16>(p, s);              // timing only: fragment reads + barriers
+        case 25: return launch<256, 256, 2, 4, 2, 2, false, false, 7 + 8>(p, s);                   // timing only: lock step, no DMA
         default: fgt_set_error("fgt_conv2d: unknown tile %d", tile); return FGT_EINVAL;
     }
 }

@@ -133,6 +133,7 @@ typedef struct fgt_conv_desc {
                                    * groups (one loads / issues LDS-DMA while the other owns the matrix pipe), counted vmcnt, s_setprio */
 #define FGT_TILE_256x128_P8 18    /* split inputs only: the same schedule on a 256x128 tile (8 wavefronts of 64x64) */
 #define FGT_TILE_256x256_P8N 19   /* 17 without s_setprio (A/B measurements) */
+#define FGT_TILE_256x256_P8L 20   /* 17 with both wavefront groups in lock step (A/B measurements) */
 
 int fgt_conv2d(const fgt_conv_desc* d, const void* x0, const void* x1, const float* w_packed,
                const float* cscale /* [Cout] or NULL */, const float* cbias /* [Cout] or NULL */,

@@ -34,6 +34,13 @@ LAYERS = {  # name: (N, H, W, C0, C1, Cout, groups, k, stride, pad)
     "b8 ffn1 512->1960": (1, 1, 97920, 512, 0, 1960, 1, 1, 1, 0),
     "b8 qkv  512->1536": (1, 1, 97920, 512, 0, 1536, 1, 1, 1, 0),
     "b8 proj 512->512": (1, 1, 97920, 512, 0, 512, 1, 1, 1, 0),
+    "b8 k    768->512": (1, 1, 138720, 768, 0, 512, 1, 1, 1, 0),
+    "b8 ffn2 40->512 7x7s3": (136, 60, 108, 40, 0, 512, 1, 7, 3, 3),
+    "e20 enc8  256->384 3x3": (20, 60, 108, 256, 0, 384, 1, 3, 1, 1),
+    "e20 enc10 640->512 g2": (20, 60, 108, 256, 384, 512, 2, 3, 1, 1),
+    "e20 p2v   128->512 7x7s3": (20, 60, 108, 128, 0, 512, 1, 7, 3, 3),
+    "e20 enc6 128->256": (20, 60, 108, 128, 0, 256, 1, 3, 1, 1),
+    "v2p 512->6272 (66 frames)": (1, 1, 47520, 512, 0, 6272, 1, 1, 1, 0),
 }
 TILES = ["128x128", "256x128", "128x128x8", "256x128x16", "256x64x8", "256x128x8s3", "256x128x8pp", "256x128x8il"]
 
@@ -55,7 +62,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--layers", default="")
+    ap.add_argument("--tiles", default="")
+    ap.add_argument("--split-only", action="store_true", help="time only the pre-split (planes) inputs; still checks bit equality with the 128x128 result")
     a = ap.parse_args()
+    global TILES
+    if a.tiles:
+        TILES = a.tiles.split(",")
     dev = torch.device("cuda:0")
     print(f"{'layer':26s} {'GFLOP':>7s} | " + " ".join(f"{t:>18s}" for t in TILES) + "   (TFLOP/s algorithmic: fp32-in / split planes / split interleaved)")
     for name, (N, H, W, C0, C1, Cout, g, k, s, p) in LAYERS.items():
@@ -73,18 +85,18 @@ def main():
         cells = []
         for t in TILES:
             o1, o2 = torch.empty_like(out), torch.empty_like(out)
-            if t.endswith(("s3", "s4", "pp", "il")):        # split inputs only
+            if t.endswith(("s3", "s4", "pp", "il", "p8", "p8n", "p8l")) or t.startswith("x2") or a.split_only:        # split inputs only
                 ops.conv2d(x, pc, x1=x1, stride=s, pad=p, act="lrelu", tile="128x128", precision="bf16x3", out=o1)
                 ms_a = float("inf")
             else:
                 ms_a = bench(lambda: ops.conv2d(x, pc, x1=x1, stride=s, pad=p, act="lrelu", tile=t, precision="bf16x3", out=o1), a.reps)
             ms_b = bench(lambda: ops.conv2d(xs, pc, x1=x1s, stride=s, pad=p, act="lrelu", tile=t, precision="bf16x3", out=o2), a.reps)
             ms_c = float("inf")
-            if can_il:
+            if can_il and not a.split_only:
                 o3 = torch.empty_like(out)
                 ms_c = bench(lambda: ops.conv2d(xi, pc, x1=x1i, stride=s, pad=p, act="lrelu", tile=t, precision="bf16x3", out=o3), a.reps)
                 o2 = o2 if torch.equal(o2, o3) else o2 + 1
-            eq = "" if torch.equal(o1, o2) and torch.equal(o1, out) else "!"
+            eq = "" if torch.equal(o1, o2) and torch.equal(o1, out) else "!"        # ("!" is expected for the timing-only x2* tiles)
             cells.append(f"{fl / ms_a / 1e9:5.0f}/{fl / ms_b / 1e9:5.0f}/{fl / ms_c / 1e9:5.0f}{eq:1s}")
         print(f"{name:26s} {fl / 1e9:7.1f} | " + " ".join(cells), flush=True)
         del x, x1, xs, x1s, out
