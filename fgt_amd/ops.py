@@ -628,6 +628,26 @@ def laplace_fill(maps, masks, iters=1000, tol=1e-6):
     return out
 
 
+def flow_propagate(gx, gy, mask, flow_f, flow_b, consistency_thres=5.0, alpha=0.1, tab=32):
+    """fgt_flow_propagate: gx, gy [N,H,W,3] fp32, mask [N,H,W] (non-zero = hole), flow_f / flow_b [N-1,H,W,2] fp32 ->
+    (gx, gy [N,H,W,3], mask_tofill [N,H,W] bool).  tool/get_flowNN_gradient.py:11-534 for the whole clip in one call."""
+    _require_dev(gx, gy, flow_f, flow_b)
+    N, H, W, _ = gx.shape
+    assert gy.shape == gx.shape and gx.shape[-1] == 3 and tuple(mask.shape) == (N, H, W) and mask.is_cuda
+    assert N == 1 or (tuple(flow_f.shape) == (N - 1, H, W, 2) and tuple(flow_b.shape) == (N - 1, H, W, 2))
+    gx, gy = gx.contiguous(), gy.contiguous()
+    m8 = (mask != 0).to(torch.uint8).contiguous()
+    ff = None if N == 1 else flow_f.contiguous()
+    fb = None if N == 1 else flow_b.contiguous()
+    ox, oy = torch.empty_like(gx), torch.empty_like(gy)
+    fill = torch.empty(N, H, W, dtype=torch.uint8, device=gx.device)
+    ws = torch.empty(_lib.lib().fgt_flow_propagate_workspace(N, H, W), dtype=torch.uint8, device=gx.device)
+    check(_lib.lib().fgt_flow_propagate(_ptr(gx), _ptr(gy), C.c_void_p(m8.data_ptr()), _ptr(ff), _ptr(fb), N, H, W, float(consistency_thres),
+                                        float(alpha), int(tab), _ptr(ox), _ptr(oy), C.c_void_p(fill.data_ptr()), C.c_void_p(ws.data_ptr()), _stream()),
+          "fgt_flow_propagate")
+    return ox, oy, fill.bool()
+
+
 def prof_enable(on):
     global _prof_on
     _prof_on = bool(on)

@@ -293,6 +293,21 @@ long fgt_laplace_fill_workspace(int B, int H, int W);
 int fgt_laplace_fill(const float* I, const unsigned char* mask, int B, int n_masks, int H, int W, float* out, void* workspace,
                      int iters, float tol, void* stream);
 
+/* Flow-guided gradient propagation (tool/get_flowNN_gradient.py:11-534 with Nonlocal = False; call site tool/video_inpainting.py:
+ * 623-633): for every hole pixel, chase the completed backward / forward flow through the clip to a known pixel (round-trip
+ * consistency < consistency_thres, transitive chaining through holes), take the image gradient found there (bilinear) and fuse the
+ * two candidates with weights exp(-round-trip error / alpha).  Frame-major channels-last layout:
+ *   gx, gy [N,H,W,3] fp32 (gradients, 0 inside the dilated mask), mask [N,H,W] uint8 (non-zero = hole: the tool passes its DILATED
+ *   gradient mask), flow_f / flow_b [N-1,H,W,2] fp32 (u, v): completed flows t -> t+1 / t+1 -> t.
+ *   out_gx / out_gy [N,H,W,3]; mask_tofill [N,H,W] uint8 = hole pixels that found no flow neighbour.
+ * tab: coordinate table of the bilinear sampler that stands for cv2.remap(INTER_LINEAR) (tool/utils/common_utils.py:164,250-251):
+ * 32 = OpenCV-style 1/32-pixel quantisation (the specification in oracle/prop_oracle.py), 0 = plain float bilinear.
+ * One call enqueues every launch of the clip (one per frame and sweep); workspace: fgt_flow_propagate_workspace() bytes, 8-byte aligned. */
+long fgt_flow_propagate_workspace(int N, int H, int W);
+int fgt_flow_propagate(const float* gx, const float* gy, const unsigned char* mask, const float* flow_f, const float* flow_b,
+                       int N, int H, int W, double consistency_thres, double alpha, int tab, float* out_gx, float* out_gy,
+                       unsigned char* mask_tofill, void* workspace, void* stream);
+
 /* ---- per-kernel timing with HIP events on the launch stream (bench.py's roofline blocks) ----
  * fgt_prof_enable(1) makes every fgt_conv2d (MFMA kernels) and fgt_attention launch record an event pair and its ALGORITHMIC
  * flops: conv/GEMM 2*M*Cout_g*K*groups (K before channel padding, fgt_conv_desc.k_alg); attention 4*n_q*n_k*128 per
