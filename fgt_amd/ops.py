@@ -648,6 +648,23 @@ def flow_propagate(gx, gy, mask, flow_f, flow_b, consistency_thres=5.0, alpha=0.
     return ox, oy, fill.bool()
 
 
+def poisson_blend(target, gx, gy, hole, gmask, iters=2000, tol=1e-7):
+    """fgt_poisson_blend: target, gx, gy [N,H,W,3] fp32; hole, gmask [N,H,W] (non-zero = hole / gradient unknown) ->
+    (blend [N,H,W,3], unfilled [N,H,W] bool).  tool/utils/Poisson_blend_img.py:19-244 for the whole clip."""
+    _require_dev(target, gx, gy)
+    N, H, W, _ = target.shape
+    assert gx.shape == target.shape and gy.shape == target.shape and tuple(hole.shape) == (N, H, W) and tuple(gmask.shape) == (N, H, W)
+    target, gx, gy = target.contiguous(), gx.contiguous(), gy.contiguous()
+    h8, g8 = (hole != 0).to(torch.uint8).contiguous(), (gmask != 0).to(torch.uint8).contiguous()
+    out = torch.empty_like(target)
+    unf = torch.empty(N, H, W, dtype=torch.uint8, device=target.device)
+    ws = torch.empty(_lib.lib().fgt_poisson_blend_workspace(N, H, W), dtype=torch.uint8, device=target.device)
+    check(_lib.lib().fgt_poisson_blend(_ptr(target), _ptr(gx), _ptr(gy), C.c_void_p(h8.data_ptr()), C.c_void_p(g8.data_ptr()), N, H, W,
+                                       int(iters), float(tol), _ptr(out), C.c_void_p(unf.data_ptr()), C.c_void_p(ws.data_ptr()), _stream()),
+          "fgt_poisson_blend")
+    return out, unf.bool()
+
+
 def prof_enable(on):
     global _prof_on
     _prof_on = bool(on)

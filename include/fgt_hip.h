@@ -308,6 +308,20 @@ int fgt_flow_propagate(const float* gx, const float* gy, const unsigned char* ma
                        int N, int H, int W, double consistency_thres, double alpha, int tab, float* out_gx, float* out_gy,
                        unsigned char* mask_tofill, void* workspace, void* stream);
 
+/* Poisson blending of propagated gradients into the frames (tool/utils/Poisson_blend_img.py:19-244; call site
+ * tool/video_inpainting.py:644-682), all frames and colour channels of a clip in one call: per hole pixel up to four equations
+ * (x_p - x_q = gradient, or x_p = target_q + gradient next to a known pixel) for the neighbours whose gradient lies outside
+ * `gmask`; the least-squares solution (the reference: scipy LSQR per frame and channel) by batched conjugate gradients on the
+ * normal equations, `iters` iterations always enqueued, a problem freezes at residual <= tol * |r0|.
+ *   target [N,H,W,3] fp32 (0..1), gx / gy [N,H,W,3] (gx[y][x] = I[y][x+1] - I[y][x]; last column / row ignored),
+ *   hole / gmask [N,H,W] uint8 (non-zero = hole / gradient unknown).
+ *   blend [N,H,W,3] = solution inside the hole, target outside; unfilled [N,H,W] uint8 = UnfilledMask (:143-168): hole pixels the
+ *   two raster sweeps cannot reach through valid gradients (the tool repaints them).
+ * workspace: fgt_poisson_blend_workspace() bytes, 8-byte aligned.  Bit-reproducible (ordered reductions). */
+long fgt_poisson_blend_workspace(int N, int H, int W);
+int fgt_poisson_blend(const float* target, const float* gx, const float* gy, const unsigned char* hole, const unsigned char* gmask,
+                      int N, int H, int W, int iters, float tol, float* blend, unsigned char* unfilled, void* workspace, void* stream);
+
 /* ---- per-kernel timing with HIP events on the launch stream (bench.py's roofline blocks) ----
  * fgt_prof_enable(1) makes every fgt_conv2d (MFMA kernels) and fgt_attention launch record an event pair and its ALGORITHMIC
  * flops: conv/GEMM 2*M*Cout_g*K*groups (K before channel padding, fgt_conv_desc.k_alg); attention 4*n_q*n_k*128 per
