@@ -288,11 +288,46 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
         key = (N, H, W, C0, C1, pc.Cout, pc.groups, pc.kh, pc.kw, sh, sw, ph, pw, dh, dw, d.upsample, d.epi, d.out_nchw, d.precision,
                d.in_split, d.out_split, d.w_il, int(bool(osp) and out_s.il))
         best = _tile_cache.get(key)
-        if best is None:
+        if best is None and not torch.cuda.is_current_stream_capturing() and not _aliases(out, out_s, x, x1, aux1, aux2):
+            # (tuning re-launches the kernel into the caller's buffers and synchronises: illegal under stream capture, and it would
+            #  corrupt an output that aliases an input / aux operand — such calls run on the static tile and are not cached)
             best = _tile_cache[key] = _autotune(d, args)
-        d.tile = best
+        d.tile = best or 0
     check(_lib.lib().fgt_conv2d(*args, _stream()), "fgt_conv2d")
     return {0: out, 1: out_s, 2: (out, out_s)}[osp]
+
+
+def _aliases(out, out_s, *ins):
+    """True when an output buffer overlaps one of the input / aux tensors (in-place epilogues).  Channel slices of one wide
+    channels-last buffer (same row stride, disjoint channel windows: the concat buffers of RAFT / the token buffers) do not overlap."""
+    def box(t):
+        if t is None:
+            return None
+        t = t.data if isinstance(t, Split) else t
+        if t.numel() == 0:
+            return None
+        lo = t.storage_offset()
+        hi = lo + sum((n - 1) * st for n, st in zip(t.shape, t.stride())) + 1             # element range inside the storage
+        ld = max([st for n, st in zip(t.shape[:-1], t.stride()[:-1]) if n > 1 and st > 0], default=0)
+        ld = min([st for n, st in zip(t.shape[:-1], t.stride()[:-1]) if n > 1 and st > 0], default=0) if ld else 0
+        return (t.untyped_storage().data_ptr(), t.element_size(), lo, hi, ld, t.shape[-1] if t.dim() else 1)
+
+    def overlap(a, b):
+        if a[0] != b[0] or a[1] != b[1]:
+            # different storages (or element sizes): compare byte ranges
+            a0, a1 = a[0] + a[2] * a[1], a[0] + a[3] * a[1]
+            b0, b1 = b[0] + b[2] * b[1], b[0] + b[3] * b[1]
+            return a0 < b1 and b0 < a1
+        if not (a[2] < b[3] and b[2] < a[3]):
+            return False
+        if a[4] and a[4] == b[4] and a[5] <= a[4] and b[5] <= b[4]:                       # same pixel stride: compare channel windows
+            ca, cb = a[2] % a[4], b[2] % b[4]
+            if ca + a[5] <= a[4] and cb + b[5] <= b[4]:
+                return ca < cb + b[5] and cb < ca + a[5]
+        return True
+
+    outs = [o for o in (box(out), box(out_s)) if o]
+    return any(overlap(o, i) for o in outs for i in (box(t) for t in ins) if i)
 
 
 def _autotune(d, args):

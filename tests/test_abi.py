@@ -63,3 +63,16 @@ def test_bench_and_smoke_fail_loudly_without_a_gpu():
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "needs the MI355X" in (r.stderr + r.stdout)
+
+
+def test_autotune_alias_guard():
+    """ops._aliases decides whether a conv may be tile-tuned in place (the tuner re-launches into the caller's output): outputs that
+    overlap an input / aux operand must be detected, disjoint channel or row slices of one buffer must not."""
+    import torch
+    from fgt_amd import ops
+    buf = torch.zeros(6, 5, 384)
+    assert not ops._aliases(buf[..., :128], None, buf[..., 128:]) and ops._aliases(buf[..., :128], None, buf[..., :128])
+    assert ops._aliases(buf[..., :200], None, None, buf[..., 128:])
+    rows = torch.zeros(100, 64)
+    assert not ops._aliases(rows[:50], None, rows[50:]) and ops._aliases(rows[:60], None, rows[50:])
+    assert not ops._aliases(torch.zeros(3, 4), None, rows) and not ops._aliases(None, None, rows)

@@ -112,7 +112,7 @@ def test_tool_chain_over_dropins_matches_fast_paths(dev, tmp_path):
     assert type(RAFT_model).__module__ == "fgt_amd.raft_model" and type(LAFC_model).__module__ == "fgt_amd.lafc_model"
     assert type(FGT_model).__module__ == "fgt_amd.fgt_model"
 
-    N, H, W = 20, 64, 96
+    N, H, W = 20, 128, 160                                                # (RAFT's 4-level correlation pyramid needs H, W >= 128)
     frames01, _, masks = synth_clip(N, H, W, seed=21, device=dev)
     video = frames01[0] * 255.0                                           # [N,3,H,W] 0..255
     # ---- step 2: RAFT pair by pair (tool) vs per-frame encoder cache + batched pairs
@@ -142,8 +142,9 @@ def test_tool_chain_over_dropins_matches_fast_paths(dev, tmp_path):
     hole = flow_mask
     gx = np.concatenate((np.diff(vid, axis=1), np.zeros((H, 1, 3, N), np.float32)), 1)
     gy = np.concatenate((np.diff(vid, axis=0), np.zeros((1, W, 3, N), np.float32)), 0)
-    gx[hole] = 0
-    gy[hole] = 0
+    h4 = np.broadcast_to(hole[:, :, None, :], gx.shape)
+    gx[h4] = 0
+    gy[h4] = 0
     pargs = argparse.Namespace(Nonlocal=False, consistencyThres=5.0, alpha=0.1)
     gxf, gyf, mgrad = propagation.get_flowNN_gradient(pargs, gx, gy, hole, hole, videoFlowF, videoFlowB, None, None)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(np.moveaxis(a, -1, 0))).to(dev)
