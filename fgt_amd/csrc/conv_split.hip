@@ -565,12 +565,14 @@ int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_256x128x8_IL: return launch<256, 128, 4, 2, 2, 2, false, true>(p, s);
         case FGT_TILE_256x256_P8: return launch<256, 256, 2, 4, 2, 2, false, false, 3>(p, s);     // 8-phase staggered schedule, setprio around the MFMAs
         case FGT_TILE_256x128_P8: return launch<256, 128, 4, 2, 2, 2, false, false, 3>(p, s);
-        case FGT_TILE_256x256_P8N: return launch<256, 256, 2, 4, 2, 2, false, false, 1>(p, s);    // the same without s_setprio (A/B)
-        case FGT_TILE_256x256_P8L: return launch<256, 256, 2, 4, 2, 2, false, false, 7>(p, s);    // the same phases in lock step (A/B)
-        case 22: return launch<256, 256, 2, 4, 2, 2, false, false, 3 + 8>(p, s);                   // timing only: no DMA in the loop
+#ifdef FGT_P8_ABLATIONS   // A/B and timing-only instances behind profiles/r02_run3_split_sweep_p8*.txt (build with -DFGT_P8_ABLATIONS to reproduce)
+        case FGT_TILE_256x256_P8N: return launch<256, 256, 2, 4, 2, 2, false, false, 1>(p, s);    // without s_setprio
+        case FGT_TILE_256x256_P8L: return launch<256, 256, 2, 4, 2, 2, false, false, 7>(p, s);    // the same phases in lock step
+        case 22: return launch<256, 256, 2, 4, 2, 2, false, false, 3 + 8>(p, s);                   // timing only (wrong results): no DMA in the loop
         case 23: return launch<256, 256, 2, 4, 2, 2, false, false, 3 + 16>(p, s);                  // timing only: no MFMAs
         case 24: return launch<256, 256, 2, 4, 2, 2, false, false, 3 + 8 + 16>(p, s);              // timing only: fragment reads + barriers
         case 25: return launch<256, 256, 2, 4, 2, 2, false, false, 7 + 8>(p, s);                   // timing only: lock step, no DMA
+#endif
         default: fgt_set_error("fgt_conv2d: unknown tile %d", tile); return FGT_EINVAL;
     }
 }
