@@ -33,33 +33,40 @@ def _install(tab=32):
         cv2.setNumThreads = lambda n: None
         cv2.ocl = types.SimpleNamespace(setUseOpenCL=lambda x: None)
     sys.modules["cv2"] = cv2
+
+
+_cache = {}
+
+
+def _import_from_tool(name):
+    """Import `name` with tool/ FIRST on sys.path and no foreign `utils` package in sys.modules (RAFT, FGT and LAFC each ship a
+    top-level `utils` / `models`; other tests put those trees on sys.path), then restore both."""
+    if name in _cache:
+        return _cache[name]
     tool = os.path.join(REF, "tool")
-    if tool not in sys.path:
-        sys.path.insert(0, tool)
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "utils" or k.startswith("utils.")}
+    sys.path.insert(0, tool)
+    try:
+        mod = importlib.import_module(name)
+    finally:
+        sys.path.remove(tool)
+        for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+            sys.modules.pop(k)
+        sys.modules.update(saved)
+    _cache[name] = mod
+    return mod
 
 
 def get_flownn_gradient_fn(tab=32):
     """The reference function `get_flowNN_gradient(args, gradient_x, gradient_y, mask_RGB, mask, videoFlowF, videoFlowB, None, None)`."""
     _install(tab)
-    saved = sys.modules.pop("utils", None)          # `utils` must resolve to tool/utils here (RAFT has a package of that name too)
-    try:
-        mod = importlib.import_module("get_flowNN_gradient")
-    finally:
-        if saved is not None:
-            sys.modules["utils"] = saved
-    return mod.get_flowNN_gradient
+    return _import_from_tool("get_flowNN_gradient").get_flowNN_gradient
 
 
 def poisson_blend_fn():
     """The reference function `Poisson_blend_img(imgTrg, imgSrc_gx, imgSrc_gy, holeMask, gradientMask)` (scipy lsqr inside)."""
     _install()
-    saved = sys.modules.pop("utils", None)
-    try:
-        mod = importlib.import_module("utils.Poisson_blend_img")
-    finally:
-        if saved is not None:
-            sys.modules["utils"] = saved
-    return mod.Poisson_blend_img
+    return _import_from_tool("utils.Poisson_blend_img").Poisson_blend_img
 
 
 def run_get_flownn_gradient(gx, gy, mask, flow_f, flow_b, thres=5.0, alpha=0.1, tab=32):
