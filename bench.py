@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
+PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured with a float4 copy)
 KERNELS = {"conv": "conv_split_kernel / conv_igemm_kernel (implicit-GEMM conv + every Linear; all fgt_conv2d MFMA launches)",
            "attn_temporal": "attn_bf16x3_kernel<8,true> / attn_kernel<4> (temporal zone attention, fgt_attention mode 0)",
            "attn_spatial": "attn_bf16x3_kernel<2,false> / attn_kernel<2> (spatial window + global-token attention, fgt_attention mode 1)"}
@@ -203,8 +204,8 @@ def main():
                 scale = args.steps
             ops.prof_enable(False)
             for k in KERNELS:
-                ms, fl, n = ops.prof_collect(k)
-                kinds[k] = (ms * scale, fl * scale, n * scale)
+                ms, fl, n, by = ops.prof_collect(k)
+                kinds[k] = (ms * scale, fl * scale, n * scale, by * scale)
         return max_over_ranks(dt), host_dt, comp, kinds
 
     def rooflines(kinds, prec, dt):
@@ -212,12 +213,16 @@ def main():
         peak = PEAK_FP32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
         traffic = kernel_traffic(prec)
         out = []
-        for k, (ms, fl, n) in kinds.items():
+        for k, (ms, fl, n, by) in kinds.items():
             if ms <= 0 or n == 0:
                 continue
             ach = passes * fl / (ms * 1e-3) / 1e12
-            out.append({"bound": "mfma", "kernel": KERNELS[k], "kind": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": traffic.get(k, {}).get("hbm_bytes_per_launch"),
+            gbs = by / (ms * 1e-3) / 1e9
+            # the same launches on the HBM roofline: unique bytes (every input / weight / output byte once) over the same time
+            hbm = {"algorithmic_GBps": round(gbs, 1), "peak_GBps": PEAK_HBM_GBPS, "frac": round(gbs / PEAK_HBM_GBPS, 4), "bytes_per_launch": round(by / n)}
+            out.append({"bound": "mfma" if ach / peak >= gbs / PEAK_HBM_GBPS else "hbm (closer to the HBM roof than to the MFMA roof: see `hbm`)",
+                        "kernel": KERNELS[k], "kind": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "hbm": hbm, "traffic": traffic.get(k, {}).get("hbm_bytes_per_launch"),
                         "algorithmic_tflops": round(fl / (ms * 1e-3) / 1e12, 2), "mfma_passes_per_product": passes,
                         "launches": n, "avg_launch_us": round(1e3 * ms / n, 2), "kernel_ms_per_step": round(ms / args.steps, 3),
                         "share_of_step": round(ms / (1e3 * dt), 3)})

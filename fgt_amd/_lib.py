@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
 class AttnDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("mode", "b", "t", "h", "w", "nh", "nw", "heads", "group", "ws", "n_global",
                                        "ldq", "qoff", "ldk", "koff", "ldv", "voff", "ldg_k", "ldg_v", "ldo", "precision", "out_split")] + \
-               [("pso", C.c_longlong)]
+               [("pso", C.c_longlong)] + [(n, C.c_int) for n in ("in_split", "reserved1")] + \
+               [(n, C.c_longlong) for n in ("psq", "psk", "psv", "psg_k", "psg_v")]
 
 
 _P = C.c_void_p
@@ -76,7 +77,7 @@ SIGNATURES = {
     "fgt_poisson_blend": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "fgt_prof_enable": [_I],
     "fgt_prof_collect": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)],
-    "fgt_prof_collect_kind": [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)],
+    "fgt_prof_collect_kind": [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)],
 }
 _RESTYPES = {"fgt_last_error": C.c_char_p, "fgt_prof_enable": None, "fgt_laplace_fill_workspace": C.c_long, "fgt_flow_propagate_workspace": C.c_long, "fgt_poisson_blend_workspace": C.c_long}
 

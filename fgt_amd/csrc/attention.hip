@@ -468,13 +468,20 @@ bool attn_nw8() {
 
 }  // namespace
 
-extern "C" int fgt_attention(const fgt_attn_desc* dd, const float* Q, const float* K, const float* V,
-                             const float* KG, const float* VG, float* O, void* stream) {
-    FGT_REQUIRE(dd && Q && K && V && O, "fgt_attention: null pointer");
+// attention_split.hip
+int fgt_attention_split(const fgt_attn_desc* dd, const void* Q, const void* K, const void* V, const void* KG, const void* VG, float* O,
+                        int n_q, int n_k, int n_loc, int zh, int zw, int gh, int gw, int problems, float scale_log2e, hipStream_t s);
+
+extern "C" int fgt_attention(const fgt_attn_desc* dd, const void* Qv, const void* Kv, const void* Vv,
+                             const void* KGv, const void* VGv, float* O, void* stream) {
+    FGT_REQUIRE(dd && Qv && Kv && Vv && O, "fgt_attention: null pointer");
+    const float *Q = static_cast<const float*>(Qv), *K = static_cast<const float*>(Kv), *V = static_cast<const float*>(Vv);
+    const float *KG = static_cast<const float*>(KGv), *VG = static_cast<const float*>(VGv);
     AttnP p;
     p.d = *dd;
     const fgt_attn_desc& d = p.d;
     FGT_REQUIRE(d.heads > 0 && d.nh > 0 && d.nw > 0 && d.b > 0 && d.t > 0, "fgt_attention: bad sizes");
+    FGT_REQUIRE(d.in_split == 0 || d.in_split == 1, "fgt_attention: in_split must be 0 or 1");
     FGT_REQUIRE(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.ldo % 4 == 0 && d.qoff % 4 == 0 &&
                 d.koff % 4 == 0 && d.voff % 4 == 0, "fgt_attention: strides/offsets must be multiples of 4 floats");
     FGT_REQUIRE((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)KG | (uintptr_t)VG) & 15) == 0,
@@ -503,8 +510,16 @@ extern "C" int fgt_attention(const fgt_attn_desc* dd, const float* Q, const floa
     hipStream_t s = (hipStream_t)stream;
     FGT_REQUIRE(d.precision == 0 || d.precision == 1, "fgt_attention: unknown precision %d", d.precision);
     FGT_REQUIRE(d.out_split == 0 || (d.out_split == 1 && d.pso > 0 && d.pso % 4 == 0), "fgt_attention: bad out_split / pso");
+    // unique-byte floor: every Q, K, V row of the maps and every global token once, the output once (4 B per value)
+    const double rows_in = (double)d.b * d.t * d.nh * d.nw, cc = (double)d.heads * HD;
+    const double attn_bytes = 4.0 * cc * (3.0 * rows_in + (d.mode == 1 ? 2.0 * d.b * d.t * d.n_global + (double)d.b * d.t * d.h * d.w : rows_in));
     const int prof = fgt_prof_begin(d.mode == 0 ? FGT_PROF_ATTN_TEMPORAL : FGT_PROF_ATTN_SPATIAL,
-                                    4.0 * (double)p.n_q * p.n_k * HD * problems, s);
+                                    4.0 * (double)p.n_q * p.n_k * HD * problems, attn_bytes, s);
+    if (d.in_split) {
+        const int rc = fgt_attention_split(dd, Qv, Kv, Vv, KGv, VGv, O, p.n_q, p.n_k, p.n_loc, p.zh, p.zw, p.gh, p.gw, problems, p.scale_log2e, s);
+        fgt_prof_end(prof, s);
+        return rc;
+    }
     if (p.n_q <= 64) {
         dim3 grid(cdiv(p.n_q, 64), problems);
         if (d.precision == 0) hipLaunchKernelGGL((attn_kernel<2>), grid, dim3(128), 0, s, p);

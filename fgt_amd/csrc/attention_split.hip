@@ -1,0 +1,320 @@
+// bf16x3 flash attention on PRE-SPLIT operands: Q, K, V arrive as hi/lo bf16 planes (written once by the projection GEMM's epilogue,
+// fgt_conv_desc.out_split), K and V tiles are streamed global -> LDS by LDS-DMA, and V is consumed in its natural [key][d] layout
+// through gfx950's transposing LDS read.  Same arithmetic family as attn_bf16x3_kernel (attention.hip): every product is three
+// v_mfma_f32_32x32x16_bf16 on hi/lo operands with fp32 accumulation, base-2 online softmax, both contractions issued "swapped" so a
+// lane keeps its query from QK^T to PV — but no conversion work is left in the kernel:
+//   * attn_bf16x3_kernel re-split the K and V tiles of a zone in EVERY 256-query workgroup (12 times per zone at t = 17) through
+//     registers (16 global loads + ~56 VALU + 4 LDS stores per thread and tile) and transposed V on the way;
+//   * here a tile is 4 LDS-DMA instructions per wavefront (K hi, K lo, V hi, V lo: four key rows of 256 bytes each), issued one tile
+//     ahead into the other LDS stage, so the copy of tile i+1 runs under the MFMAs of tile i with ONE barrier per tile.
+// The one arithmetic difference to attn_bf16x3_kernel: Q is stored unscaled, so log2(e)/sqrt(d) multiplies the fp32 scores after the
+// contraction (the reference's order: attention_base.py:17-18 scales QK^T) instead of the fp32 queries before their split.
+//
+// LDS image of a stage: [K hi | K lo | V hi | V lo], each 32 key rows x 128 bf16 (256 bytes).  DMA writes are lane-linear (16 bytes per
+// lane, 4 rows per instruction), so the bank swizzles are applied on the SOURCE side and undone by the readers:
+//   K  (ds_read_b128, rows = lanes):       16-byte chunk c of row r sits in slot  c ^ (r & 15)
+//   V  (ds_read_b64_tr_b16, 4 rows x 32 B): 32-byte segment s of row r sits in segment  s ^ ((r & 3) << 1)
+// ds_read_b64_tr_b16 (probed on the MI355X, tools/micro/tr_probe.hip): within a 16-lane group, lane i receives element (i & 3) of the
+// 8-byte words read by lanes (i >> 2) + 4k, k = 0..3.  With lane j pointing at V[key0 + (j >> 2)][d0 + 4 (j & 3)] the group reads a
+// [4 keys][16 d] block and lane i gets V[key0 .. key0+3][d0 + i]: the 4 consecutive keys of one d that half an MFMA operand needs.
+// The PV operand of this kernel takes its 8 keys as two such runs: key(e = 8ks + j, h) = 16ks + 4h + (j & 3) + 8 (j >> 2).
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+constexpr int HD = 128, KT = 32;
+constexpr int PLANE = KT * HD * 2;        // bytes of one 32 x 128 bf16 plane
+constexpr int STAGE = 4 * PLANE;          // K hi, K lo, V hi, V lo
+
+struct AttnS {
+    fgt_attn_desc d;
+    const __bf16 *Q, *K, *V, *KG, *VG;    // hi planes; lo planes ps* elements further
+    float* O;
+    long psq, psk, psv, psgk, psgv;
+    int n_q, n_k, zh, zw, gh, gw, n_loc;
+    float scale_log2e;
+};
+
+struct Prob { int frame0, zi, zj, hd; };
+
+__device__ __forceinline__ int local_pix(const AttnS& p, const Prob& pr, int n) {
+    const fgt_attn_desc& d = p.d;
+    if (d.mode == 0) {
+        const int zsz = p.zh * p.zw;
+        const int tt = n / zsz, rem = n - tt * zsz;
+        const int i = rem / p.zw, j = rem - i * p.zw;
+        return ((pr.frame0 + tt) * d.nh + pr.zi * p.zh + i) * d.nw + pr.zj * p.zw + j;
+    }
+    const int a = n / d.ws, b = n - a * d.ws;
+    return (pr.frame0 * d.nh + pr.zi * d.ws + a) * d.nw + pr.zj * d.ws + b;
+}
+
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const f32x2 v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2 l = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xFFFF0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(l, bf16x2));
+}
+
+struct U4 { unsigned x, y, z, w; };
+__device__ __forceinline__ bf16x8 as_bf16x8(unsigned a, unsigned b, unsigned c, unsigned d) {
+    const U4 u = {a, b, c, d};
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+struct S8 { s16x4 a, b; };
+__device__ __forceinline__ bf16x8 tr_pair(const char* lds_lo_run, const char* lds_hi_run) {
+    // two transposing reads: keys run 0 (j = 0..3) and run 1 (j = 4..7) of this lane's d
+    S8 r;
+    r.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_lo_run);
+    r.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_hi_run);
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
+    constexpr int NT = NW * 64;
+    constexpr int PPW = 32 / NW;                 // DMA pieces (4 key rows of one plane) per wavefront and tile
+    static_assert(32 % NW == 0, "pieces per wavefront");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [2 stages][STAGE] tiles, then the row-address tables of the two stages: k / v hi-plane byte addresses of the 32 keys
+    unsigned long* ktab = reinterpret_cast<unsigned long*>(smem + 2 * STAGE);
+    unsigned long* vtab = ktab + 2 * KT;
+
+    const fgt_attn_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    Prob pr;
+    {
+        int y = blockIdx.y;
+        pr.hd = y % d.heads; y /= d.heads;
+        if (d.mode == 0) {
+            pr.zj = y % d.group; y /= d.group;
+            pr.zi = y % d.group; y /= d.group;
+            pr.frame0 = y * d.t;
+        } else {
+            pr.zj = y % p.gw; y /= p.gw;
+            pr.zi = y % p.gh; y /= p.gh;
+            pr.frame0 = y;
+        }
+    }
+    const int choff = pr.hd * HD;
+
+    // row addresses of tile `tile` into table slot `slot` (threads 0..31; keys past the end clamp to the last one and are masked later)
+    auto key_pointers = [&](int tile, int slot) {
+        if (tid < KT) {
+            const int key = min(tile * KT + tid, p.n_k - 1);
+            const __bf16 *kr, *vr;
+            if (key < p.n_loc) {
+                const long pix = local_pix(p, pr, key);
+                kr = p.K + pix * d.ldk + d.koff + choff;
+                vr = p.V + pix * d.ldv + d.voff + choff;
+            } else {
+                const long gr = (long)pr.frame0 * d.n_global + (key - p.n_loc);
+                kr = p.KG + gr * d.ldg_k + choff;
+                vr = p.VG + gr * d.ldg_v + choff;
+            }
+            ktab[slot * KT + tid] = reinterpret_cast<unsigned long>(kr);
+            vtab[slot * KT + tid] = reinterpret_cast<unsigned long>(vr);
+        }
+    };
+    const bool glob_tile_possible = d.mode == 1;
+    // this wavefront's DMA pieces of a tile: piece q = wave + i * NW -> plane q / 8 (K hi, K lo, V hi, V lo), rows 4 (q % 8) .. + 3
+    auto issue_tile = [&](int tile, int slot) {
+        char* st = smem + slot * STAGE;
+        const int rsub = lane >> 4, pc = lane & 15;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = wave + i * NW, plane = q >> 3, grp = q & 7;
+            const int R = grp * 4 + rsub;
+            const bool isv = plane >= 2, islo = plane & 1;
+            const unsigned long base = (isv ? vtab : ktab)[slot * KT + R];
+            const int c = isv ? ((((pc >> 1) ^ ((R & 3) << 1)) << 1) | (pc & 1)) : (pc ^ (R & 15));       // logical 16-byte chunk this lane fetches
+            long ps = isv ? p.psv : p.psk;
+            if (glob_tile_possible && min(tile * KT + R, p.n_k - 1) >= p.n_loc) ps = isv ? p.psgv : p.psgk;   // global tokens live in their own tensors
+            const unsigned long src = base + (unsigned long)c * 16 + (islo ? (unsigned long)ps * 2 : 0ul);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(st + plane * PLANE + grp * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- Q rows into registers, already split: step s holds d = 16s + 8h + (0..7) of the hi and the lo plane
+    const int qi = blockIdx.x * (NW * 32) + wave * 32 + l31;
+    const int qpix = local_pix(p, pr, min(qi, p.n_q - 1));
+    bf16x8 qh[8], ql[8];
+    {
+        const __bf16* qp = p.Q + (long)qpix * d.ldq + d.qoff + choff + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            qh[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+            ql[s] = *reinterpret_cast<const bf16x8*>(qp + p.psq + 16 * s);
+        }
+    }
+
+    f32x16 o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (p.n_k + KT - 1) / KT;
+    key_pointers(0, 0);
+    __syncthreads();
+    issue_tile(0, 0);
+
+    // per-lane LDS offsets of the operand reads (stage-relative)
+    const int krow = l31 * 256;                                             // K: row l31, chunk (2 st + lh) ^ (l31 & 15)
+    // V (transposing read): group gi = lane >> 4: d block (gi & 1) * 16, key half lh = gi >> 1; lane j = lane & 15 -> key row (j >> 2), 8-byte word (j & 3)
+    const int gi = lane >> 4, j16 = lane & 15;
+    const int vrow_in = j16 >> 2, vword = j16 & 3;
+
+    for (int it = 0; it < ntiles; ++it) {
+        const int slot = it & 1;
+        if (it + 1 < ntiles) key_pointers(it + 1, slot ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wavefront's pieces of tile `it` have landed
+        __builtin_amdgcn_s_barrier();                                       // ... everyone's have; tile it-1 is fully consumed; table slot^1 is visible
+        if (it + 1 < ntiles) issue_tile(it + 1, slot ^ 1);                  // streams under the MFMAs below
+        const char* st = smem + slot * STAGE;
+        const int k0 = it * KT;
+
+        // ---- S^T tile = K . Q^T
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int sx = 0; sx < 8; ++sx) {
+            const int off = krow + (((2 * sx + lh) ^ (l31 & 15)) << 4);
+            const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(st + off);
+            const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(st + PLANE + off);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, qh[sx], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, ql[sx], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, qh[sx], s, 0, 0, 0);
+        }
+        // ---- online softmax in base 2 (scale applied to the fp32 scores), keys of this lane: k0 + (e&3) + 8*(e>>2) + 4*lh
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const float v = key < p.n_k ? s[e] * p.scale_log2e : -INFINITY;
+            s[e] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float pe = __builtin_amdgcn_exp2f(s[e] - m_new);
+            s[e] = pe;
+            psum += pe;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        // the running maximum settles after a few tiles: when NO query of this wavefront saw a new one, alpha is exactly 1 for all of
+        // them and the 64 multiplies are skipped (bit-identical: x * 1.0f == x)
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
+        }
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+            split2(s[8 * ks + 0], s[8 * ks + 1], h0, l0); split2(s[8 * ks + 2], s[8 * ks + 3], h1, l1);
+            split2(s[8 * ks + 4], s[8 * ks + 5], h2, l2); split2(s[8 * ks + 6], s[8 * ks + 7], h3, l3);
+            const bf16x8 p_h = as_bf16x8(h0, h1, h2, h3), p_l = as_bf16x8(l0, l1, l2, l3);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                // run 0: keys 16ks + 4lh + (0..3); run 1: + 8.  row & 3 = vrow_in for both (16ks, 4lh, 8 are multiples of 4)
+                const int seg = (t * 2 + (gi & 1)) ^ (vrow_in << 1);        // swizzled 32-byte segment of d block t*32 + 16 (gi & 1)
+                const int r0 = 16 * ks + 4 * (gi >> 1) + vrow_in;
+                const int a0 = r0 * 256 + seg * 32 + vword * 8, a1 = a0 + 8 * 256;
+                const bf16x8 v_h = tr_pair(st + 2 * PLANE + a0, st + 2 * PLANE + a1);
+                const bf16x8 v_l = tr_pair(st + 3 * PLANE + a0, st + 3 * PLANE + a1);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_l, p_h, o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h, p_l, o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h, p_h, o[t], 0, 0, 0);
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_tot;
+    if (qi < p.n_q) {
+        long orow;
+        bool keep = true;
+        if (d.mode == 0) {
+            orow = qpix;
+        } else {
+            const int fr = qpix / (d.nh * d.nw), rem = qpix - fr * (d.nh * d.nw);
+            const int y = rem / d.nw, x = rem - y * d.nw;
+            keep = y < d.h && x < d.w;
+            orow = ((long)fr * d.h + y) * d.w + x;
+        }
+        if (keep) {
+            const long ob = orow * d.ldo + choff + 4 * lh;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const float4 v = make_float4(o[t][4 * e4 + 0] * inv, o[t][4 * e4 + 1] * inv, o[t][4 * e4 + 2] * inv, o[t][4 * e4 + 3] * inv);
+                    if (d.out_split) {
+                        uint2 hi, lo;
+                        fgt_split4(v, hi, lo);
+                        __bf16* o16 = reinterpret_cast<__bf16*>(p.O) + ob + t * 32 + 8 * e4;
+                        *reinterpret_cast<uint2*>(o16) = hi;
+                        *reinterpret_cast<uint2*>(o16 + d.pso) = lo;
+                    } else {
+                        *reinterpret_cast<float4*>(p.O + ob + t * 32 + 8 * e4) = v;
+                    }
+                }
+        }
+    }
+}
+
+template <int NW>
+int launch(const AttnS& p, int problems, hipStream_t s) {
+    constexpr int smem = 2 * STAGE + 4 * KT * (int)sizeof(unsigned long);
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<NW>), smem, lds_set, "attn_split")) return rc;
+    dim3 grid(cdiv(p.n_q, NW * 32), problems);
+    hipLaunchKernelGGL((attn_split_kernel<NW>), grid, dim3(NW * 64), smem, s, p);
+    return fgt_check_launch("attn_split_kernel");
+}
+
+}  // namespace
+
+// called by fgt_attention (attention.hip) when desc.in_split is set
+int fgt_attention_split(const fgt_attn_desc* dd, const void* Q, const void* K, const void* V, const void* KG, const void* VG, float* O,
+                        int n_q, int n_k, int n_loc, int zh, int zw, int gh, int gw, int problems, float scale_log2e, hipStream_t s) {
+    AttnS p;
+    p.d = *dd;
+    const fgt_attn_desc& d = p.d;
+    FGT_REQUIRE(d.precision == FGT_PREC_BF16X3, "fgt_attention: split inputs need FGT_PREC_BF16X3");
+    FGT_REQUIRE(d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldv % 8 == 0 && d.qoff % 8 == 0 && d.koff % 8 == 0 && d.voff % 8 == 0 &&
+                d.psq % 8 == 0 && d.psk % 8 == 0 && d.psv % 8 == 0 && d.psq > 0 && d.psk > 0 && d.psv > 0,
+                "fgt_attention: split inputs need strides / offsets / plane strides that are positive multiples of 8 bf16 elements");
+    FGT_REQUIRE(d.n_global == 0 || (d.ldg_k % 8 == 0 && d.ldg_v % 8 == 0 && d.psg_k % 8 == 0 && d.psg_v % 8 == 0 && d.psg_k > 0 && d.psg_v > 0),
+                "fgt_attention: split global tokens need strides / plane strides that are positive multiples of 8");
+    p.Q = static_cast<const __bf16*>(Q); p.K = static_cast<const __bf16*>(K); p.V = static_cast<const __bf16*>(V);
+    p.KG = static_cast<const __bf16*>(KG); p.VG = static_cast<const __bf16*>(VG); p.O = O;
+    p.psq = d.psq; p.psk = d.psk; p.psv = d.psv; p.psgk = d.psg_k; p.psgv = d.psg_v;
+    p.n_q = n_q; p.n_k = n_k; p.n_loc = n_loc; p.zh = zh; p.zw = zw; p.gh = gh; p.gw = gw;
+    p.scale_log2e = scale_log2e;
+    if (n_q <= 64) return launch<2>(p, problems, s);
+    if (n_q >= 2048) return launch<8>(p, problems, s);
+    return launch<4>(p, problems, s);
+}

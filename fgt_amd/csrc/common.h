@@ -13,7 +13,7 @@ void fgt_set_error(const char* fmt, ...);
 
 // runtime.hip: per-launch event timing (no-ops returning -1 unless fgt_prof_enable(1))
 bool fgt_prof_on();
-int fgt_prof_begin(int kind, double flops, hipStream_t s);
+int fgt_prof_begin(int kind, double flops, double bytes, hipStream_t s);
 void fgt_prof_end(int idx, hipStream_t s);
 
 #define FGT_REQUIRE(cond, ...)          \

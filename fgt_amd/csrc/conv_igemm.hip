@@ -395,7 +395,10 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     const bool direct = d.tile == 0 && d.precision == 0 && d.out_split == 0 && fgt_conv_direct_eligible(p);
     // roofline accounting is about the MFMA kernels only; algorithmic flops use the UNPADDED K (flow 2 -> 4, RGB 3 -> 4 channel
     // padding is not work the reference does): desc.k_alg = kh*kw*Cin_real/groups, 0 = the padded K
-    const int prof = direct ? -1 : fgt_prof_begin(FGT_PROF_CONV, 2.0 * (double)M * p.Cout_g * (d.k_alg > 0 ? d.k_alg : p.K) * d.groups, s);
+    // unique-byte floor: input map(s) once (4 B per value, fp32 or hi + lo), weights once, every output form once, aux operands once
+    const double conv_bytes = 4.0 * ((double)d.N * d.H * d.W * (d.C0 + d.C1) + (double)d.Cout * p.K +
+                                     (double)M * d.Cout * ((d.out_split == 2 ? 2 : 1) + (d.epi != FGT_EPI_NONE ? 1 : 0) + (d.epi == FGT_EPI_GRU ? 1 : 0)));
+    const int prof = direct ? -1 : fgt_prof_begin(FGT_PROF_CONV, 2.0 * (double)M * p.Cout_g * (d.k_alg > 0 ? d.k_alg : p.K) * d.groups, conv_bytes, s);
     FGT_REQUIRE(d.precision == 0 || d.precision == 1, "fgt_conv2d: unknown precision %d", d.precision);
     int rc;
     if (direct) rc = fgt_conv_direct(p, s);   // Cout <= 4: VALU direct conv (fp32)

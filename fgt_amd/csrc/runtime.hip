@@ -63,9 +63,9 @@ extern "C" int fgt_init(int device) {
 
 // ---- optional per-launch timing with HIP events on the launch stream (bench.py's roofline blocks) --------------------------------
 // A launcher brackets its kernel with fgt_prof_begin / fgt_prof_end; records carry a kind (FGT_PROF_*) and the launch's ALGORITHMIC
-// flop count.  fgt_prof_collect_kind synchronises the events of one kind and returns its totals.  Single host thread (the bench).
+// flop count and its unique-byte floor (every input / output byte once).  fgt_prof_collect_kind synchronises the events of one kind and returns its totals.  Single host thread (the bench).
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; int kind; };
+struct ProfRec { hipEvent_t a, b; double flops, bytes; int kind; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_event_pool;
@@ -80,9 +80,9 @@ hipEvent_t get_event() {
 
 bool fgt_prof_on() { return g_prof_on; }
 
-int fgt_prof_begin(int kind, double flops, hipStream_t s) {
+int fgt_prof_begin(int kind, double flops, double bytes, hipStream_t s) {
     if (!g_prof_on) return -1;
-    ProfRec r{get_event(), get_event(), flops, kind};
+    ProfRec r{get_event(), get_event(), flops, bytes, kind};
     hipEventRecord(r.a, s);
     g_prof.push_back(r);
     return (int)g_prof.size() - 1;
@@ -94,8 +94,8 @@ void fgt_prof_end(int idx, hipStream_t s) {
 
 extern "C" void fgt_prof_enable(int on) { g_prof_on = on != 0; }
 
-extern "C" int fgt_prof_collect_kind(int kind, double* total_ms, double* total_flops, long* launches) {
-    double ms = 0, fl = 0;
+extern "C" int fgt_prof_collect_kind(int kind, double* total_ms, double* total_flops, double* total_bytes, long* launches) {
+    double ms = 0, fl = 0, by = 0;
     long n = 0;
     std::vector<ProfRec> keep;
     for (auto& r : g_prof) {
@@ -103,16 +103,17 @@ extern "C" int fgt_prof_collect_kind(int kind, double* total_ms, double* total_f
         hipEventSynchronize(r.b);
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) { fgt_set_error("hipEventElapsedTime failed"); return FGT_ELAUNCH; }
-        ms += t; fl += r.flops; ++n;
+        ms += t; fl += r.flops; by += r.bytes; ++n;
         g_event_pool.push_back(r.a); g_event_pool.push_back(r.b);
     }
     g_prof.swap(keep);
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = fl;
+    if (total_bytes) *total_bytes = by;
     if (launches) *launches = n;
     return FGT_OK;
 }
 
 extern "C" int fgt_prof_collect(double* total_ms, double* total_flops, long* launches) {
-    return fgt_prof_collect_kind(FGT_PROF_CONV, total_ms, total_flops, launches);
+    return fgt_prof_collect_kind(FGT_PROF_CONV, total_ms, total_flops, nullptr, launches);
 }

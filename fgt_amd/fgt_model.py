@@ -13,8 +13,14 @@ import math
 import torch
 import torch.nn as nn
 
+import os
+
 from . import ops
 from .ops import PackedConv
+
+# bf16x3 mode: q / k / v travel from the projection GEMMs to the attention as split tensors (FGT_SPLIT_ATTN=0: fp32 tensors re-split
+# inside attn_bf16x3_kernel, the round-1 path, kept for A/B measurements)
+SPLIT_ATTENTION = os.environ.get("FGT_SPLIT_ATTN", "1") != "0"
 
 
 # ----------------------------------------------------------------------------- parameter holders
@@ -319,7 +325,8 @@ class FGT(nn.Module):
         s = ops.layernorm(x, *P["n1"], splitA=sc and not padded)            # GEMM operands travel pre-split in bf16x3 mode
         if padded:
             s = ops.pad_tokens(s, bt, th, tw, nh, nw)
-        qkv = ops.linear(s, P["qkv"])
+        # bf16x3 mode: the QKV GEMM hands q, k, v over pre-split; the attention streams K / V tiles by LDS-DMA (csrc/attention_split.hip)
+        qkv = ops.linear(s, P["qkv"], out_split="only" if (sc and SPLIT_ATTENTION) else None)
         a = ops.attention_temporal(qkv, b, t, nh, nw, cfg["heads"], G, c, out_split=sc and not padded)
         if padded:
             a = ops.pad_tokens(a, bt, nh, nw, th, tw)                      # crop (attention_base.py:71-72)
@@ -359,9 +366,10 @@ class FGT(nn.Module):
         ops.layernorm(gk, *P["kn"], outA=kin[rows:])
         ops.layernorm(xp, *P["vn"], outA=vin[:rows])
         ops.layernorm(gv, *P["vn"], outA=vin[rows:])
-        q = ops.linear(q_ln, P["q"])
-        kk = ops.linear(kin, P["k"])
-        vv = ops.linear(vin, P["v"])
+        osp = "only" if (sc and SPLIT_ATTENTION) else None
+        q = ops.linear(q_ln, P["q"], out_split=osp)
+        kk = ops.linear(kin, P["k"], out_split=osp)
+        vv = ops.linear(vin, P["v"], out_split=osp)
         a = ops.attention_spatial(q, kk[:rows], vv[:rows], kk[rows:], vv[rows:], bt, th, tw, nh, nw, cfg["heads"], ws, ng, out_split=sc)
         return ops.linear(a, P["out"], epi="add", aux1=x)
 

@@ -398,35 +398,53 @@ def _attn_out(rows, c, device, out_split, d):
     return out, t
 
 
+def _attn_in(t):
+    """(tensor holding the data pointer, row stride, plane stride) of an fp32 tensor or a planes-layout Split input."""
+    if isinstance(t, Split):
+        assert not t.il, "attention takes the planes layout"
+        return t.hi, t.hi.stride(0), t.ps
+    return t, (0 if t is None else t.stride(0)), 0
+
+
 def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None, out_split=False):
-    """Temporal zone attention reading q/k/v in place from a fused [b*t*nh*nw, 3c] projection buffer."""
-    _require_dev(qkv)
+    """Temporal zone attention reading q/k/v in place from a fused [b*t*nh*nw, 3c] projection buffer (fp32, or a Split written by the
+    QKV GEMM: K / V tiles then stream through LDS-DMA, csrc/attention_split.hip)."""
+    insp = isinstance(qkv, Split)
+    if not insp:
+        _require_dev(qkv)
     d = AttnDesc()
     d.mode, d.b, d.t, d.h, d.w, d.nh, d.nw, d.heads, d.group = 0, b, t, nh, nw, nh, nw, heads, group
     d.ws, d.n_global = 0, 0
-    d.ldq = d.ldk = d.ldv = qkv.stride(0)
+    src, ld, ps = _attn_in(qkv)
+    d.ldq = d.ldk = d.ldv = ld
     d.qoff, d.koff, d.voff = 0, c, 2 * c
     d.ldg_k = d.ldg_v = 0
-    out, optr = _attn_out(b * t * nh * nw, c, qkv.device, out_split, d)
-    d.precision = PREC[precision if precision is not None else DEFAULT_ATTN_PRECISION]
-    check(_lib.lib().fgt_attention(C.byref(d), _ptr(qkv), _ptr(qkv), _ptr(qkv), None, None, _ptr(optr), _stream()),
+    d.in_split, d.psq, d.psk, d.psv = int(insp), ps, ps, ps
+    out, optr = _attn_out(b * t * nh * nw, c, src.device, out_split, d)
+    d.precision = PREC["bf16x3" if insp else (precision if precision is not None else DEFAULT_ATTN_PRECISION)]
+    check(_lib.lib().fgt_attention(C.byref(d), _ptr(src), _ptr(src), _ptr(src), None, None, _ptr(optr), _stream()),
           "fgt_attention(temporal)")
     return out
 
 
 def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, precision=None, out_split=False):
-    """Window attention + shared global tokens; q/k/v are [bt*nh*nw, c] maps on the padded grid, output cropped."""
-    _require_dev(q, k, v, kg, vg)
+    """Window attention + shared global tokens; q/k/v are [bt*nh*nw, c] maps on the padded grid, output cropped.  All five inputs fp32, or
+    all five Splits (written by the projection GEMMs)."""
+    insp = isinstance(q, Split)
+    assert all(isinstance(x, Split) == insp for x in (k, v, kg, vg)), "attention_spatial: inputs must all be fp32 or all be Splits"
+    if not insp:
+        _require_dev(q, k, v, kg, vg)
     c = q.shape[1]
     d = AttnDesc()
     d.mode, d.b, d.t, d.h, d.w, d.nh, d.nw, d.heads, d.group = 1, 1, bt, h, w, nh, nw, heads, 0
     d.ws, d.n_global = ws, n_global
-    d.ldq, d.ldk, d.ldv = q.stride(0), k.stride(0), v.stride(0)
+    (qt, d.ldq, d.psq), (kt, d.ldk, d.psk), (vt, d.ldv, d.psv) = _attn_in(q), _attn_in(k), _attn_in(v)
+    (kgt, d.ldg_k, d.psg_k), (vgt, d.ldg_v, d.psg_v) = _attn_in(kg), _attn_in(vg)
     d.qoff = d.koff = d.voff = 0
-    d.ldg_k, d.ldg_v = kg.stride(0), vg.stride(0)
-    out, optr = _attn_out(bt * h * w, c, q.device, out_split, d)
-    d.precision = PREC[precision if precision is not None else DEFAULT_ATTN_PRECISION]
-    check(_lib.lib().fgt_attention(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(kg), _ptr(vg), _ptr(optr), _stream()),
+    d.in_split = int(insp)
+    out, optr = _attn_out(bt * h * w, c, qt.device, out_split, d)
+    d.precision = PREC["bf16x3" if insp else (precision if precision is not None else DEFAULT_ATTN_PRECISION)]
+    check(_lib.lib().fgt_attention(C.byref(d), _ptr(qt), _ptr(kt), _ptr(vt), _ptr(kgt), _ptr(vgt), _ptr(optr), _stream()),
           "fgt_attention(spatial)")
     return out
 
@@ -714,7 +732,7 @@ PROF_KINDS = {"conv": 0, "attn_temporal": 1, "attn_spatial": 2, "all": -1}
 
 
 def prof_collect(kind="conv"):
-    """(total ms, total algorithmic flops, launches) of the launches of `kind` recorded since the last collect."""
-    ms, fl, n = C.c_double(), C.c_double(), C.c_long()
-    check(_lib.lib().fgt_prof_collect_kind(PROF_KINDS[kind], C.byref(ms), C.byref(fl), C.byref(n)), "fgt_prof_collect_kind")
-    return ms.value, fl.value, n.value
+    """(total ms, total algorithmic flops, launches, total unique bytes) of the launches of `kind` recorded since the last collect."""
+    ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_long()
+    check(_lib.lib().fgt_prof_collect_kind(PROF_KINDS[kind], C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)), "fgt_prof_collect_kind")
+    return ms.value, fl.value, n.value, by.value

@@ -176,10 +176,16 @@ typedef struct fgt_attn_desc {
     int precision;          /* FGT_PREC_FP32 | FGT_PREC_BF16X3 (Q, K, P, V split into hi/lo bf16, 3 MFMAs per product) */
     int out_split;          /* 1: O is a split tensor (see fgt_conv_desc): pointer to the bf16 hi plane, ldo in bf16 elements */
     long long pso;          /* plane stride of O in bf16 elements (out_split = 1)                                            */
+    int in_split;           /* 1 (FGT_PREC_BF16X3 only): Q, K, V (and KG, VG) point to the bf16 hi planes of split tensors written by
+                             * the projection GEMMs (fgt_conv_desc.out_split); ld* / *off in bf16 elements (multiples of 8), lo planes
+                             * ps* elements further.  K / V tiles then travel global -> LDS by LDS-DMA and nothing is converted in the
+                             * kernel (csrc/attention_split.hip); Q is stored unscaled and 1/sqrt(d) multiplies the fp32 scores.   */
+    int reserved1;
+    long long psq, psk, psv, psg_k, psg_v;
 } fgt_attn_desc;
 
-int fgt_attention(const fgt_attn_desc* d, const float* Q, const float* K, const float* V,
-                  const float* KG, const float* VG, float* O, void* stream);
+int fgt_attention(const fgt_attn_desc* d, const void* Q, const void* K, const void* V,
+                  const void* KG, const void* VG, float* O, void* stream);
 
 /* Depthwise kxk stride-k convolution over [x0 | x1] maps -> global tokens [bt, (nh/k)*(nw/k), C0+C1]
  * (attention_flow.py:44-48,80-81,87-91).  w is the reference layout [C,1,k,k], bias [C]. */
@@ -326,12 +332,14 @@ int fgt_poisson_blend(const float* target, const float* gx, const float* gy, con
  * fgt_prof_enable(1) makes every fgt_conv2d (MFMA kernels) and fgt_attention launch record an event pair and its ALGORITHMIC
  * flops: conv/GEMM 2*M*Cout_g*K*groups (K before channel padding, fgt_conv_desc.k_alg); attention 4*n_q*n_k*128 per
  * (problem, head) — the two contractions of attention_base.py:16-22 as torch's flop counter counts them.
- * fgt_prof_collect_kind synchronises the events of one kind and returns (and clears) its totals; kind -1 = all. */
+ * Each record also carries the launch's unique-byte floor (every input / weight / output byte once), so that a kernel can be
+ * placed on the HBM roofline as well.  fgt_prof_collect_kind synchronises the events of one kind and returns (and clears) its
+ * totals; kind -1 = all. */
 #define FGT_PROF_CONV 0
 #define FGT_PROF_ATTN_TEMPORAL 1
 #define FGT_PROF_ATTN_SPATIAL 2
 void fgt_prof_enable(int on);
-int fgt_prof_collect_kind(int kind, double* total_ms, double* total_flops, long* launches);
+int fgt_prof_collect_kind(int kind, double* total_ms, double* total_flops, double* total_bytes, long* launches);
 int fgt_prof_collect(double* total_ms, double* total_flops, long* launches); /* = kind FGT_PROF_CONV */
 
 #ifdef __cplusplus

@@ -114,7 +114,12 @@ def linear(x, pc, **kw):
     out = kw.pop("out", None)
     x1 = kw.pop("x1", None)
     img = lambda t: None if t is None else (Split(t.x.unsqueeze(0).unsqueeze(0)) if isinstance(t, Split) else t.unsqueeze(0).unsqueeze(0))
-    y = conv2d(img(x), pc, x1=img(x1), **kw).reshape(rows, pc.Cout)
+    y = conv2d(img(x), pc, x1=img(x1), **kw)
+    if isinstance(y, Split):                      # out_split = "only"
+        return Split(y.x.reshape(rows, pc.Cout))
+    if isinstance(y, tuple):                      # out_split = "both"
+        return y[0].reshape(rows, pc.Cout), Split(y[1].x.reshape(rows, pc.Cout))
+    y = y.reshape(rows, pc.Cout)
     if out is not None:
         out.copy_(y)
         return out
@@ -143,7 +148,16 @@ def _sdpa(q, k, v):
     return torch.matmul(F.softmax(s, dim=-1), v)
 
 
+def _unsplit(*ts):
+    """attention inputs: all fp32, or all Splits (then only in the bf16x3 mode) -> the fp32 tensors"""
+    if any(isinstance(t, Split) for t in ts):
+        assert all(isinstance(t, Split) for t in ts) and DEFAULT_CONV_PRECISION == "bf16x3", "Split attention inputs need the bf16x3 mode, all together"
+        return tuple(t.x for t in ts)
+    return ts
+
+
 def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None, out_split=False):
+    (qkv,) = _unsplit(qkv)
     zh, zw, d = nh // group, nw // group, c // heads
 
     def zones(y):
@@ -154,6 +168,7 @@ def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None, out_s
 
 
 def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, precision=None, out_split=False):
+    q, k, v, kg, vg = _unsplit(q, k, v, kg, vg)
     c = q.shape[1]
     gh, gw, d = nh // ws, nw // ws, c // heads
 

@@ -451,3 +451,64 @@ def test_attention_spatial_config5_grid(prec, tol, dev):
     a = a.transpose(2, 3).reshape(bt, gh, gw, ws, ws, c).transpose(2, 3).reshape(bt * h * w, c)
     out = ops.attention_spatial(q.to(dev), k.to(dev), v.to(dev), kg.to(dev), vg.to(dev), bt, h, w, nh, nw, heads, ws, ng, precision=prec)
     assert report(f"attn spatial 40x72 {prec}", out.cpu(), a)[1] < tol
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Split-input attention (csrc/attention_split.hip): q / k / v arrive as hi/lo bf16 planes from the projection GEMMs, K / V tiles are
+# streamed by LDS-DMA and V is read through ds_read_b64_tr_b16.  Reference: fp64 attention on hi + lo (what the planes represent:
+# the fp32 values rounded to 16 mantissa bits), so the tolerance is the same bf16x3 bar as above.
+def _split_vals(sp):
+    return sp.float().cpu()          # hi + lo as fp32
+
+
+@pytest.mark.parametrize("b,t,nh,nw", [(1, 3, 20, 36), (2, 2, 6, 8), (1, 5, 22, 36), (1, 13, 20, 36), (2, 17, 20, 36), (1, 26, 40, 72)])
+def test_attention_temporal_split_inputs(b, t, nh, nw, dev):
+    from fgt_amd import ops
+    heads, G, c = 4, 2, 512
+    qkv = _rand(b * t * nh * nw, 3 * c, seed=200 + t)
+    qkv[:, :2 * c] *= 1.5
+    sp = ops.split(qkv.to(dev))
+    ref = _temporal_ref64(_split_vals(sp), b, t, nh, nw, heads, G, c, "cpu" if t <= 5 else dev)
+    out = ops.attention_temporal(sp, b, t, nh, nw, heads, G, c)
+    assert report(f"attn temporal split-in b{b} t{t} {nh}x{nw}", out.cpu(), ref)[1] < 1e-4
+    o2 = ops.attention_temporal(sp, b, t, nh, nw, heads, G, c, out_split=True)          # the model's path: split in, split out
+    assert torch.equal(o2.float(), ops.split(out).float())
+    # a Split that is a slice of a wider fused buffer with extra leading rows (ld > 3c, row offset)
+    wide = ops.split(torch.cat([_rand(7, 3 * c + 64, seed=1), torch.cat([qkv, _rand(qkv.shape[0], 64, seed=2)], 1)], 0).to(dev))
+    view = ops.Split(wide.data[:, 7:, :3 * c])
+    assert torch.equal(ops.attention_temporal(view, b, t, nh, nw, heads, G, c), out)
+
+
+def test_attention_split_forced_rescale(dev):
+    from fgt_amd import ops
+    b, t, nh, nw, heads, G, c = 1, 4, 8, 8, 4, 2, 512
+    qkv = _rand(b * t * nh * nw, 3 * c, seed=9) * 0.3
+    qkv[-1, c:2 * c] = qkv[5, :c] * 40.0
+    sp = ops.split(qkv.to(dev))
+    ref = _temporal_ref64(_split_vals(sp), b, t, nh, nw, heads, G, c, "cpu")
+    out = ops.attention_temporal(sp, b, t, nh, nw, heads, G, c)
+    assert report("attn split-in forced rescale", out.cpu(), ref)[1] < 1e-4
+
+
+@pytest.mark.parametrize("bt,h,w", [(2, 20, 36), (1, 22, 35), (2, 8, 8), (3, 40, 72)])
+def test_attention_spatial_split_inputs(bt, h, w, dev):
+    from fgt_amd import ops
+    heads, ws, gd, c = 4, 8, 4, 512
+    nh, nw = (h + ws - 1) // ws * ws, (w + ws - 1) // ws * ws
+    gh, gw = nh // ws, nw // ws
+    ng = (nh // gd) * (nw // gd)
+    rows = bt * nh * nw
+    # k / v as ONE buffer [window rows | global rows] like the model's fused projections
+    qs = ops.split(_rand(rows, c, seed=31).to(dev))
+    ks = ops.split(_rand(rows + bt * ng, c, seed=32).to(dev))
+    vs = ops.split(_rand(rows + bt * ng, c, seed=33).to(dev))
+    q, kall, vall = _split_vals(qs), _split_vals(ks), _split_vals(vs)
+    k, kg, v, vg = kall[:rows], kall[rows:], vall[:rows], vall[rows:]
+    windows = lambda y: y.view(bt, gh, ws, gw, ws, c).transpose(2, 3).reshape(bt, gh * gw, ws * ws, c)
+    heads_ = lambda y: y.reshape(bt, gh * gw, -1, heads, c // heads).permute(0, 1, 3, 2, 4)
+    K = torch.cat([windows(k), kg.view(bt, 1, ng, c).expand(-1, gh * gw, -1, -1)], 2)
+    V = torch.cat([windows(v), vg.view(bt, 1, ng, c).expand(-1, gh * gw, -1, -1)], 2)
+    a = _sdpa(heads_(windows(q)).double(), heads_(K).double(), heads_(V).double()).float()
+    a = a.transpose(2, 3).reshape(bt, gh, gw, ws, ws, c).transpose(2, 3).reshape(bt, nh, nw, c)[:, :h, :w].reshape(bt * h * w, c)
+    out = ops.attention_spatial(qs, ks[:rows], vs[:rows], ks[rows:], vs[rows:], bt, h, w, nh, nw, heads, ws, ng)
+    assert report(f"attn spatial split-in bt{bt} {h}x{w}", out.cpu(), a)[1] < 1e-4
