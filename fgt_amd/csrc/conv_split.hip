@@ -38,13 +38,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else static_assert(N == 0, "add the immediate");
 }
 
-template <int BM, int BN, int WM, int WN, int MINW, int NS, bool PP, bool IL = false, int P8 = 0>
+template <int BM, int BN, int WM, int WN, int MINW, int NS, bool PP, bool IL = false, int P8 = 0, bool EA = false>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const ConvP p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -57,6 +58,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     static_assert(NS >= 2 && NS <= 4, "LDS ring depth");
     static_assert(!PP || (NS >= 3 && NW % 2 == 0), "ping-pong needs a ring of >= 3 stages and an even wavefront count");
     static_assert(!IL || (NS == 2 && !PP && TM >= 2), "interleaved schedule: double buffer, >= 2 row blocks per wavefront");
+    static_assert(!EA || (NS == 2 && !PP && !IL && !P8), "early stage release: plain double buffer");
     static_assert(!P8 || (NS == 2 && !PP && !IL && NW == 8 && BM == 256 && TM % 2 == 0 && TN % 2 == 0 && A_IT == 2 && (B_IT == 2 || B_IT == 4)),
                   "8-phase schedule: 256-row tile on 8 wavefronts, double buffer");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -215,8 +217,8 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
 
     const int l31 = lane & 31, lh = lane >> 5;
 
-    // ---- prologue: tiles 0 .. NS-2 in flight, tile 0 landed
-    constexpr int AHEAD = NS - 1;
+    // ---- prologue: tiles 0 .. NS-2 in flight, tile 0 landed (EA: tiles 0 and 1 in flight)
+    constexpr int AHEAD = EA ? 2 : NS - 1;
 #pragma unroll
     for (int t = 0; t < AHEAD; ++t)
         if (t < p.nk) issue_tile(t);
@@ -479,6 +481,30 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
             slot_in ^= 1;
         }
         if (!g1) __builtin_amdgcn_s_barrier();
+    } else if constexpr (EA) {
+        // Early stage release.  The K loop of the plain double buffer is LATENCY-bound: the DMAs of tile kt+1 are issued at the top of
+        // step kt and must have landed at its end, so a step cannot be shorter than the L2 / HBM -> LDS latency (~1.9 us under load:
+        // PMC on the bench, profiles/r02_run5_pmc_clock.txt: matrix pipe 39 % busy, wavefronts 39 % parked at s_waitcnt / barrier at
+        // 2.1 GHz), whatever the compute.  But a step reads ALL its fragments into registers before its first MFMA, so the stage is dead
+        // as soon as every wavefront has read it: one extra barrier after the fragment reads frees it for tile kt+2 a whole step
+        // early — two tiles (2 x DPT pieces per wavefront) in flight with the same two stages, a copy now has two steps to land.
+        //   step kt: read tile kt (stage kt&1) | lgkmcnt(0) | barrier | issue tile kt+2 -> stage kt&1 | MFMAs | vmcnt(DPT): tile kt+1
+        //            landed, tile kt+2 may fly | barrier.   Same products in the same order: bit-identical.
+        for (int kt = 0; kt < p.nk; ++kt) {
+            bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+            read_frags(ah, al, bh, bl);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();                   // every wavefront holds its fragments of tile kt: the stage can be refilled
+            const bool more = kt + 2 < p.nk;
+            if (more) issue_tile(slot);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(ah, al, bh, bl);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) wait_vmcnt<DPT>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            slot ^= 1;
+        }
     } else if constexpr (!PP) {
         for (int kt = 0; kt < p.nk; ++kt) {
             if (kt + AHEAD < p.nk) issue_tile(slot_in);
@@ -529,19 +555,19 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
 }
 
-template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2, bool PP = false, bool IL = false, int P8 = 0>
+template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2, bool PP = false, bool IL = false, int P8 = 0, bool EA = false>
 int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr size_t smem = (size_t)NS * (BM + BN) * LDB * sizeof(float);
     static_assert(smem <= 160 * 1024, "LDS ring does not fit");
     static std::atomic<unsigned long long> lds_set{0};
-    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL, P8>), (int)smem, lds_set, "conv_split")) return rc;
+    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL, P8, EA>), (int)smem, lds_set, "conv_split")) return rc;
     ConvP q = p;
     q.mtiles = cdiv(p.M, BM);
     q.ntiles = cdiv(p.Cout_g, BN);
     q.mchunk = cdiv(q.mtiles, 8);
     dim3 grid(q.xcd_swizzle ? 8 * q.mchunk * q.ntiles : q.mtiles * q.ntiles, p.d.groups);
-    hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL, P8>), grid, dim3(NT), smem, s, q);
+    hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL, P8, EA>), grid, dim3(NT), smem, s, q);
     return fgt_check_launch("conv_split");
 }
 
@@ -563,6 +589,13 @@ int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_256x128x8_PP: return launch<256, 128, 4, 2, 2, 3, true>(p, s);  // + ping-pong wavefront groups
         case FGT_TILE_128x128x8_PP: return launch<128, 128, 2, 4, 4, 4, true>(p, s);
         case FGT_TILE_256x128x8_IL: return launch<256, 128, 4, 2, 2, 2, false, true>(p, s);
+        // early stage release (two tiles in flight on two stages): the production tiles again, bit-identical results
+        case FGT_TILE_128x128_EA: return launch<128, 128, 2, 2, 2, 2, false, false, 0, true>(p, s);
+        case FGT_TILE_128x64_EA: return launch<128, 64, 2, 2, 2, 2, false, false, 0, true>(p, s);
+        case FGT_TILE_64x64_EA: return launch<64, 64, 2, 2, 2, 2, false, false, 0, true>(p, s);
+        case FGT_TILE_128x128x8_EA: return launch<128, 128, 2, 4, 4, 2, false, false, 0, true>(p, s);
+        case FGT_TILE_256x128x16_EA: return launch<256, 128, 4, 4, 4, 2, false, false, 0, true>(p, s);
+        case FGT_TILE_256x64x8_EA: return launch<256, 64, 4, 2, 2, 2, false, false, 0, true>(p, s);
         case FGT_TILE_256x256_P8: return launch<256, 256, 2, 4, 2, 2, false, false, 3>(p, s);     // 8-phase staggered schedule, setprio around the MFMAs
         case FGT_TILE_256x128_P8: return launch<256, 128, 4, 2, 2, 2, false, false, 3>(p, s);
 #ifdef FGT_P8_ABLATIONS   // A/B and timing-only instances behind profiles/r02_run3_split_sweep_p8*.txt (build with -DFGT_P8_ABLATIONS to reproduce)

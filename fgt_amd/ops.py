@@ -22,7 +22,9 @@ DEFAULT_ATTN_PRECISION = os.environ.get("FGT_ATTN_PRECISION", "fp32")
 # events and caches the fastest.  Tiles only change the work decomposition: results are bit-identical across tiles
 # (the k order of every accumulation is the same), so tuning never changes numerics.
 AUTOTUNE = os.environ.get("FGT_AUTOTUNE", "1") != "0"
-TILE_CANDIDATES = ("128x128", "64x64", "128x64", "256x128", "128x32", "128x128x8", "256x128x16", "256x64x8")
+TILE_CANDIDATES = ("128x128", "64x64", "128x64", "256x128", "128x32", "128x128x8", "256x128x16", "256x64x8",
+                   # split inputs only (rejected, hence skipped, for fp32 inputs): the same tiles with early stage release
+                   "128x128ea", "64x64ea", "128x64ea", "128x128x8ea", "256x128x16ea", "256x64x8ea")
 _tile_cache = {}
 
 

@@ -132,6 +132,12 @@ typedef struct fgt_conv_desc {
 #define FGT_TILE_256x256_P8 17    /* split inputs only: 256x256 on 8 wavefronts of 128x64, 8-phase schedule: two staggered wavefront
                                    * groups (one loads / issues LDS-DMA while the other owns the matrix pipe), counted vmcnt, s_setprio */
 #define FGT_TILE_256x128_P8 18    /* split inputs only: the same schedule on a 256x128 tile (8 wavefronts of 64x64) */
+#define FGT_TILE_128x128_EA 26    /* split inputs only: tiles 1, 2, 3, 6, 7, 8 with EARLY STAGE RELEASE — an extra barrier after the fragment reads frees */
+#define FGT_TILE_128x64_EA 27     /* the LDS stage for tile kt+2 one step early: two tiles in flight on two stages (the K loop is bound by the */
+#define FGT_TILE_64x64_EA 28      /* global -> LDS latency, not by the matrix pipe).  Bit-identical results.                                */
+#define FGT_TILE_128x128x8_EA 29
+#define FGT_TILE_256x128x16_EA 30
+#define FGT_TILE_256x64x8_EA 31
 #define FGT_TILE_256x256_P8N 19   /* 17 without s_setprio (A/B measurements) */
 #define FGT_TILE_256x256_P8L 20   /* 17 with both wavefront groups in lock step (A/B measurements) */
 
