@@ -23,7 +23,7 @@ def kind_of(name):
         return "conv"
     if "attn_" in name:
         # spatial windows run the 2-wavefront instances (64 queries), temporal zones the 4- / 8-wavefront ones
-        return "attn_spatial" if re.search(r"attn_(bf16x3_)?kernel<2", name) else "attn_temporal"
+        return "attn_spatial" if re.search(r"attn_(bf16x3_|split_)?kernel<2", name) else "attn_temporal"
     return None
 
 
