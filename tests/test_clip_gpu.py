@@ -54,6 +54,8 @@ def test_cliprunner_cache_batch8_matches_oracle_clip(prec, max_rate, clip46, mon
     assert torch.equal(ClipRunner(m, fr, fl, ms, cache_features=True, window_batch=1, use_graphs=False).run().cpu(), got)
     g = ClipRunner(m, fr, fl, ms, cache_features=True, window_batch=8, use_graphs=True)
     assert torch.equal(g.run().cpu(), got) and torch.equal(g.run().cpu(), got)
+    two = ClipRunner(m, fr, fl, ms, cache_features=True, window_batch=2, n_streams=2)          # window groups on two concurrent HIP streams
+    assert len(two.groups) >= 3 and torch.equal(two.run().cpu(), got) and torch.equal(two.run().cpu(), got)
 
 
 def test_cliprunner_other_schedule_matches_oracle_clip(dev):
