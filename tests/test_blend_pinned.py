@@ -90,3 +90,29 @@ def test_hip_blend_clip_432x240_matches_oracle(dev):
         d = np.abs(blend[i] - want)[~wunf]
         print(f"[parity] poisson blend 432x240 frame {i}: hole px {hole.sum()}, unfilled {wunf.sum()}, max |hip - lsq| {d.max():.2e}")
         assert d.max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_hip_blend_edge_cases(dev):
+    """Empty holes (nothing to solve), a hole covering a whole frame (no boundary equation anywhere: everything unfilled), and a frame wider
+    than one scan chunk (W > 1024: the UnfilledMask row scan carries across chunks)."""
+    from fgt_amd import ops
+    rng = np.random.default_rng(3)
+    H, W = 6, 1100
+    trg = rng.random((3, H, W, 3)).astype(np.float32)
+    gx = (rng.normal(size=(3, H, W, 3)) * 0.05).astype(np.float32)
+    gy = (rng.normal(size=(3, H, W, 3)) * 0.05).astype(np.float32)
+    hole = np.zeros((3, H, W), bool)
+    gm = np.zeros((3, H, W), bool)
+    hole[1] = True                                     # whole frame
+    hole[2, 1:5, 3:1097] = True                        # one long hole spanning both scan chunks ...
+    gm[2, 1:5, 600] = True                             # ... cut by a column of unknown gradients
+    gm[2, 2, 100:1000] = True
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    blend, unf = ops.poisson_blend(t(trg), t(gx), t(gy), t(hole), t(gm))
+    blend, unf = blend.cpu().numpy(), unf.cpu().numpy()
+    assert np.array_equal(blend[0], trg[0]) and not unf[0].any()
+    assert unf[1].all() and np.isfinite(blend[1]).all()
+    want, wunf = BO.poisson_blend(trg[2], gx[2][:, : W - 1], gy[2][: H - 1], hole[2], gm[2])
+    assert np.array_equal(unf[2], wunf) and 0 < wunf.sum() < hole[2].sum()
+    assert np.abs(blend[2] - want)[~wunf].max() < 1e-4
