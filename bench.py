@@ -208,10 +208,27 @@ def main():
                 kinds[k] = (ms * scale, fl * scale, n * scale, by * scale)
         return max_over_ranks(dt), host_dt, comp, kinds
 
+    sustained_cache = {}
+
+    def sustained_peak(prec):
+        """The matrix-core rate THIS chip sustains under load (fgt_mfma_probe: back-to-back MFMAs on random operands, clock measured in
+        the kernel).  The nominal peaks assume 2.4 GHz; the chip clocks to its power budget, so this is the reachable roof."""
+        if prec not in sustained_cache:
+            try:
+                tf, ghz = ops.mfma_probe(f32=(prec == "fp32"), device=dev)
+                sustained_cache[prec] = {"peak": round(tf, 1), "clock_ghz": round(ghz, 3),
+                                         "how": "fgt_mfma_probe: 256 workgroups x 8 wavefronts of independent "
+                                                + ("v_mfma_f32_32x32x2_f32" if prec == "fp32" else "v_mfma_f32_32x32x16_bf16")
+                                                + " on random operands in registers; clock = d(s_memtime)/d(s_memrealtime)"}
+            except Exception as e:  # noqa: BLE001 - a diagnostic must not take the bench line down
+                sustained_cache[prec] = {"peak": None, "error": str(e)[:200]}
+        return sustained_cache[prec]
+
     def rooflines(kinds, prec, dt):
         passes = 1 if prec == "fp32" else 3          # MFMA flops issued per algorithmic flop
         peak = PEAK_FP32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
         traffic = kernel_traffic(prec)
+        sus = sustained_peak(prec) if kinds else None
         out = []
         for k, (ms, fl, n, by) in kinds.items():
             if ms <= 0 or n == 0:
@@ -226,6 +243,8 @@ def main():
                         "algorithmic_tflops": round(fl / (ms * 1e-3) / 1e12, 2), "mfma_passes_per_product": passes,
                         "launches": n, "avg_launch_us": round(1e3 * ms / n, 2), "kernel_ms_per_step": round(ms / args.steps, 3),
                         "share_of_step": round(ms / (1e3 * dt), 3)})
+            if sus and sus.get("peak"):
+                out[-1]["sustained"] = dict(sus, frac=round(ach / sus["peak"], 4))
         out.sort(key=lambda r: -r["share_of_step"])
         return out
 

@@ -7,7 +7,8 @@ import torch  # noqa: F401  -- MUST precede loading libfgt_hip.so: torch ships i
 #                              bring up a second HIP runtime with no device context ("no ROCm-capable device is detected").
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfgt_hip.so")
+# FGT_HIP_LIB: diagnostic builds of the same library (tools/conv_trace.py); there is still no fallback — a missing file raises.
+LIB_PATH = os.environ.get("FGT_HIP_LIB") or os.path.join(_HERE, "lib", "libfgt_hip.so")
 
 ACT = {"none": 0, None: 0, "lrelu": 1, "relu": 2, "sigmoid": 3, "tanh": 4}
 EPI = {"none": 0, None: 0, "mul": 1, "add": 2, "gru": 3}
@@ -75,11 +76,13 @@ SIGNATURES = {
     "fgt_flow_propagate": [_P, _P, _P, _P, _P, _I, _I, _I, C.c_double, C.c_double, _I, _P, _P, _P, _P, _P],
     "fgt_poisson_blend_workspace": [_I, _I, _I],
     "fgt_poisson_blend": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],
+    "fgt_mfma_probe_workspace": [],
+    "fgt_mfma_probe": [_I, _I, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), _P],
     "fgt_prof_enable": [_I],
     "fgt_prof_collect": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)],
     "fgt_prof_collect_kind": [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)],
 }
-_RESTYPES = {"fgt_last_error": C.c_char_p, "fgt_prof_enable": None, "fgt_laplace_fill_workspace": C.c_long, "fgt_flow_propagate_workspace": C.c_long, "fgt_poisson_blend_workspace": C.c_long}
+_RESTYPES = {"fgt_last_error": C.c_char_p, "fgt_prof_enable": None, "fgt_laplace_fill_workspace": C.c_long, "fgt_flow_propagate_workspace": C.c_long, "fgt_poisson_blend_workspace": C.c_long, "fgt_mfma_probe_workspace": C.c_long}
 
 _lib = None
 

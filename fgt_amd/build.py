@@ -26,9 +26,11 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, variant=None, extra_flags=()):
+    """variant / extra_flags: diagnostic builds (lib/libfgt_hip_<variant>.so, e.g. tools/conv_trace.py); the product library has neither."""
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "obj" + (f"_{variant}" if variant else ""))
+    lib = os.path.join(LIBDIR, f"libfgt_hip_{variant}.so") if variant else LIB
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(CSRC, "conv_tile.h"), os.path.join(HERE, "..", "include", "fgt_hip.h")]
     hipcc = _hipcc()
@@ -39,7 +41,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -50,9 +52,9 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or not os.path.exists(LIB):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if force or jobs or not os.path.exists(lib):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":

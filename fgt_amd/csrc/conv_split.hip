@@ -45,6 +45,23 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N == 0, "add the immediate");
 }
 
+#ifdef FGT_CONV_TRACE
+// Diagnostic build only (python tools/conv_trace.py): every wavefront stamps s_memtime at the phase boundaries of its first TR_STEPS K-steps
+// into spare LDS and the workgroup dumps them (plus HW_ID / XCC_ID) to a global buffer before the epilogue.  Not part of the product library.
+constexpr int TR_STEPS = 32, TR_NST = 8, TR_HDR = 8;
+__device__ unsigned* g_conv_trace = nullptr;
+__device__ long g_conv_trace_words = 0;
+#define TR_STAMP(i) ts[i] = __builtin_readcyclecounter()
+#define TR_STORE(kt)                                                                                              \
+    if ((kt) < TR_STEPS && lane == 0) {                                                                           \
+        unsigned* tr_ = trace_lds + (wave * TR_STEPS + (kt)) * TR_NST;                                            \
+        for (int i_ = 0; i_ < TR_NST; ++i_) tr_[i_] = (unsigned)ts[i_];                                           \
+    }
+#else
+#define TR_STAMP(i)
+#define TR_STORE(kt)
+#endif
+
 template <int BM, int BN, int WM, int WN, int MINW, int NS, bool PP, bool IL = false, int P8 = 0, bool EA = false>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const ConvP p) {
     constexpr int NW = WM * WN;
@@ -216,6 +233,13 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
+#ifdef FGT_CONV_TRACE
+    unsigned long long ts[TR_NST] = {};
+    unsigned* const trace_lds = reinterpret_cast<unsigned*>(smem + NS * STAGE);
+    const unsigned long long tr_t0 = __builtin_readcyclecounter();
+    const unsigned long long tr_r0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: shader clock = d(memtime) / d(memrealtime)
+    for (int i = tid; i < NW * TR_STEPS * TR_NST; i += NW * 64) trace_lds[i] = 0;
+#endif
 
     // ---- prologue: tiles 0 .. NS-2 in flight, tile 0 landed (EA: tiles 0 and 1 in flight)
     constexpr int AHEAD = EA ? 2 : NS - 1;
@@ -225,6 +249,9 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     if (p.nk >= AHEAD) wait_vmcnt<DPT * (AHEAD - 1)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     int slot = 0, slot_in = AHEAD % NS;
+#ifdef FGT_CONV_TRACE
+    const unsigned long long tr_t1 = __builtin_readcyclecounter();   // prologue over (tile 0 landed)
+#endif
 
     auto read_frags = [&](bf16x8 (&ah)[2][TM], bf16x8 (&al)[2][TM], bf16x8 (&bh)[2][TN], bf16x8 (&bl)[2][TN]) {
         const __bf16* base = reinterpret_cast<const __bf16*>(smem + slot * STAGE);
@@ -492,32 +519,50 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
         //            landed, tile kt+2 may fly | barrier.   Same products in the same order: bit-identical.
         for (int kt = 0; kt < p.nk; ++kt) {
             bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+            TR_STAMP(0);
             read_frags(ah, al, bh, bl);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            TR_STAMP(1);
             __builtin_amdgcn_s_barrier();                   // every wavefront holds its fragments of tile kt: the stage can be refilled
+            TR_STAMP(2);
             const bool more = kt + 2 < p.nk;
             if (more) issue_tile(slot);
             __builtin_amdgcn_sched_barrier(0);
+            TR_STAMP(3);
             mfmas(ah, al, bh, bl);
             __builtin_amdgcn_sched_barrier(0);
+            TR_STAMP(4);
             if (more) wait_vmcnt<DPT>(); else wait_vmcnt<0>();
+            TR_STAMP(5);
             __builtin_amdgcn_s_barrier();
+            TR_STAMP(6);
+            TR_STORE(kt);
             slot ^= 1;
         }
     } else if constexpr (!PP) {
         for (int kt = 0; kt < p.nk; ++kt) {
+            TR_STAMP(0);
             if (kt + AHEAD < p.nk) issue_tile(slot_in);
+            TR_STAMP(2);
             bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
             read_frags(ah, al, bh, bl);
             __builtin_amdgcn_sched_barrier(0);   // keep all fragment reads of the step ahead of its MFMAs
+#ifdef FGT_CONV_TRACE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            TR_STAMP(3);
             mfmas(ah, al, bh, bl);
             // The wait + barrier stay BEHIND the MFMAs (hoisted above them, the DMA latency would be exposed in front of this
             // wavefront's matrix work instead of running underneath it).  Tile kt+1 must have landed; while NS-2 younger tiles
             // exist they stay in flight (the last NS-2 steps drain everything: a constant immediate needs a constant count).
             __builtin_amdgcn_sched_barrier(0);
+            TR_STAMP(4);
             if (kt + AHEAD < p.nk) wait_vmcnt<DPT * (AHEAD - 1)>(); else wait_vmcnt<0>();
+            TR_STAMP(5);
             __builtin_amdgcn_s_barrier();
+            TR_STAMP(6);
+            TR_STORE(kt);
             slot = slot + 1 == NS ? 0 : slot + 1;
             slot_in = slot_in + 1 == NS ? 0 : slot_in + 1;
         }
@@ -551,14 +596,50 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
         if (!g1) __builtin_amdgcn_s_barrier();
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef FGT_CONV_TRACE
+    unsigned* tr_hdr = nullptr;
+    {
+        const unsigned long long tr_t2 = __builtin_readcyclecounter();   // K loop over
+        __syncthreads();
+        constexpr int PER_WG = NW * (TR_HDR + TR_STEPS * TR_NST);
+        const long wg = (long)blockIdx.y * gridDim.x + blockIdx.x;
+        unsigned* out = g_conv_trace;
+        if (out && (wg + 1) * PER_WG <= g_conv_trace_words) {
+            out += wg * PER_WG;
+            if (lane == 0) {
+                unsigned* h = out + wave * TR_HDR;
+                h[0] = __builtin_amdgcn_s_getreg(63492);    // HW_ID
+                h[1] = __builtin_amdgcn_s_getreg(63508);    // XCC_ID
+                h[2] = (unsigned)tr_t0;
+                h[3] = (unsigned)p.nk;
+                h[4] = (unsigned)tr_t1;
+                h[5] = (unsigned)tr_t2;
+                tr_hdr = h;
+            }
+            for (int i = tid; i < NW * TR_STEPS * TR_NST; i += NW * 64) out[NW * TR_HDR + i] = trace_lds[i];
+        }
+        __syncthreads();
+    }
+#endif
 
     conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
+#ifdef FGT_CONV_TRACE
+    if (tr_hdr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tr_hdr[6] = (unsigned)__builtin_readcyclecounter();              // epilogue over (stores acknowledged)
+        tr_hdr[7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - tr_r0);
+    }
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2, bool PP = false, bool IL = false, int P8 = 0, bool EA = false>
 int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
+#ifdef FGT_CONV_TRACE
+    constexpr size_t smem = (size_t)NS * (BM + BN) * LDB * sizeof(float) + (size_t)WM * WN * TR_STEPS * TR_NST * 4;
+#else
     constexpr size_t smem = (size_t)NS * (BM + BN) * LDB * sizeof(float);
+#endif
     static_assert(smem <= 160 * 1024, "LDS ring does not fit");
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL, P8, EA>), (int)smem, lds_set, "conv_split")) return rc;
@@ -572,6 +653,15 @@ int launch(const ConvP& p, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef FGT_CONV_TRACE
+extern "C" int fgt_debug_conv_trace(void* buf, long words) {
+    unsigned* b = static_cast<unsigned*>(buf);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_conv_trace), &b, sizeof(b)) != hipSuccess) return FGT_ELAUNCH;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_conv_trace_words), &words, sizeof(words)) != hipSuccess) return FGT_ELAUNCH;
+    return FGT_OK;
+}
+#endif
 
 int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s) {
     switch (tile) {

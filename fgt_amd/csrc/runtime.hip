@@ -15,7 +15,7 @@ void fgt_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* fgt_last_error(void) { return g_err; }
-extern "C" int fgt_abi_version(void) { return 3; }
+extern "C" int fgt_abi_version(void) { return 4; }
 
 // One 256-byte zero-filled allocation PER DEVICE (the target of out-of-image im2col gathers: a kernel on device d must not be
 // handed memory of device 0), created under a mutex.  fgt_init(device) creates it eagerly so that the lazy path below never runs
@@ -116,4 +116,87 @@ extern "C" int fgt_prof_collect_kind(int kind, double* total_ms, double* total_f
 
 extern "C" int fgt_prof_collect(double* total_ms, double* total_flops, long* launches) {
     return fgt_prof_collect_kind(FGT_PROF_CONV, total_ms, total_flops, nullptr, launches);
+}
+
+// ---- sustained matrix-core rate of THIS chip under load (bench.py reports it beside the nominal peak) ------------------------------
+// 256 workgroups x 8 wavefronts issue nothing but independent MFMAs on random operands held in registers; every workgroup measures the
+// shader clock it ran at as d(s_memtime) / d(s_memrealtime) (s_memrealtime: constant 100 MHz).  The chip clocks to its power budget:
+// on random data the bf16 pipe sustains ~1.8 PF at ~1.75 GHz, not the nominal 2.5 PF at 2.4 GHz (tools/micro/clock_probe.hip).
+namespace {
+typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ inline unsigned probe_hash(unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+
+template <bool F32>
+__global__ void __launch_bounds__(512) mfma_probe_kernel(float* out, int iters, unsigned long long* cyc, unsigned long long* real) {
+    probe_bf16x8 a[2], b[2];
+    float fa[2], fb[2];
+    for (int j = 0; j < 2; ++j) {
+        for (int i = 0; i < 8; ++i) {
+            const unsigned h = probe_hash(threadIdx.x * 64 + blockIdx.x * 4096 + i * 2 + j);
+            a[j][i] = (__bf16)((float)(h & 0xffff) / 65536.f - 0.5f);
+            b[j][i] = (__bf16)((float)(h >> 16) / 65536.f - 0.5f);
+        }
+        const unsigned h = probe_hash(threadIdx.x * 2 + blockIdx.x * 1024 + j + 77);
+        fa[j] = (float)(h & 0xffffff) / 16777216.f - 0.5f;
+        fb[j] = (float)(h >> 8) / 16777216.f - 0.5f;
+    }
+    probe_f32x16 acc[4];
+    for (int n = 0; n < 4; ++n)
+        for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if constexpr (F32) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[n & 1], fb[r], acc[n], 0, 0, 0);
+                else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[n & 1], b[r], acc[n], 0, 0, 0);
+            }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int n = 0; n < 4; ++n)
+        for (int e = 0; e < 16; ++e) s += acc[n][e];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; real[blockIdx.x] = r1 - r0; }
+}
+}  // namespace
+
+extern "C" long fgt_mfma_probe_workspace(void) { return 256L * 512 * 4 + 2 * 256 * 8; }
+
+extern "C" int fgt_mfma_probe(int f32, int iters, void* workspace, double* tflops, double* ghz, void* stream) {
+    if (!workspace || iters <= 0) { fgt_set_error("fgt_mfma_probe: workspace / iters"); return FGT_EINVAL; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* out = static_cast<float*>(workspace);
+    unsigned long long* cyc = reinterpret_cast<unsigned long long*>(out + 256 * 512);
+    unsigned long long* real = cyc + 256;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { fgt_set_error("fgt_mfma_probe: hipEventCreate"); return FGT_ELAUNCH; }
+    // warm the clocks into their loaded state, then the timed launch
+    for (int rep = 0; rep < 2; ++rep) {
+        if (rep == 1) hipEventRecord(e0, s);
+        if (f32) hipLaunchKernelGGL(mfma_probe_kernel<true>, dim3(256), dim3(512), 0, s, out, iters, cyc, real);
+        else hipLaunchKernelGGL(mfma_probe_kernel<false>, dim3(256), dim3(512), 0, s, out, iters, cyc, real);
+    }
+    hipEventRecord(e1, s);
+    int rc = fgt_check_launch("mfma_probe");
+    if (rc == FGT_OK && hipEventSynchronize(e1) != hipSuccess) { fgt_set_error("fgt_mfma_probe: sync"); rc = FGT_ELAUNCH; }
+    if (rc == FGT_OK) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> h(512);
+        if (hipMemcpy(h.data(), cyc, 512 * 8, hipMemcpyDeviceToHost) != hipSuccess) { fgt_set_error("fgt_mfma_probe: copy"); rc = FGT_ELAUNCH; }
+        else {
+            double g = 0;
+            for (int i = 0; i < 256; ++i) g += (double)h[i] / ((double)h[256 + i] * 10.0);
+            const double flops_per_mfma = f32 ? 2.0 * 32 * 32 * 2 : 2.0 * 32 * 32 * 16;
+            if (tflops) *tflops = (double)iters * 8 * flops_per_mfma * 256 * 8 / (ms * 1e-3) / 1e12;
+            if (ghz) *ghz = g / 256;
+        }
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return rc;
 }

@@ -738,3 +738,14 @@ def prof_collect(kind="conv"):
     ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_long()
     check(_lib.lib().fgt_prof_collect_kind(PROF_KINDS[kind], C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)), "fgt_prof_collect_kind")
     return ms.value, fl.value, n.value, by.value
+
+
+def mfma_probe(f32=False, iters=20000, device=None):
+    """Sustained rate of the matrix cores on random operands and the shader clock they run at under that load (fgt_mfma_probe):
+    (TFLOP/s, GHz).  The nominal peaks (2.5 PF bf16, 157.3 TF fp32) assume 2.4 GHz; the chip clocks to its power budget."""
+    dev = torch.device(device or "cuda:0")
+    _require_dev(dev)
+    ws = torch.empty(_lib.lib().fgt_mfma_probe_workspace(), dtype=torch.uint8, device=dev)
+    tf, ghz = C.c_double(), C.c_double()
+    check(_lib.lib().fgt_mfma_probe(int(bool(f32)), int(iters), ws.data_ptr(), C.byref(tf), C.byref(ghz), _stream()), "fgt_mfma_probe")
+    return tf.value, ghz.value

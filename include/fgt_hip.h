@@ -348,6 +348,14 @@ void fgt_prof_enable(int on);
 int fgt_prof_collect_kind(int kind, double* total_ms, double* total_flops, double* total_bytes, long* launches);
 int fgt_prof_collect(double* total_ms, double* total_flops, long* launches); /* = kind FGT_PROF_CONV */
 
+/* ---- sustained matrix-core rate of this chip (bench.py: `roofline.sustained`) ----
+ * 256 workgroups x 8 wavefronts of back-to-back independent MFMAs (f32 = 0: v_mfma_f32_32x32x16_bf16, 1: v_mfma_f32_32x32x2_f32) on
+ * random operands held in registers; returns the rate of the second of two launches and the shader clock the workgroups measured
+ * (d s_memtime / d s_memrealtime).  The nominal peaks assume 2.4 GHz; under load the chip clocks to its power budget.
+ * Synchronises the stream; workspace >= fgt_mfma_probe_workspace() bytes of device memory. */
+long fgt_mfma_probe_workspace(void);
+int fgt_mfma_probe(int f32, int iters, void* workspace, double* tflops, double* ghz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,126 @@
+// Micro-benchmark: sustained global -> LDS rate per CU of global_load_lds_dwordx4 (and, for comparison, global_load_dwordx4 into
+// registers) as a function of the access shape (bytes a row contributes to one 1-KB wave instruction: 64 / 128 / 1024), of the
+// footprint (L1-sized / L2-sized / beyond L2) and of the wavefronts per CU.  Every CU gets the same number of workgroups in one round.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/lds_dma_rate.hip -o tools/micro/bin/lds_dma_rate && tools/micro/bin/lds_dma_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One workgroup = NW wavefronts.  Per iteration every wavefront issues PIECES 1-KB instructions, then waits until at most PIECES are
+// outstanding (two iterations in flight).  The workgroup walks a [rows x row_stride] byte matrix like an implicit-GEMM A tile: its
+// NW * PIECES * (1024 / seg) rows are fixed, the k offset advances by `seg` bytes per iteration and wraps at `kwrap`.
+template <int MODE, int PIECES>   // MODE 0: LDS-DMA, 1: loads into registers
+__global__ void __launch_bounds__(1024) rate_kernel(const char* src, long row_stride, int seg, int kwrap, int iters, long wg_rows_stride, int row_mod,
+                                                   unsigned long long* cycles, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lanes_per_row = seg / 16, rows_per_piece = 64 / lanes_per_row;
+    const int r = lane / lanes_per_row, c = lane % lanes_per_row;
+    const char* base[PIECES];
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+        long row = (long)blockIdx.x * wg_rows_stride + (long)(wave * PIECES + p) * rows_per_piece + r;
+        if (row_mod) row %= row_mod;
+        base[p] = src + row * row_stride + c * 16;
+    }
+    char* dst = lds + wave * PIECES * 1024;
+    f32x4 regs[PIECES];
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) regs[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) {
+            if constexpr (MODE == 0) {
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(base[p] + k), (lds_ptr_t)(dst + p * 1024), 16, 0, 0);
+            } else {
+                // "+v": the destination stays live across the loop, so the allocator cannot hand these registers to an address while a load
+                // is still in flight (the compiler does not see the asynchronous write)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(regs[p]) : "v"(base[p] + k));
+            }
+        }
+        k += seg;
+        if (k >= kwrap) k = 0;
+        if constexpr (PIECES == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if constexpr (PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+    float acc = 0.f;
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) acc += regs[p][0];
+    if (sink && lane == 0) sink[blockIdx.x * nw + wave] = acc + lds[threadIdx.x];
+}
+
+template <int MODE, int PIECES>
+void run(const char* src, size_t bytes, int nw, int wgs_per_cu, int seg, long row_stride, int kwrap, const char* label, int row_mod = 0) {
+    const int grid = 256 * wgs_per_cu, iters = 400;
+    unsigned long long* cyc;
+    hipMalloc(&cyc, grid * sizeof(unsigned long long));
+    const int rows_per_wg = nw * PIECES * (64 / (seg / 16));
+    long wg_rows_stride = rows_per_wg;
+    if ((long)grid * rows_per_wg * row_stride > (long)bytes) wg_rows_stride = 0;   // small footprint: every workgroup reads the same rows
+    const size_t smem = 160 * 1024 / wgs_per_cu - 1024;                           // forces exactly wgs_per_cu workgroups per CU
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&rate_kernel<MODE, PIECES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    for (int rep = 0; rep < 2; ++rep)
+        hipLaunchKernelGGL((rate_kernel<MODE, PIECES>), dim3(grid), dim3(nw * 64), smem, 0, src, row_stride, seg, kwrap, iters, wg_rows_stride, row_mod, cyc, nullptr);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((rate_kernel<MODE, PIECES>), dim3(grid), dim3(nw * 64), smem, 0, src, row_stride, seg, kwrap, iters, wg_rows_stride, row_mod, cyc, nullptr);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(grid);
+    hipMemcpy(h.data(), cyc, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double mean = 0;
+    for (auto v : h) mean += (double)v;
+    mean /= grid;
+    const double bytes_wg = (double)iters * nw * PIECES * 1024;
+    const double foot = row_mod ? (double)row_mod * kwrap : wg_rows_stride ? (double)grid * rows_per_wg * kwrap : (double)rows_per_wg * kwrap;
+    printf("%-4s seg %4d B  %2d waves x %d WG/CU  pieces/iter %d  footprint %8.2f MB (%s): %6.1f B/clk/CU (%5.0f cycles per 1-KB instr per CU), %6.2f TB/s chip\n",
+           MODE == 0 ? "DMA" : "REG", seg, nw, wgs_per_cu, PIECES, foot / 1e6, label, bytes_wg * wgs_per_cu / mean, mean / (iters * nw * PIECES * wgs_per_cu),
+           bytes_wg * grid / (ms * 1e-3) / 1e12);
+    hipFree(cyc);
+}
+
+int main() {
+    const size_t bytes = 1ull << 30;
+    char* src;
+    hipMalloc(&src, bytes);
+    hipMemset(src, 1, bytes);
+    // conv-like: rows 1280 B apart (640 channels of bf16); footprints: 8 KB (L1), 2.6 MB shared by every workgroup (fits each XCD's L2),
+    // 84 MB (Infinity Cache), 1 GB streamed once (HBM)
+    for (int seg : {64, 128, 1024}) {
+        const long stride = seg == 1024 ? 1024 : 1280;
+        const int wrap = seg == 1024 ? 1024 : 1280;
+        run<0, 4>(src, bytes, 8, 2, seg, stride, 128 < seg ? seg : 128, "L1", 64);
+        run<1, 4>(src, bytes, 8, 2, seg, stride, 128 < seg ? seg : 128, "L1", 64);
+        run<0, 4>(src, bytes, 8, 2, seg, stride, wrap, "L2", 2048);
+        run<1, 4>(src, bytes, 8, 2, seg, stride, wrap, "L2", 2048);
+        run<0, 4>(src, bytes, 8, 2, seg, stride, wrap, "Infinity Cache", 65536);
+    }
+    // wavefront count / depth at the conv's shape (64-B segments), L2-resident
+    for (int nw : {4, 8, 16}) run<0, 4>(src, bytes, nw, 1, 64, 1280, 1280, "L2", 2048);
+    run<0, 8>(src, bytes, 8, 2, 64, 1280, 1280, "L2, 16 KB/wave in flight", 2048);
+    run<0, 2>(src, bytes, 8, 2, 64, 1280, 1280, "L2, 4 KB/wave in flight", 2048);
+    run<0, 8>(src, bytes, 8, 1, 128, 1280, 1280, "L2", 2048);
+    run<0, 8>(src, bytes, 16, 1, 128, 1280, 1280, "L2", 2048);
+    run<0, 4>(src, bytes, 16, 2, 64, 1280, 1280, "L2, 32 waves/CU", 2048);
+    // streaming (no reuse): every row read once
+    run<0, 4>(src, bytes, 8, 2, 128, 8192, 8192, "streaming: HBM");
+    run<1, 4>(src, bytes, 8, 2, 128, 8192, 8192, "streaming: HBM");
+    hipFree(src);
+    return 0;
+}
