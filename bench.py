@@ -243,8 +243,8 @@ def main():
                         "algorithmic_tflops": round(fl / (ms * 1e-3) / 1e12, 2), "mfma_passes_per_product": passes,
                         "launches": n, "avg_launch_us": round(1e3 * ms / n, 2), "kernel_ms_per_step": round(ms / args.steps, 3),
                         "share_of_step": round(ms / (1e3 * dt), 3)})
-            if sus and sus.get("peak"):
-                out[-1]["sustained"] = dict(sus, frac=round(ach / sus["peak"], 4))
+            if sus:
+                out[-1]["sustained"] = dict(sus, frac=round(ach / sus["peak"], 4)) if sus.get("peak") else sus
         out.sort(key=lambda r: -r["share_of_step"])
         return out
 

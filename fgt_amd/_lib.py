@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
 class AttnDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("mode", "b", "t", "h", "w", "nh", "nw", "heads", "group", "ws", "n_global",
                                        "ldq", "qoff", "ldk", "koff", "ldv", "voff", "ldg_k", "ldg_v", "ldo", "precision", "out_split")] + \
-               [("pso", C.c_longlong)] + [(n, C.c_int) for n in ("in_split", "reserved1")] + \
+               [("pso", C.c_longlong)] + [(n, C.c_int) for n in ("in_split", "tq")] + \
                [(n, C.c_longlong) for n in ("psq", "psk", "psv", "psg_k", "psg_v")]
 
 

@@ -182,7 +182,8 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_kernel(const AttnP p) {
         long orow;
         bool keep = true;
         if (d.mode == 0) {
-            orow = qpix;
+            // tq: only the first tq frames of every batch element are queried and O holds b * tq frames, compactly
+            orow = qpix - (d.tq > 0 ? (long)(pr.frame0 / d.t) * (d.t - d.tq) * d.nh * d.nw : 0);
         } else {
             const int fr = qpix / (d.nh * d.nw), rem = qpix - fr * (d.nh * d.nw);
             const int y = rem / d.nw, x = rem - y * d.nw;
@@ -432,7 +433,8 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_bf16x3_kernel(const AttnP p) 
         long orow;
         bool keep = true;
         if (d.mode == 0) {
-            orow = qpix;
+            // tq: only the first tq frames of every batch element are queried and O holds b * tq frames, compactly
+            orow = qpix - (d.tq > 0 ? (long)(pr.frame0 / d.t) * (d.t - d.tq) * d.nh * d.nw : 0);
         } else {
             const int fr = qpix / (d.nh * d.nw), rem = qpix - fr * (d.nh * d.nw);
             const int y = rem / d.nw, x = rem - y * d.nw;
@@ -493,7 +495,9 @@ extern "C" int fgt_attention(const fgt_attn_desc* dd, const void* Qv, const void
     if (d.mode == 0) {
         FGT_REQUIRE(d.group > 0 && d.nh % d.group == 0 && d.nw % d.group == 0, "fgt_attention: grid %dx%d not divisible into %d zones", d.nh, d.nw, d.group);
         p.zh = d.nh / d.group; p.zw = d.nw / d.group;
-        p.n_q = p.n_k = p.n_loc = d.t * p.zh * p.zw;
+        FGT_REQUIRE(d.tq >= 0 && d.tq <= d.t, "fgt_attention: tq %d outside [0, t = %d]", d.tq, d.t);
+        p.n_k = p.n_loc = d.t * p.zh * p.zw;
+        p.n_q = (d.tq > 0 ? d.tq : d.t) * p.zh * p.zw;        // zone tokens are ordered (frame, y, x): the queried frames are a prefix
         problems = d.b * d.group * d.group * d.heads;
     } else if (d.mode == 1) {
         FGT_REQUIRE(d.ws > 0 && d.nh % d.ws == 0 && d.nw % d.ws == 0 && d.h <= d.nh && d.w <= d.nw && d.h > 0 && d.w > 0, "fgt_attention: bad window geometry");
@@ -512,7 +516,8 @@ extern "C" int fgt_attention(const fgt_attn_desc* dd, const void* Qv, const void
     FGT_REQUIRE(d.out_split == 0 || (d.out_split == 1 && d.pso > 0 && d.pso % 4 == 0), "fgt_attention: bad out_split / pso");
     // unique-byte floor: every Q, K, V row of the maps and every global token once, the output once (4 B per value)
     const double rows_in = (double)d.b * d.t * d.nh * d.nw, cc = (double)d.heads * HD;
-    const double attn_bytes = 4.0 * cc * (3.0 * rows_in + (d.mode == 1 ? 2.0 * d.b * d.t * d.n_global + (double)d.b * d.t * d.h * d.w : rows_in));
+    const double q_frac = (d.mode == 0 && d.tq > 0) ? (double)d.tq / d.t : 1.0;     // Q and O rows that exist
+    const double attn_bytes = 4.0 * cc * ((2.0 + q_frac) * rows_in + (d.mode == 1 ? 2.0 * d.b * d.t * d.n_global + (double)d.b * d.t * d.h * d.w : q_frac * rows_in));
     const int prof = fgt_prof_begin(d.mode == 0 ? FGT_PROF_ATTN_TEMPORAL : FGT_PROF_ATTN_SPATIAL,
                                     4.0 * (double)p.n_q * p.n_k * HD * problems, attn_bytes, s);
     if (d.in_split) {

@@ -257,7 +257,8 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
         long orow;
         bool keep = true;
         if (d.mode == 0) {
-            orow = qpix;
+            // tq: only the first tq frames of every batch element are queried and O holds b * tq frames, compactly
+            orow = qpix - (d.tq > 0 ? (long)(pr.frame0 / d.t) * (d.t - d.tq) * d.nh * d.nw : 0);
         } else {
             const int fr = qpix / (d.nh * d.nw), rem = qpix - fr * (d.nh * d.nw);
             const int y = rem / d.nw, x = rem - y * d.nw;

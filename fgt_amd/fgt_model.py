@@ -313,8 +313,11 @@ class FGT(nn.Module):
         ops.conv2d(F, P["conv2"], stride=s, pad=p, in_relu=not sc, epi="add", aux1=x_res, out=out.view(bt, th, tw, -1))
         return out
 
-    def _temporal(self, x, P, b, t, th, tw, Hf, Wf):
-        """FGT/models/model.py:124-130 + attention_base.py:44-74."""
+    def _temporal(self, x, P, b, t, th, tw, Hf, Wf, tq=None):
+        """FGT/models/model.py:124-130 + attention_base.py:44-74.
+        tq (clip scheduler, last temporal block): only the first tq frames of each of the b windows are produced — every frame still
+        supplies keys and values, but queries, output projection and the FFN are per token, so the rows of the tq*b produced frames are
+        the same values as in the full block; returns [b*tq*n, c]."""
         cfg = self.cfg
         G, c, bt = cfg["group"], cfg["c"], b * t
         zh, zw = math.ceil(th / G), math.ceil(tw / G)
@@ -327,7 +330,11 @@ class FGT(nn.Module):
             s = ops.pad_tokens(s, bt, th, tw, nh, nw)
         # bf16x3 mode: the QKV GEMM hands q, k, v over pre-split; the attention streams K / V tiles by LDS-DMA (csrc/attention_split.hip)
         qkv = ops.linear(s, P["qkv"], out_split="only" if (sc and SPLIT_ATTENTION) else None)
-        a = ops.attention_temporal(qkv, b, t, nh, nw, cfg["heads"], G, c, out_split=sc and not padded)
+        a = ops.attention_temporal(qkv, b, t, nh, nw, cfg["heads"], G, c, out_split=sc and not padded, tq=tq)
+        if tq is not None and tq < t:
+            n = th * tw
+            x = x.view(b, t * n, -1)[:, : tq * n].reshape(b * tq * n, -1) if b > 1 else x[: tq * n]     # the residual rows of the produced frames
+            bt = b * tq
         if padded:
             a = ops.pad_tokens(a, bt, nh, nw, th, tw)                      # crop (attention_base.py:71-72)
         x = ops.linear(a, P["out"], epi="add", aux1=x)
@@ -433,31 +440,49 @@ class FGT(nn.Module):
         assert (tok.shape[1], tok.shape[2]) == (th, tw)
         return enc, tok.view(bt * th * tw, -1), ftok.view(bt * th * tw, -1), th, tw
 
-    def transform_decode(self, enc, x, f, b, t, th, tw, n_out=None, keep=None):
+    def transform_decode(self, enc, x, f, b, t, th, tw, n_out=None, keep=None, tq=None, keep_q=None):
         """model.py:272-283 given per-frame features.  Soft composition + decoder run only for the frames whose output is
         consumed — the tool discards the decoded reference frames (tool/video_inpainting.py:727: only
         `range(len(neighbor_ids))` is read) and both stages are per-frame, so the kept frames are unchanged:
-        `n_out` (b == 1): the first n_out frames; `keep` (any b): an int32 device tensor of frame indices in [0, b*t)."""
+        `n_out` (b == 1): the first n_out frames; `keep` (any b): an int32 device tensor of frame indices in [0, b*t).
+        `tq` (with keep / n_out): the consumed frames are among the first tq of each window's t frames.  Then the LAST transformer pair is
+        pruned as well: its temporal block produces only those tq frames per window (all t frames still act as keys / values) and its
+        spatial block — per frame throughout — runs on them alone; everything the kept frames depend on is computed exactly as before.
+        `keep_q`: `keep` re-indexed for the pruned layout ((j*t + i) -> j*tq + i), precomputed by the caller (else derived here)."""
         P = self.packed()
         cfg = self.cfg
         bt = b * t
+        n = th * tw
         Hf, Wf = enc.shape[1], enc.shape[2]
+        if n_out is not None and tq is None:
+            tq = n_out                                                  # b == 1: the consumed frames are the prefix itself
+        prune = tq is not None and 0 < tq < t and (keep is not None or n_out is not None) and len(P["blocks"]) > 0
         x = self._temporal(x, P["t0"], b, t, th, tw, Hf, Wf)
         if self.ape:
             x = ops.dw3x3_residual(x.view(bt, th, tw, -1), bt, th, tw, *P["pos"]).view(bt * th * tw, -1)
         x = self._spatial(x, f, P["s0"], bt, th, tw, Hf, Wf)
-        for pt, ps in P["blocks"]:
-            x = self._temporal(x, pt, b, t, th, tw, Hf, Wf)
-            x = self._spatial(x, f, ps, bt, th, tw, Hf, Wf)
+        for i, (pt, ps) in enumerate(P["blocks"]):
+            if prune and i == len(P["blocks"]) - 1:
+                x = self._temporal(x, pt, b, t, th, tw, Hf, Wf, tq=tq)                   # [b*tq*n, c]
+                fq = f.view(b, t * n, -1)[:, : tq * n].reshape(b * tq * n, -1) if b > 1 else f[: tq * n]
+                x = self._spatial(x, fq, ps, b * tq, th, tw, Hf, Wf)
+            else:
+                x = self._temporal(x, pt, b, t, th, tw, Hf, Wf)
+                x = self._spatial(x, f, ps, bt, th, tw, Hf, Wf)
         if keep is not None:
             assert n_out is None
-            x = ops.gather_rows(x.view(bt, th * tw, -1), keep).view(keep.numel() * th * tw, -1)
-            enc = ops.gather_rows(enc, keep)
+            if prune:                                                   # frame j*t + i of the full layout is frame j*tq + i of the pruned one
+                enc = ops.gather_rows(enc, keep)
+                keep = keep_q if keep_q is not None else (torch.div(keep, t, rounding_mode="floor") * tq + keep % t).to(torch.int32)
+                x = ops.gather_rows(x.view(b * tq, n, -1), keep).view(keep.numel() * n, -1)
+            else:
+                x = ops.gather_rows(x.view(bt, n, -1), keep).view(keep.numel() * n, -1)
+                enc = ops.gather_rows(enc, keep)
             bt = keep.numel()
         elif n_out is not None and n_out < bt:
             assert b == 1, "n_out needs a single clip (frames of one batch element are contiguous); use keep= for b > 1"
             bt = n_out
-            x, enc = x[: bt * th * tw], enc[:bt]
+            x, enc = x[: bt * n], enc[:bt]
         Y = ops.linear(x, P["v2p"])
         feat = ops.fold(Y, bt, th, tw, P["v2p_c"], cfg["k"][0], cfg["s"][0], cfg["p"][0], Hf, Wf, normalize=False, res=enc)
         D = P["dec"]

@@ -408,9 +408,10 @@ def _attn_in(t):
     return t, (0 if t is None else t.stride(0)), 0
 
 
-def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None, out_split=False):
+def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None, out_split=False, tq=None):
     """Temporal zone attention reading q/k/v in place from a fused [b*t*nh*nw, 3c] projection buffer (fp32, or a Split written by the
-    QKV GEMM: K / V tiles then stream through LDS-DMA, csrc/attention_split.hip)."""
+    QKV GEMM: K / V tiles then stream through LDS-DMA, csrc/attention_split.hip).
+    tq: only the first tq frames of every batch element are queried (keys / values: all t frames); the result has b*tq*nh*nw rows."""
     insp = isinstance(qkv, Split)
     if not insp:
         _require_dev(qkv)
@@ -422,7 +423,10 @@ def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None, out_s
     d.qoff, d.koff, d.voff = 0, c, 2 * c
     d.ldg_k = d.ldg_v = 0
     d.in_split, d.psq, d.psk, d.psv = int(insp), ps, ps, ps
-    out, optr = _attn_out(b * t * nh * nw, c, src.device, out_split, d)
+    tq = t if tq is None else int(tq)
+    assert 0 < tq <= t
+    d.tq = 0 if tq == t else tq
+    out, optr = _attn_out(b * tq * nh * nw, c, src.device, out_split, d)
     d.precision = PREC["bf16x3" if insp else (precision if precision is not None else DEFAULT_ATTN_PRECISION)]
     check(_lib.lib().fgt_attention(C.byref(d), _ptr(src), _ptr(src), _ptr(src), None, None, _ptr(optr), _stream()),
           "fgt_attention(temporal)")
@@ -744,8 +748,11 @@ def mfma_probe(f32=False, iters=20000, device=None):
     """Sustained rate of the matrix cores on random operands and the shader clock they run at under that load (fgt_mfma_probe):
     (TFLOP/s, GHz).  The nominal peaks (2.5 PF bf16, 157.3 TF fp32) assume 2.4 GHz; the chip clocks to its power budget."""
     dev = torch.device(device or "cuda:0")
-    _require_dev(dev)
+    if dev.type != "cuda":
+        raise RuntimeError("fgt_mfma_probe runs on the MI355X (cuda) device")
+    _lib.init_device(dev.index or 0)
     ws = torch.empty(_lib.lib().fgt_mfma_probe_workspace(), dtype=torch.uint8, device=dev)
     tf, ghz = C.c_double(), C.c_double()
-    check(_lib.lib().fgt_mfma_probe(int(bool(f32)), int(iters), ws.data_ptr(), C.byref(tf), C.byref(ghz), _stream()), "fgt_mfma_probe")
+    with torch.cuda.device(dev):
+        check(_lib.lib().fgt_mfma_probe(int(bool(f32)), int(iters), C.c_void_p(ws.data_ptr()), C.byref(tf), C.byref(ghz), _stream()), "fgt_mfma_probe")
     return tf.value, ghz.value

@@ -128,8 +128,10 @@ def compose_torch(out, nb, frames01, masks, comp, visited):
 class ClipRunner:
     def __init__(self, model, frames01, flows_normed, masks, neighbor_stride=5, ref_length=10, num_ref=-1,
                  rank=0, world=1, forward=None, group=None, cache_features=None, encode_chunk=20, use_graphs=False, window_batch=8,
-                 n_streams=None):
+                 n_streams=None, prune_last=True):
         self.model = model
+        # prune_last: the last transformer pair computes only the frames the tool consumes (FGT.transform_decode `tq`): exact
+        self.prune_last = bool(prune_last)
         self.frames01, self.flows, self.masks = frames01, flows_normed, masks
         self.n = frames01.shape[1]
         self.H, self.W = frames01.shape[-2:]
@@ -190,13 +192,19 @@ class ClipRunner:
                 j, i = divmod(o, self.ck)
                 self._row_of[f] = j * world * self.ck + r * self.ck + i
         self.rows = world * self.ck * self.n_chunks if world > 1 else self.n
-        self._group_ids, self._group_keep = [], []
+        self._group_ids, self._group_keep, self._group_tq, self._group_keep_q = [], [], [], []
         for ws in self.groups:
             t = len(self.sched[ws[0]][0]) + len(self.sched[ws[0]][1])
             self._group_ids.append(torch.tensor([self._row_of[f] for wi in ws for f in self.sched[wi][0] + self.sched[wi][1]],
                                                 dtype=torch.int32, device=self.dev))
             self._group_keep.append(torch.tensor([j * t + i for j, wi in enumerate(ws) for i in range(len(self.sched[wi][0]))],
                                                  dtype=torch.int32, device=self.dev))
+            # the consumed (neighbour) frames are the first len(neighbour_ids) of a window: the last transformer pair produces only
+            # the first tq frames of every window of the group (FGT.transform_decode)
+            tq = max(len(self.sched[wi][0]) for wi in ws)
+            self._group_tq.append(tq if self.prune_last else None)
+            self._group_keep_q.append(torch.tensor([j * tq + i for j, wi in enumerate(ws) for i in range(len(self.sched[wi][0]))],
+                                                   dtype=torch.int32, device=self.dev))
         import os
         # window groups on `n_streams` concurrent HIP streams (default 1; FGT_STREAMS): +1.8 % clip throughput with 2 on the bench
         # clip, bit-identical composite — off by default because overlapped launches make the per-launch event timings of
@@ -282,6 +290,7 @@ class ClipRunner:
         """Transformer + decoder for one group of equal-length windows as a single batched forward; returns {window: out}."""
         enc, tok, ftok, th, tw = feats
         ws, ids, keep = self.groups[gi], self._group_ids[gi], self._group_keep[gi]
+        tq, keep_q = self._group_tq[gi], self._group_keep_q[gi]
         b, bt = len(ws), ids.numel()
         t = bt // b
         if self.on_gpu:
@@ -294,11 +303,13 @@ class ClipRunner:
             if self._graphs is None:
                 from .graph import GraphCache
                 # b travels as the SHAPE of a dummy tensor: graphs are cached per input-shape signature (+ weights / arithmetic mode)
-                self._graphs = GraphCache(lambda e_, x_, f_, k_, b_: net.transform_decode(e_, x_, f_, b_.shape[0], e_.shape[0] // b_.shape[0],
-                                                                                       th, tw, keep=k_), state_key=net._cache_key)
-            out = self._graphs(e, x, f, keep, torch.empty(b, device=self.dev)).clone()   # the static buffer is reused by the next group of this shape
+                # (tq as well: 0 = no pruning)
+                self._graphs = GraphCache(lambda e_, x_, f_, k_, kq_, b_, tq_: net.transform_decode(e_, x_, f_, b_.shape[0], e_.shape[0] // b_.shape[0],
+                                                                                                  th, tw, keep=k_, tq=tq_.shape[0] or None, keep_q=kq_),
+                                          state_key=net._cache_key)
+            out = self._graphs(e, x, f, keep, keep_q, torch.empty(b, device=self.dev), torch.empty(tq or 0, device=self.dev)).clone()   # the static buffer is reused by the next group of this shape
         else:
-            out = net.transform_decode(e, x, f, b, t, th, tw, keep=keep)
+            out = net.transform_decode(e, x, f, b, t, th, tw, keep=keep, tq=tq, keep_q=keep_q)
         outs, o = {}, 0
         for wi in ws:
             nb = len(self.sched[wi][0])

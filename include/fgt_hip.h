@@ -186,7 +186,9 @@ typedef struct fgt_attn_desc {
                              * the projection GEMMs (fgt_conv_desc.out_split); ld* / *off in bf16 elements (multiples of 8), lo planes
                              * ps* elements further.  K / V tiles then travel global -> LDS by LDS-DMA and nothing is converted in the
                              * kernel (csrc/attention_split.hip); Q is stored unscaled and 1/sqrt(d) multiplies the fp32 scores.   */
-    int reserved1;
+    int tq;                 /* mode 0: 0 = every frame queries; 0 < tq <= t: only the first tq frames of each batch element do (K / V still
+                             * span all t frames) and O holds b * tq frames compactly — the clip scheduler's last temporal block, whose
+                             * other frames nobody reads (tool/video_inpainting.py:727 consumes the neighbour frames only)            */
     long long psq, psk, psv, psg_k, psg_v;
 } fgt_attn_desc;
 

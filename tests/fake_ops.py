@@ -156,15 +156,17 @@ def _unsplit(*ts):
     return ts
 
 
-def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None, out_split=False):
+def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None, out_split=False, tq=None):
     (qkv,) = _unsplit(qkv)
     zh, zw, d = nh // group, nw // group, c // heads
+    tq = t if tq is None else tq
 
-    def zones(y):
-        return y.reshape(b, t, group, zh, group, zw, heads, d).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, group * group, heads, -1, d)
+    def zones(y, tt=t):
+        return y.reshape(b, tt, group, zh, group, zw, heads, d).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, group * group, heads, -1, d)
 
-    a = _sdpa(zones(qkv[:, :c]), zones(qkv[:, c:2 * c]), zones(qkv[:, 2 * c:3 * c]))
-    return _emit(a.view(b, group, group, heads, t, zh, zw, d).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(b * t * nh * nw, c), None, out_split)
+    q = qkv[:, :c].reshape(b, t, nh * nw, c)[:, :tq].reshape(b * tq * nh * nw, c)        # queries: the first tq frames of each batch element
+    a = _sdpa(zones(q, tq), zones(qkv[:, c:2 * c]), zones(qkv[:, 2 * c:3 * c]))
+    return _emit(a.view(b, group, group, heads, tq, zh, zw, d).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(b * tq * nh * nw, c), None, out_split)
 
 
 def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, precision=None, out_split=False):

@@ -51,6 +51,10 @@ def test_cliprunner_cache_batch8_matches_oracle_clip(prec, max_rate, clip46, mon
     assert rate < max_rate
     # every HIP variant of the same arithmetic is bit-identical: no cache (the reference's work), batch 1, graph replay
     assert torch.equal(ClipRunner(m, fr, fl, ms, cache_features=False).run().cpu(), got)
+    # `got` had the last transformer pair pruned to the consumed frames (queries of the first tq frames only): same bits without it
+    assert all(tq is not None and tq < len(r.sched[g[0]][0]) + len(r.sched[g[0]][1]) for g, tq in zip(r.groups, r._group_tq))
+    full = ClipRunner(m, fr, fl, ms, cache_features=True, window_batch=8, prune_last=False)
+    assert all(tq is None for tq in full._group_tq) and torch.equal(full.run().cpu(), got)
     assert torch.equal(ClipRunner(m, fr, fl, ms, cache_features=True, window_batch=1, use_graphs=False).run().cpu(), got)
     g = ClipRunner(m, fr, fl, ms, cache_features=True, window_batch=8, use_graphs=True)
     assert torch.equal(g.run().cpu(), got) and torch.equal(g.run().cpu(), got)

@@ -479,6 +479,26 @@ def test_attention_temporal_split_inputs(b, t, nh, nw, dev):
     assert torch.equal(ops.attention_temporal(view, b, t, nh, nw, heads, G, c), out)
 
 
+@pytest.mark.parametrize("b,t,tq,nh,nw", [(1, 5, 3, 20, 36), (3, 4, 1, 6, 8), (2, 17, 11, 20, 36), (1, 26, 11, 40, 72)])
+@pytest.mark.parametrize("kind", ["fp32", "bf16x3", "split"])
+def test_attention_temporal_query_prefix(b, t, tq, nh, nw, kind, dev):
+    """fgt_attn_desc.tq: queries of the first tq frames of every batch element only (keys / values: all t frames), O compact —
+    the rows must be the very bits of the full call (HIP vs HIP; the full call is checked against fp64 above)."""
+    from fgt_amd import ops
+    heads, G, c = 4, 2, 512
+    qkv = _rand(b * t * nh * nw, 3 * c, seed=300 + t).to(dev)
+    src = ops.split(qkv) if kind == "split" else qkv
+    prec = None if kind == "split" else kind
+    full = ops.attention_temporal(src, b, t, nh, nw, heads, G, c, precision=prec)
+    part = ops.attention_temporal(src, b, t, nh, nw, heads, G, c, precision=prec, tq=tq)
+    n = nh * nw
+    assert part.shape == (b * tq * n, c)
+    assert torch.equal(part.view(b, tq * n, c), full.view(b, t * n, c)[:, : tq * n])
+    if kind == "split":
+        ps = ops.attention_temporal(src, b, t, nh, nw, heads, G, c, tq=tq, out_split=True)
+        assert torch.equal(ps.float(), ops.split(part).float())
+
+
 def test_attention_split_forced_rescale(dev):
     from fgt_amd import ops
     b, t, nh, nw, heads, G, c = 1, 4, 8, 8, 4, 2, 512
@@ -512,3 +532,14 @@ def test_attention_spatial_split_inputs(bt, h, w, dev):
     a = a.transpose(2, 3).reshape(bt, gh, gw, ws, ws, c).transpose(2, 3).reshape(bt, nh, nw, c)[:, :h, :w].reshape(bt * h * w, c)
     out = ops.attention_spatial(qs, ks[:rows], vs[:rows], ks[rows:], vs[rows:], bt, h, w, nh, nw, heads, ws, ng)
     assert report(f"attn spatial split-in bt{bt} {h}x{w}", out.cpu(), a)[1] < 1e-4
+
+
+def test_mfma_probe_reports_a_plausible_sustained_rate(dev):
+    """fgt_mfma_probe (bench.py's `roofline.sustained`): rates below the nominal peaks, clock within the part's range."""
+    from fgt_amd import ops
+    tf, ghz = ops.mfma_probe(f32=False, iters=4000, device=dev)
+    print(f"[probe] bf16 MFMA sustained {tf:.0f} TFLOP/s at {ghz:.2f} GHz")
+    assert 800 < tf < 2600 and 1.0 < ghz < 2.6
+    tf32, ghz32 = ops.mfma_probe(f32=True, iters=1000, device=dev)
+    print(f"[probe] fp32 MFMA sustained {tf32:.0f} TFLOP/s at {ghz32:.2f} GHz")
+    assert 60 < tf32 < 165 and 1.0 < ghz32 < 2.6

@@ -45,6 +45,23 @@ def test_cached_equals_uncached_equals_oracle(monkeypatch):
         fgt_model.ops, fgt_model.PackedConv = real_ops, real_pc
 
 
+def test_last_pair_pruning_is_exact():
+    """The last temporal + spatial block computed only for the frames the tool consumes (transform_decode tq / keep_q) == all frames."""
+    real_ops, real_pc = fgt_model.ops, fgt_model.PackedConv
+    try:
+        m, sd, fr, fl, ms = _setup()
+        full = ClipRunner(m, fr, fl, ms, neighbor_stride=3, ref_length=4, cache_features=True, window_batch=4, prune_last=False)
+        pruned = ClipRunner(m, fr, fl, ms, neighbor_stride=3, ref_length=4, cache_features=True, window_batch=4)
+        assert all(tq is None for tq in full._group_tq) and any(tq is not None for tq in pruned._group_tq)
+        for g, tq, kq, k in zip(pruned.groups, pruned._group_tq, pruned._group_keep_q, pruned._group_keep):
+            t = len(pruned.sched[g[0]][0]) + len(pruned.sched[g[0]][1])
+            assert tq == max(len(pruned.sched[w][0]) for w in g) and kq.tolist() == [(i // t) * tq + i % t for i in k.tolist()]
+        a, b = full.run(), pruned.run()
+        assert (b - a).abs().max().item() <= 1.0 and ((b - a).abs() > 0).float().mean().item() < 1e-3
+    finally:
+        fgt_model.ops, fgt_model.PackedConv = real_ops, real_pc
+
+
 def test_window_batching_is_exact():
     """Equal-length windows batched as b > 1 through transform_decode(keep=...) == one window per forward (the CPU spec's
     torch convs may differ in the last bit with the batch size, hence the same +-1 uint8 allowance as above)."""
