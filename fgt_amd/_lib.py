@@ -33,7 +33,8 @@ class AttnDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("mode", "b", "t", "h", "w", "nh", "nw", "heads", "group", "ws", "n_global",
                                        "ldq", "qoff", "ldk", "koff", "ldv", "voff", "ldg_k", "ldg_v", "ldo", "precision", "out_split")] + \
                [("pso", C.c_longlong)] + [(n, C.c_int) for n in ("in_split", "tq")] + \
-               [(n, C.c_longlong) for n in ("psq", "psk", "psv", "psg_k", "psg_v")]
+               [(n, C.c_longlong) for n in ("psq", "psk", "psv", "psg_k", "psg_v")] + \
+               [(n, C.c_int) for n in ("compact", "pad_row")]
 
 
 _P = C.c_void_p
@@ -50,7 +51,7 @@ SIGNATURES = {
     "fgt_split": [_P, _L, _I, _I, _P, _I, C.c_longlong, _I, _P],
     "fgt_layernorm": [_P, _I, _I, _P, _I, _I, _L, _F, _P, _P, _P, _I, _P, _P, _P, _I, C.c_longlong, C.c_longlong, _P],
     "fgt_attention": [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P],
-    "fgt_dw_pool": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
+    "fgt_dw_pool": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "fgt_dw3x3_residual": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
     "fgt_fold": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, C.c_longlong, _P],
     "fgt_nchw_to_nhwc": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _F, _P],

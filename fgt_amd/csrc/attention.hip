@@ -31,6 +31,16 @@ constexpr int KLD = HD + 4;  // K tile row stride (floats): float4-aligned, conf
 
 struct Prob { int frame0, zi, zj, hd; };
 
+// mode 1 with desc.compact: row of the Q / K / V maps that padded-grid pixel `pix` (index into [bt, nh, nw]) reads
+__device__ __forceinline__ long attn_map_row(const fgt_attn_desc& d, long pix) {
+    if (d.mode != 1 || !d.compact) return pix;
+    const int plane = d.nh * d.nw;
+    const int fr = (int)(pix / plane), rem = (int)(pix - (long)fr * plane);
+    const int y = rem / d.nw, x = rem - y * d.nw;
+    return (y < d.h && x < d.w) ? ((long)fr * d.h + y) * d.w + x : (long)d.pad_row;
+}
+
+
 // pixel index (row of a [bt, nh, nw] map) of local token n of the problem
 __device__ __forceinline__ int local_pix(const AttnP& p, const Prob& pr, int n) {
     const fgt_attn_desc& d = p.d;
@@ -53,7 +63,7 @@ __device__ __forceinline__ void key_pointers(const AttnP& p, const Prob& pr, int
         const fgt_attn_desc& d = p.d;
         const int key = min(k0 + tid, p.n_k - 1);
         if (key < p.n_loc) {
-            const long pix = local_pix(p, pr, key);
+            const long pix = attn_map_row(d, local_pix(p, pr, key));
             kptr[tid] = p.K + pix * d.ldk + d.koff + choff;
             vptr[tid] = p.V + pix * d.ldv + d.voff + choff;
         } else {
@@ -98,7 +108,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_kernel(const AttnP p) {
     const int qpix = local_pix(p, pr, min(qi, p.n_q - 1));
     float q[64];
     {
-        const float* qp = p.Q + (long)qpix * d.ldq + d.qoff + choff + 64 * lh;
+        const float* qp = p.Q + attn_map_row(d, qpix) * d.ldq + d.qoff + choff + 64 * lh;
 #pragma unroll
         for (int s4 = 0; s4 < 16; ++s4) {
             const float4 v = *reinterpret_cast<const float4*>(qp + 4 * s4);
@@ -276,7 +286,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_bf16x3_kernel(const AttnP p) 
     const int qpix = local_pix(p, pr, min(qi, p.n_q - 1));
     bf16x8 qh[8], ql[8];
     {
-        const float* qp = p.Q + (long)qpix * d.ldq + d.qoff + choff + 8 * lh;
+        const float* qp = p.Q + attn_map_row(d, qpix) * d.ldq + d.qoff + choff + 8 * lh;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const float4 a = *reinterpret_cast<const float4*>(qp + 16 * s);
@@ -502,6 +512,7 @@ extern "C" int fgt_attention(const fgt_attn_desc* dd, const void* Qv, const void
     } else if (d.mode == 1) {
         FGT_REQUIRE(d.ws > 0 && d.nh % d.ws == 0 && d.nw % d.ws == 0 && d.h <= d.nh && d.w <= d.nw && d.h > 0 && d.w > 0, "fgt_attention: bad window geometry");
         FGT_REQUIRE(d.n_global >= 0 && (d.n_global == 0 || (KG && VG && d.ldg_k % 4 == 0 && d.ldg_v % 4 == 0)), "fgt_attention: global tokens missing");
+        FGT_REQUIRE(d.compact == 0 || (d.compact == 1 && d.pad_row >= 0), "fgt_attention: compact maps need pad_row >= 0");
         p.gh = d.nh / d.ws; p.gw = d.nw / d.ws;
         p.n_q = p.n_loc = d.ws * d.ws;
         p.n_k = p.n_loc + d.n_global;
@@ -515,7 +526,7 @@ extern "C" int fgt_attention(const fgt_attn_desc* dd, const void* Qv, const void
     FGT_REQUIRE(d.precision == 0 || d.precision == 1, "fgt_attention: unknown precision %d", d.precision);
     FGT_REQUIRE(d.out_split == 0 || (d.out_split == 1 && d.pso > 0 && d.pso % 4 == 0), "fgt_attention: bad out_split / pso");
     // unique-byte floor: every Q, K, V row of the maps and every global token once, the output once (4 B per value)
-    const double rows_in = (double)d.b * d.t * d.nh * d.nw, cc = (double)d.heads * HD;
+    const double rows_in = (double)d.b * d.t * ((d.mode == 1 && d.compact) ? (double)d.h * d.w : (double)d.nh * d.nw), cc = (double)d.heads * HD;
     const double q_frac = (d.mode == 0 && d.tq > 0) ? (double)d.tq / d.t : 1.0;     // Q and O rows that exist
     const double attn_bytes = 4.0 * cc * ((2.0 + q_frac) * rows_in + (d.mode == 1 ? 2.0 * d.b * d.t * d.n_global + (double)d.b * d.t * d.h * d.w : q_frac * rows_in));
     const int prof = fgt_prof_begin(d.mode == 0 ? FGT_PROF_ATTN_TEMPORAL : FGT_PROF_ATTN_SPATIAL,

@@ -45,6 +45,16 @@ struct AttnS {
 
 struct Prob { int frame0, zi, zj, hd; };
 
+// mode 1 with desc.compact: row of the Q / K / V maps that padded-grid pixel `pix` (index into [bt, nh, nw]) reads
+__device__ __forceinline__ long attn_map_row(const fgt_attn_desc& d, long pix) {
+    if (d.mode != 1 || !d.compact) return pix;
+    const int plane = d.nh * d.nw;
+    const int fr = (int)(pix / plane), rem = (int)(pix - (long)fr * plane);
+    const int y = rem / d.nw, x = rem - y * d.nw;
+    return (y < d.h && x < d.w) ? ((long)fr * d.h + y) * d.w + x : (long)d.pad_row;
+}
+
+
 __device__ __forceinline__ int local_pix(const AttnS& p, const Prob& pr, int n) {
     const fgt_attn_desc& d = p.d;
     if (d.mode == 0) {
@@ -116,7 +126,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
             const int key = min(tile * KT + tid, p.n_k - 1);
             const __bf16 *kr, *vr;
             if (key < p.n_loc) {
-                const long pix = local_pix(p, pr, key);
+                const long pix = attn_map_row(d, local_pix(p, pr, key));
                 kr = p.K + pix * d.ldk + d.koff + choff;
                 vr = p.V + pix * d.ldv + d.voff + choff;
             } else {
@@ -152,7 +162,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     const int qpix = local_pix(p, pr, min(qi, p.n_q - 1));
     bf16x8 qh[8], ql[8];
     {
-        const __bf16* qp = p.Q + (long)qpix * d.ldq + d.qoff + choff + 8 * lh;
+        const __bf16* qp = p.Q + attn_map_row(d, qpix) * d.ldq + d.qoff + choff + 8 * lh;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             qh[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);

@@ -75,8 +75,10 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* x0, int C0,
 
 // ------------------------------------------------------------------ depthwise k x k stride k ("global tokens")
 __global__ void __launch_bounds__(256) dw_pool_kernel(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1,
-                                                      int bt, int nh, int nw, int k, const float* w, const float* bias,
+                                                      int bt, int nh, int nw, int vh, int vw, int k, const float* w, const float* bias,
                                                       float* out, int ldo) {
+    // (vh, vw) < (nh, nw): the maps hold only the vh x vw real tokens of a frame ([bt*vh*vw] rows); the rest of the nh x nw grid is the
+    // reference's zero padding (attention_flow.py:120-124) and contributes acc + 0 * w == acc
     const int C = C0 + C1, c4n = C >> 2;
     const int gh = nh / k, gw = nw / k;
     const long total = (long)bt * gh * gw * c4n;
@@ -88,7 +90,9 @@ __global__ void __launch_bounds__(256) dw_pool_kernel(const float* x0, int C0, i
         float acc[4] = {bias[c], bias[c + 1], bias[c + 2], bias[c + 3]};
         for (int a = 0; a < k; ++a)
             for (int b = 0; b < k; ++b) {
-                const long pix = ((long)f * nh + gy * k + a) * nw + gx * k + b;
+                const int yy = gy * k + a, xx = gx * k + b;
+                if (yy >= vh || xx >= vw) continue;
+                const long pix = ((long)f * vh + yy) * vw + xx;
                 const float4 v = c < C0 ? *reinterpret_cast<const float4*>(x0 + pix * ld0 + c)
                                         : *reinterpret_cast<const float4*>(x1 + pix * ld1 + (c - C0));
                 const int wi = a * k + b, kk = k * k;
@@ -148,7 +152,7 @@ __global__ void __launch_bounds__(256) dw3x3_res_kernel(const float* x, int bt, 
 // k = 4 (the shipped g_downSize): the 16 taps unrolled, the tap loads issued back to back, weights as float4 rows (the generic kernel
 // above walks the taps with 4 scalar weight loads each and ran at ~1 TB/s).  Same accumulation order: bit-identical results.
 __global__ void __launch_bounds__(256) dw_pool4_kernel(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1,
-                                                       int bt, int nh, int nw, const float* w, const float* bias,
+                                                       int bt, int nh, int nw, int vh, int vw, const float* w, const float* bias,
                                                        float* out, int ldo) {
     const int C = C0 + C1, c4n = C >> 2;
     const int gh = nh / 4, gw = nw / 4;
@@ -161,12 +165,15 @@ __global__ void __launch_bounds__(256) dw_pool4_kernel(const float* x0, int C0, 
         const bool s0 = c < C0;
         const float* src = s0 ? x0 + c : x1 + (c - C0);               // select on the address, loads stay straight-line
         const long ld = s0 ? ld0 : ld1;
-        const long pix0 = ((long)f * nh + gy * 4) * nw + gx * 4;
+        const long pix0 = ((long)f * vh + gy * 4) * vw + gx * 4;
         float4 v[16];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) v[a * 4 + b] = *reinterpret_cast<const float4*>(src + (pix0 + (long)a * nw + b) * ld);
+            for (int b = 0; b < 4; ++b) {
+                const bool in = gy * 4 + a < vh && gx * 4 + b < vw;         // past the real grid: the reference's zero padding
+                v[a * 4 + b] = in ? *reinterpret_cast<const float4*>(src + (pix0 + (long)a * vw + b) * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         float wv[4][16];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -384,18 +391,19 @@ extern "C" int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, 
     return fgt_check_launch("layernorm");
 }
 
-extern "C" int fgt_dw_pool(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, int bt, int nh, int nw, int k,
-                           const float* w, const float* bias, float* out, int ldo, void* stream) {
+extern "C" int fgt_dw_pool(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, int bt, int nh, int nw, int vh, int vw,
+                           int k, const float* w, const float* bias, float* out, int ldo, void* stream) {
     FGT_REQUIRE(x0 && w && bias && out, "fgt_dw_pool: null pointer");
+    FGT_REQUIRE(vh > 0 && vw > 0 && vh <= nh && vw <= nw, "fgt_dw_pool: real grid %dx%d must fit the padded grid %dx%d", vh, vw, nh, nw);
     FGT_REQUIRE(C0 % 4 == 0 && C1 % 4 == 0 && ld0 % 4 == 0 && (C1 == 0 || (x1 && ld1 % 4 == 0)) && ldo % 4 == 0, "fgt_dw_pool: alignment");
     FGT_REQUIRE(k > 0 && nh % k == 0 && nw % k == 0, "fgt_dw_pool: grid %dx%d not divisible by %d", nh, nw, k);
     const long total = (long)bt * (nh / k) * (nw / k) * ((C0 + C1) / 4);
     if (k == 4 && (((uintptr_t)w | (uintptr_t)bias) & 15) == 0)
         hipLaunchKernelGGL(dw_pool4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, bt, nh,
-                           nw, w, bias, out, ldo);
+                           nw, vh, vw, w, bias, out, ldo);
     else
         hipLaunchKernelGGL(dw_pool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, bt, nh,
-                           nw, k, w, bias, out, ldo);
+                           nw, vh, vw, k, w, bias, out, ldo);
     return fgt_check_launch("dw_pool");
 }
 

@@ -348,37 +348,50 @@ class FGT(nn.Module):
         return self._ffn(y, x, P["ffn"], bt, th, tw, Hf, Wf)
 
     def _spatial_attention(self, x, f, P, bt, th, tw):
-        """x + SWMHSA(x, f)  (model.py:145 + attention_flow.py:57-113), global tokens projected once per frame."""
+        """x + SWMHSA(x, f)  (model.py:145 + attention_flow.py:57-113), global tokens projected once per frame.
+        The reference zero-pads the token grid to a multiple of the window (attention_flow.py:120-124: 20x36 -> 24x40, a third more
+        rows) and sends the padded tokens through the re-weighting, the LayerNorms and the q / k / v Linears; all of these act per
+        token, so every padded token carries the SAME values: the projections of a zero row.  Those are computed once (row R of
+        each map: one extra row of the same LayerNorm / GEMM launches) and the attention kernel reads that row for every padded
+        position (fgt_attn_desc.compact) — the padded rows themselves never exist.  Bit-identical to the padded computation."""
         cfg = self.cfg
         ws, gd, c, cf = cfg["ws"], cfg["gd"], cfg["c"], cfg["cf"]
         pad_r, pad_b = (ws - tw % ws) % ws, (ws - th % ws) % ws
         nh, nw = th + pad_b, tw + pad_r
-        rows = bt * nh * nw
-        if pad_r or pad_b:
-            xp = ops.pad_tokens(x, bt, th, tw, nh, nw)
-            fp = ops.pad_tokens(f, bt, th, tw, nh, nw)
-        else:
-            xp, fp = x, f
-        fw = ops.linear(xp, P["rw"], x1=fp, act="sigmoid", epi="mul", aux1=fp)          # f * sigmoid(Linear([x|f]))
+        R = bt * th * tw
+        fw = ops.linear(x, P["rw"], x1=f, act="sigmoid", epi="mul", aux1=f)            # f * sigmoid(Linear([x|f]))
         ng = (nh // gd) * (nw // gd)
         dev = x.device
         sc = self._split_chain()
         new = (lambda r, ch: ops.Split.empty((r, ch), dev)) if sc else (lambda r, ch: torch.empty(r, ch, dtype=torch.float32, device=dev))
-        kin, vin, q_ln = new(rows + bt * ng, c + cf), new(rows + bt * ng, c), new(rows, c + cf)     # LN outputs = GEMM operands
+        # LN outputs = GEMM operands: rows [0, R) real tokens, row R the padded token, rows R+1.. the frames' global tokens
+        kin, vin, q_ln = new(R + 1 + bt * ng, c + cf), new(R + 1 + bt * ng, c), new(R + 1, c + cf)
         gk = torch.empty(bt * ng, c + cf, dtype=torch.float32, device=dev)
         gv = torch.empty(bt * ng, c, dtype=torch.float32, device=dev)
-        ops.dw_pool(xp, fw, bt, nh, nw, gd, *P["gk"], out=gk)
-        ops.dw_pool(xp, None, bt, nh, nw, gd, *P["gv"], out=gv)
-        ops.layernorm(xp, *P["qn"], x1=fw, gB=P["kn"][0], bB=P["kn"][1], outA=q_ln, outB=kin[:rows])
-        ops.layernorm(gk, *P["kn"], outA=kin[rows:])
-        ops.layernorm(xp, *P["vn"], outA=vin[:rows])
-        ops.layernorm(gv, *P["vn"], outA=vin[rows:])
+        ops.dw_pool(x, fw, bt, nh, nw, gd, *P["gk"], out=gk, h=th, w_real=tw)
+        ops.dw_pool(x, None, bt, nh, nw, gd, *P["gv"], out=gv, h=th, w_real=tw)
+        z = self._zero_row(dev, c + cf)
+        ops.layernorm(x, *P["qn"], x1=fw, gB=P["kn"][0], bB=P["kn"][1], outA=q_ln[:R], outB=kin[:R])
+        ops.layernorm(z[:, :c], *P["qn"], x1=z[:, c:], gB=P["kn"][0], bB=P["kn"][1], outA=q_ln[R:R + 1], outB=kin[R:R + 1])
+        ops.layernorm(gk, *P["kn"], outA=kin[R + 1:])
+        ops.layernorm(x, *P["vn"], outA=vin[:R])
+        ops.layernorm(z[:, :c], *P["vn"], outA=vin[R:R + 1])
+        ops.layernorm(gv, *P["vn"], outA=vin[R + 1:])
         osp = "only" if (sc and SPLIT_ATTENTION) else None
         q = ops.linear(q_ln, P["q"], out_split=osp)
         kk = ops.linear(kin, P["k"], out_split=osp)
         vv = ops.linear(vin, P["v"], out_split=osp)
-        a = ops.attention_spatial(q, kk[:rows], vv[:rows], kk[rows:], vv[rows:], bt, th, tw, nh, nw, cfg["heads"], ws, ng, out_split=sc)
+        a = ops.attention_spatial(q, kk[:R + 1], vv[:R + 1], kk[R + 1:], vv[R + 1:], bt, th, tw, nh, nw, cfg["heads"], ws, ng, out_split=sc,
+                                  pad_row=R)
         return ops.linear(a, P["out"], epi="add", aux1=x)
+
+    def _zero_row(self, dev, ch):
+        """One row of zeros (the reference's padded token before the LayerNorms), kept per device."""
+        cache = self.__dict__.setdefault("_zero_rows", {})
+        key = (str(dev), ch)
+        if key not in cache:
+            cache[key] = torch.zeros(1, ch, dtype=torch.float32, device=dev)
+        return cache[key]
 
     # ---- per-frame stages (exposed separately so the clip scheduler can cache them) -------------
     def token_grid(self, H, W):

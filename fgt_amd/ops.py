@@ -433,9 +433,11 @@ def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None, out_s
     return out
 
 
-def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, precision=None, out_split=False):
+def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, precision=None, out_split=False, pad_row=None):
     """Window attention + shared global tokens; q/k/v are [bt*nh*nw, c] maps on the padded grid, output cropped.  All five inputs fp32, or
-    all five Splits (written by the projection GEMMs)."""
+    all five Splits (written by the projection GEMMs).
+    pad_row: the maps are COMPACT — rows [0, bt*h*w) are the real tokens and every zero-padded position of the window grid reads row
+    `pad_row` of q / k / v (the projections of a padded token are one constant row, so the padded rows are never computed)."""
     insp = isinstance(q, Split)
     assert all(isinstance(x, Split) == insp for x in (k, v, kg, vg)), "attention_spatial: inputs must all be fp32 or all be Splits"
     if not insp:
@@ -448,6 +450,9 @@ def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, pr
     (kgt, d.ldg_k, d.psg_k), (vgt, d.ldg_v, d.psg_v) = _attn_in(kg), _attn_in(vg)
     d.qoff = d.koff = d.voff = 0
     d.in_split = int(insp)
+    if pad_row is not None:
+        assert 0 <= pad_row < min(x.shape[0] for x in (q, k, v))
+        d.compact, d.pad_row = 1, int(pad_row)
     out, optr = _attn_out(bt * h * w, c, qt.device, out_split, d)
     d.precision = PREC["bf16x3" if insp else (precision if precision is not None else DEFAULT_ATTN_PRECISION)]
     check(_lib.lib().fgt_attention(C.byref(d), _ptr(qt), _ptr(kt), _ptr(vt), _ptr(kgt), _ptr(vgt), _ptr(optr), _stream()),
@@ -455,11 +460,13 @@ def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, pr
     return out
 
 
-def dw_pool(x0, x1, bt, nh, nw, k, w, bias, out):
-    """Depthwise kxk/stride-k conv over [x0 | x1] padded maps ([bt*nh*nw, C]) -> out [bt*(nh/k)*(nw/k), C0+C1]."""
+def dw_pool(x0, x1, bt, nh, nw, k, w, bias, out, h=None, w_real=None):
+    """Depthwise kxk/stride-k conv over the [x0 | x1] maps on the nh x nw window grid -> out [bt*(nh/k)*(nw/k), C0+C1].
+    (h, w_real): the maps hold only the h x w_real real tokens of every frame ([bt*h*w_real, C]); the rest of the grid is zero padding."""
     _require_dev(x0, x1, w, bias, out)
+    vh, vw = (nh if h is None else h), (nw if w_real is None else w_real)
     check(_lib.lib().fgt_dw_pool(_ptr(x0), x0.shape[1], x0.stride(0), _ptr(x1), 0 if x1 is None else x1.shape[1],
-                                 0 if x1 is None else x1.stride(0), bt, nh, nw, k, _ptr(w), _ptr(bias), _ptr(out),
+                                 0 if x1 is None else x1.stride(0), bt, nh, nw, vh, vw, k, _ptr(w), _ptr(bias), _ptr(out),
                                  out.stride(0), _stream()), "fgt_dw_pool")
     return out
 

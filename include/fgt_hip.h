@@ -190,14 +190,21 @@ typedef struct fgt_attn_desc {
                              * span all t frames) and O holds b * tq frames compactly — the clip scheduler's last temporal block, whose
                              * other frames nobody reads (tool/video_inpainting.py:727 consumes the neighbour frames only)            */
     long long psq, psk, psv, psg_k, psg_v;
+    int compact;            /* mode 1: 1 = the Q / K / V maps hold only the h x w real tokens of every frame ([bt*h*w] rows); the tokens the
+                             * reference zero-pads up to the window grid (attention_flow.py:120-124) all read row `pad_row` of the same
+                             * maps — their projections are one constant row (LN of a zero row = its bias, then the Linear), so the
+                             * padded rows never have to exist.  0 = the maps live on the padded nh x nw grid                     */
+    int pad_row;
 } fgt_attn_desc;
 
 int fgt_attention(const fgt_attn_desc* d, const void* Q, const void* K, const void* V,
                   const void* KG, const void* VG, float* O, void* stream);
 
 /* Depthwise kxk stride-k convolution over [x0 | x1] maps -> global tokens [bt, (nh/k)*(nw/k), C0+C1]
- * (attention_flow.py:44-48,80-81,87-91).  w is the reference layout [C,1,k,k], bias [C]. */
-int fgt_dw_pool(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, int bt, int nh, int nw,
+ * (attention_flow.py:44-48,80-81,87-91).  w is the reference layout [C,1,k,k], bias [C].
+ * The maps hold the vh x vw real tokens of every frame ([bt*vh*vw] rows); the rest of the nh x nw window grid is the reference's
+ * zero padding (attention_flow.py:120-124) and is never materialised (vh == nh, vw == nw: no padding). */
+int fgt_dw_pool(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, int bt, int nh, int nw, int vh, int vw,
                 int k, const float* w, const float* bias, float* out, int ldo, void* stream);
 
 /* Depthwise 3x3, stride 1, pad 1, plus identity: out = dwconv(x) + x  (FGT/models/model.py:76-88). */

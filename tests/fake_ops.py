@@ -169,8 +169,18 @@ def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None, out_s
     return _emit(a.view(b, group, group, heads, tq, zh, zw, d).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(b * tq * nh * nw, c), None, out_split)
 
 
-def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, precision=None, out_split=False):
+def _uncompact(m, bt, h, w, nh, nw, pad_row):
+    """[bt*h*w (+ more), c] compact map -> [bt*nh*nw, c] on the padded grid, padded positions = row pad_row."""
+    c = m.shape[1]
+    out = m[pad_row].reshape(1, 1, 1, c).expand(bt, nh, nw, c).clone()
+    out[:, :h, :w] = m[: bt * h * w].reshape(bt, h, w, c)
+    return out.reshape(bt * nh * nw, c)
+
+
+def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, precision=None, out_split=False, pad_row=None):
     q, k, v, kg, vg = _unsplit(q, k, v, kg, vg)
+    if pad_row is not None:
+        q, k, v = (_uncompact(m, bt, h, w, nh, nw, pad_row) for m in (q, k, v))
     c = q.shape[1]
     gh, gw, d = nh // ws, nw // ws, c // heads
 
@@ -187,9 +197,11 @@ def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, pr
     return _emit(a[:, :h, :w].reshape(bt * h * w, c), None, out_split)
 
 
-def dw_pool(x0, x1, bt, nh, nw, k, w, bias, out):
+def dw_pool(x0, x1, bt, nh, nw, k, w, bias, out, h=None, w_real=None):
     cat = x0 if x1 is None else torch.cat([x0, x1], 1)
     C = cat.shape[1]
+    if h is not None and (h, w_real) != (nh, nw):          # compact maps: zero-pad to the window grid
+        cat = F.pad(cat.reshape(bt, h, w_real, C), (0, 0, 0, nw - w_real, 0, nh - h)).reshape(bt * nh * nw, C)
     y = F.conv2d(cat.reshape(bt, nh, nw, C).permute(0, 3, 1, 2), w, bias, stride=k, groups=C)
     out.copy_(y.permute(0, 2, 3, 1).reshape(-1, C))
     return out

@@ -543,3 +543,56 @@ def test_mfma_probe_reports_a_plausible_sustained_rate(dev):
     tf32, ghz32 = ops.mfma_probe(f32=True, iters=1000, device=dev)
     print(f"[probe] fp32 MFMA sustained {tf32:.0f} TFLOP/s at {ghz32:.2f} GHz")
     assert 60 < tf32 < 165 and 1.0 < ghz32 < 2.6
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Compact token maps (fgt_attn_desc.compact / fgt_dw_pool's real-grid extents): the reference's zero-padded tokens are never
+# materialised — every padded position reads ONE row.  HIP vs HIP: the compact call must give the bits of the call on padded maps
+# (the padded calls are checked against fp64 / torch above).
+def _compact(m, bt, h, w, nh, nw, pad):
+    """[bt*nh*nw, c] padded map whose padded rows all equal `pad` -> ([bt*h*w + 1, c] compact map with the pad row last)."""
+    c = m.shape[1]
+    return torch.cat([m.view(bt, nh, nw, c)[:, :h, :w].reshape(bt * h * w, c), pad.view(1, c)], 0).contiguous()
+
+
+@pytest.mark.parametrize("bt,h,w", [(2, 20, 36), (1, 22, 35), (3, 8, 8), (1, 40, 72)])
+@pytest.mark.parametrize("kind", ["fp32", "bf16x3", "split"])
+def test_attention_spatial_compact_maps(bt, h, w, kind, dev):
+    from fgt_amd import ops
+    heads, ws, gd, c = 4, 8, 4, 512
+    nh, nw = (h + ws - 1) // ws * ws, (w + ws - 1) // ws * ws
+    ng = (nh // gd) * (nw // gd)
+    rows, R = bt * nh * nw, bt * h * w
+    maps = []
+    for i in range(3):                                    # q, k, v on the padded grid, every padded row = one constant row
+        m = _rand(rows, c, seed=40 + i).view(bt, nh, nw, c)
+        pad = _rand(c, seed=50 + i)
+        m[:, h:] = pad
+        m[:, :, w:] = pad
+        maps.append((m.reshape(rows, c).to(dev), pad.to(dev)))
+    kg, vg = _rand(bt * ng, c, seed=60).to(dev), _rand(bt * ng, c, seed=61).to(dev)
+    prec = None if kind == "split" else kind
+    wrap = (lambda t: ops.split(t)) if kind == "split" else (lambda t: t)
+    padded = ops.attention_spatial(*(wrap(m) for m, _ in maps), wrap(kg), wrap(vg), bt, h, w, nh, nw, heads, ws, ng, precision=prec)
+    comp = [wrap(_compact(m, bt, h, w, nh, nw, p)) for m, p in maps]
+    got = ops.attention_spatial(*comp, wrap(kg), wrap(vg), bt, h, w, nh, nw, heads, ws, ng, precision=prec, pad_row=R)
+    assert torch.equal(got, padded)
+
+
+def test_dw_pool_compact_maps(dev):
+    from fgt_amd import ops
+    bt, h, w, nh, nw, gd = 2, 20, 36, 24, 40, 4
+    x0, x1 = _rand(bt, h, w, 512, seed=1), _rand(bt, h, w, 256, seed=2)
+    wt, b = _rand(768, 1, gd, gd, seed=3).to(dev), _rand(768, seed=4).to(dev)
+    pad = lambda t: F.pad(t, (0, 0, 0, nw - w, 0, nh - h)).reshape(bt * nh * nw, -1).to(dev)
+    want = torch.empty(bt * (nh // gd) * (nw // gd), 768, device=dev)
+    ops.dw_pool(pad(x0), pad(x1), bt, nh, nw, gd, wt, b, want)
+    got = torch.empty_like(want)
+    ops.dw_pool(x0.reshape(bt * h * w, -1).to(dev), x1.reshape(bt * h * w, -1).to(dev), bt, nh, nw, gd, wt, b, got, h=h, w_real=w)
+    assert torch.equal(got, want)
+    got3 = torch.empty(bt * (nh // 2) * (nw // 2), 768, device=dev)            # generic (k != 4) kernel
+    want3 = torch.empty_like(got3)
+    w2 = _rand(768, 1, 2, 2, seed=5).to(dev)
+    ops.dw_pool(pad(x0), pad(x1), bt, nh, nw, 2, w2, b, want3)
+    ops.dw_pool(x0.reshape(bt * h * w, -1).to(dev), x1.reshape(bt * h * w, -1).to(dev), bt, nh, nw, 2, w2, b, got3, h=h, w_real=w)
+    assert torch.equal(got3, want3)
