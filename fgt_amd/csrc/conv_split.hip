@@ -48,7 +48,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #ifdef FGT_CONV_TRACE
 // Diagnostic build only (python tools/conv_trace.py): every wavefront stamps s_memtime at the phase boundaries of its first TR_STEPS K-steps
 // into spare LDS and the workgroup dumps them (plus HW_ID / XCC_ID) to a global buffer before the epilogue.  Not part of the product library.
-constexpr int TR_STEPS = 32, TR_NST = 8, TR_HDR = 8;
+constexpr int TR_STEPS = 32, TR_NST = 8, TR_HDR = 12;
 __device__ unsigned* g_conv_trace = nullptr;
 __device__ long g_conv_trace_words = 0;
 #define TR_STAMP(i) ts[i] = __builtin_readcyclecounter()
@@ -625,6 +625,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
 #ifdef FGT_CONV_TRACE
     if (tr_hdr) {
+        tr_hdr[8] = (unsigned)__builtin_readcyclecounter();              // epilogue instructions issued (stores may be in flight)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tr_hdr[6] = (unsigned)__builtin_readcyclecounter();              // epilogue over (stores acknowledged)
         tr_hdr[7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - tr_r0);

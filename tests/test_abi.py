@@ -25,7 +25,7 @@ def test_library_exports_every_symbol():
     h = ctypes.CDLL(_lib.LIB_PATH)
     for s in declared_symbols():
         assert hasattr(h, s), f"{s} not exported"
-    assert _lib.lib().fgt_abi_version() == 4
+    assert _lib.lib().fgt_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_struct_sizes_match_header():
@@ -76,3 +76,13 @@ def test_autotune_alias_guard():
     rows = torch.zeros(100, 64)
     assert not ops._aliases(rows[:50], None, rows[50:]) and ops._aliases(rows[:60], None, rows[50:])
     assert not ops._aliases(torch.zeros(3, 4), None, rows) and not ops._aliases(None, None, rows)
+
+
+def test_entry_build_runs_here():
+    """__graft_entry__.build(): what the driver runs on the CPU box every round (compile for gfx950, import, ABI version)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "built" in r.stdout

@@ -16,12 +16,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 TRACE_LIB = os.path.join(ROOT, "fgt_amd", "lib", "libfgt_hip_trace.so")
-TR_STEPS, TR_NST, TR_HDR = 32, 8, 8
+TR_STEPS, TR_NST, TR_HDR = 32, 8, 12
 
 LAYERS = {  # name: (N, H, W, C0, C1, Cout, groups, k, stride, pad)
     "e20enc10": (20, 60, 108, 256, 384, 512, 2, 3, 1, 1),
     "e20enc8": (20, 60, 108, 256, 0, 384, 1, 3, 1, 1),
     "b8qkv": (1, 1, 97920, 512, 0, 1536, 1, 1, 1, 0),
+    "b8ffn1": (1, 1, 97920, 512, 0, 1960, 1, 1, 1, 0),
 }
 WAVES = {"128x128": 4, "128x128ea": 4, "128x128x8": 8, "128x128x8ea": 8, "256x128x16": 16, "256x128x16ea": 16, "256x64x8": 8, "256x64x8ea": 8, "128x64": 4, "128x64ea": 4}
 
@@ -83,6 +84,8 @@ def main():
         pro = (h64[:, :, 4] - h64[:, :, 2]) & 0xFFFFFFFF
         loop = (h64[:, :, 5] - h64[:, :, 4]) & 0xFFFFFFFF
         epi = (h64[:, :, 6] - h64[:, :, 5]) & 0xFFFFFFFF
+        epi_issue = (h64[:, :, 8] - h64[:, :, 5]) & 0xFFFFFFFF
+        print(f"   epilogue: {np.median(epi_issue):.0f} cycles until the last store is issued (per wavefront, median; p90 {np.percentile(epi_issue, 90):.0f}), {np.median(epi):.0f} until all stores are acknowledged")
         life = ((h64[:, 0, 6] - h64[:, 0, 2]) & 0xFFFFFFFF).astype(np.float64)
         real = h64[:, 0, 7].astype(np.float64)            # 10-ns ticks
         ok = real > 100
