@@ -62,7 +62,7 @@ __device__ long g_conv_trace_words = 0;
 #define TR_STORE(kt)
 #endif
 
-template <int BM, int BN, int WM, int WN, int MINW, int NS, bool PP, bool IL = false, int P8 = 0, bool EA = false>
+template <int BM, int BN, int WM, int WN, int MINW, int NS, bool PP, bool IL = false, int P8 = 0, int EA = 0>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const ConvP p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -530,6 +530,9 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
             __builtin_amdgcn_s_barrier();                   // every wavefront holds its fragments of tile kt: the stage can be refilled
             TR_STAMP(2);
             const bool more = kt + 2 < p.nk;
+            // (DMAs BEFORE the MFMAs on purpose: the vector-memory pipe is the critical resource and has to be fed as early as the stage
+            //  is free.  The opposite order — MFMAs first, DMA issue underneath them — measured 6 % slower on the 3x3 layers:
+            //  profiles/r02_run9_split_sweep_mfma_first.txt)
             if (more) issue_tile(slot);
             __builtin_amdgcn_sched_barrier(0);
             TR_STAMP(3);
@@ -636,7 +639,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2, bool PP = false, bool IL = false, int P8 = 0, bool EA = false>
+template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2, bool PP = false, bool IL = false, int P8 = 0, int EA = 0>
 int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
 #ifdef FGT_CONV_TRACE
@@ -684,12 +687,12 @@ int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_128x128x8_PP: return launch<128, 128, 2, 4, 4, 4, true>(p, s);
         case FGT_TILE_256x128x8_IL: return launch<256, 128, 4, 2, 2, 2, false, true>(p, s);
         // early stage release (two tiles in flight on two stages): the production tiles again, bit-identical results
-        case FGT_TILE_128x128_EA: return launch<128, 128, 2, 2, 2, 2, false, false, 0, true>(p, s);
-        case FGT_TILE_128x64_EA: return launch<128, 64, 2, 2, 2, 2, false, false, 0, true>(p, s);
-        case FGT_TILE_64x64_EA: return launch<64, 64, 2, 2, 2, 2, false, false, 0, true>(p, s);
-        case FGT_TILE_128x128x8_EA: return launch<128, 128, 2, 4, 4, 2, false, false, 0, true>(p, s);
-        case FGT_TILE_256x128x16_EA: return launch<256, 128, 4, 4, 4, 2, false, false, 0, true>(p, s);
-        case FGT_TILE_256x64x8_EA: return launch<256, 64, 4, 2, 2, 2, false, false, 0, true>(p, s);
+        case FGT_TILE_128x128_EA: return launch<128, 128, 2, 2, 2, 2, false, false, 0, 1>(p, s);
+        case FGT_TILE_128x64_EA: return launch<128, 64, 2, 2, 2, 2, false, false, 0, 1>(p, s);
+        case FGT_TILE_64x64_EA: return launch<64, 64, 2, 2, 2, 2, false, false, 0, 1>(p, s);
+        case FGT_TILE_128x128x8_EA: return launch<128, 128, 2, 4, 4, 2, false, false, 0, 1>(p, s);
+        case FGT_TILE_256x128x16_EA: return launch<256, 128, 4, 4, 4, 2, false, false, 0, 1>(p, s);
+        case FGT_TILE_256x64x8_EA: return launch<256, 64, 4, 2, 2, 2, false, false, 0, 1>(p, s);
         case FGT_TILE_256x256_P8: return launch<256, 256, 2, 4, 2, 2, false, false, 3>(p, s);     // 8-phase staggered schedule, setprio around the MFMAs
         case FGT_TILE_256x128_P8: return launch<256, 128, 4, 2, 2, 2, false, false, 3>(p, s);
 #ifdef FGT_P8_ABLATIONS   // A/B and timing-only instances behind profiles/r02_run3_split_sweep_p8*.txt (build with -DFGT_P8_ABLATIONS to reproduce)

@@ -62,6 +62,64 @@ __global__ void __launch_bounds__(1024) rate_kernel(const char* src, long row_st
     if (sink && lane == 0) sink[blockIdx.x * nw + wave] = acc + lds[threadIdx.x];
 }
 
+// The conv's A (im2col) stream of a 3x3 layer, to compare K orders: every workgroup owns 128 consecutive pixels (4 workgroups of the
+// same XCD share them, like the 4 N tiles of one M tile), a step fetches rows pix+tap of one 32-channel chunk of both planes
+// (16 instructions per workgroup) plus a 16-KB weight slab that every workgroup shares.  ORDER 0: tap-major (ky, kx, chunk) — the
+// library's K order: the kx re-read of a row comes CHUNKS steps later; ORDER 1: (ky, chunk, kx) — it comes in the very next step.
+template <int ORDER>
+__global__ void __launch_bounds__(512) conv_like_kernel(const char* act, const char* wts, int chunks, int width, unsigned long long* cycles) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;     // 8 wavefronts: A pieces (plane, 16-row group) = wave + 8*i, i < 2; B 2 pieces
+    const int w = blockIdx.x;
+    const long m_tile = (long)(w >> 5) * 8 + (w & 7);
+    const long row_bytes = (long)chunks * 64;                       // one plane of a pixel: chunks * 32 channels * 2 B
+    const long plane_bytes = row_bytes * ((long)gridDim.x / 4 * 128 + 4 * width + 256);
+    const int r = lane >> 2, c = lane & 3;
+    char* dst = lds + wave * 4 * 1024;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    int step = 0;
+    for (int ky = 0; ky < 3; ++ky)
+        for (int a = 0; a < (ORDER ? chunks : 3); ++a)
+            for (int b = 0; b < (ORDER ? 3 : chunks); ++b, ++step) {
+                const int kx = ORDER ? b : a, ch = ORDER ? a : b;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int piece = wave + 8 * i, plane = piece >> 3, grp = piece & 7;
+                    const long pix = m_tile * 128 + grp * 16 + r + (long)ky * width + kx;
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(act + plane * plane_bytes + pix * row_bytes + ch * 64 + c * 16), (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(wts + ((long)step * 16 + wave * 2 + i) * 1024 + lane * 16), (lds_ptr_t)(dst + (2 + i) * 1024), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) cycles[blockIdx.x] = __builtin_readcyclecounter() - t0;
+}
+
+template <int ORDER>
+void run_conv_like(const char* src, int chunks, int width) {
+    const int grid = 512;
+    unsigned long long* cyc;
+    hipMalloc(&cyc, grid * sizeof(unsigned long long));
+    const size_t smem = 79 * 1024;                                   // two workgroups per CU
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_like_kernel<ORDER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const char* wts = src + (768u << 20);                            // weight slabs in the last quarter of the buffer
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((conv_like_kernel<ORDER>), dim3(grid), dim3(512), smem, 0, src, wts, chunks, width, cyc);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(grid);
+    hipMemcpy(h.data(), cyc, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double mean = 0;
+    for (auto v : h) mean += (double)v;
+    mean /= grid;
+    const int steps = 9 * chunks;
+    printf("conv-like A+B stream, %2d chunks of 32 channels, order %s: %7.0f cycles per step (2 workgroups per CU, 32 KB per step each) = %5.1f B/clk/CU\n",
+           chunks, ORDER ? "(ky, chunk, kx)" : "(ky, kx, chunk)", mean / steps, 2.0 * 32768 * steps / mean);
+    hipFree(cyc);
+}
+
 template <int MODE, int PIECES>
 void run(const char* src, size_t bytes, int nw, int wgs_per_cu, int seg, long row_stride, int kwrap, const char* label, int row_mod = 0) {
     const int grid = 256 * wgs_per_cu, iters = 400;
@@ -121,6 +179,11 @@ int main() {
     // streaming (no reuse): every row read once
     run<0, 4>(src, bytes, 8, 2, 128, 8192, 8192, "streaming: HBM");
     run<1, 4>(src, bytes, 8, 2, 128, 8192, 8192, "streaming: HBM");
+    // K order of a 3x3 layer's im2col stream (see conv_like_kernel)
+    for (int chunks : {4, 8, 10, 20}) {
+        run_conv_like<0>(src, chunks, 108);
+        run_conv_like<1>(src, chunks, 108);
+    }
     hipFree(src);
     return 0;
 }
