@@ -33,16 +33,8 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N <= 15, "vmcnt immediate");
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else static_assert(N == 0, "add the immediate");
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate (6 bits on gfx9)");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 #ifdef FGT_CONV_TRACE
@@ -62,16 +54,20 @@ __device__ long g_conv_trace_words = 0;
 #define TR_STORE(kt)
 #endif
 
-template <int BM, int BN, int WM, int WN, int MINW, int NS, bool PP, bool IL = false, int P8 = 0, int EA = 0>
+template <int BM, int BN, int WM, int WN, int MINW, int NS, bool PP, bool IL = false, int P8 = 0, int EA = 0, bool XY = false>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const ConvP p) {
     constexpr int NW = WM * WN;
+    // XY (with EA): only the upper half of the wavefronts (one per SIMD) issues LDS-DMAs — all of them; the lower half goes straight from
+    // the stage-release barrier into its MFMAs, so the matrix pipe works while the loading half is parked in front of the memory pipe
+    constexpr int NL = XY ? NW / 2 : NW;                // wavefronts that load
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr int STAGE = (BM + BN) * LDB;              // floats per stage (= (BM+BN) * 64 bf16 = hi + lo planes)
     constexpr int GA = BM / 16, GB = BN / 16;           // 16-row DMA groups per plane
-    constexpr int A_IT = GA / NW;                       // A groups per wavefront (hi and lo plane of the same rows)
-    constexpr int B_IT = 2 * GB / NW;                   // B (group, plane) pieces per wavefront: piece j = wave + it*NW -> plane j / GB, group j % GB
-    constexpr int DPT = 2 * A_IT + B_IT;                // DMA instructions per tile and wavefront
-    static_assert(GA % NW == 0 && A_IT >= 1 && (2 * GB) % NW == 0 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile / wavefront geometry");
+    constexpr int A_IT = GA / NL;                       // A groups per loading wavefront (hi and lo plane of the same rows)
+    constexpr int B_IT = 2 * GB / NL;                   // B (group, plane) pieces per loading wavefront: piece j = lwave + it*NL -> plane j / GB, group j % GB
+    constexpr int DPT = 2 * A_IT + B_IT;                // DMA instructions per tile and loading wavefront
+    static_assert(GA % NL == 0 && A_IT >= 1 && (2 * GB) % NL == 0 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile / wavefront geometry");
+    static_assert(!XY || (EA && NW % 2 == 0), "XY: early-release tiles with an even wavefront count");
     static_assert(NS >= 2 && NS <= 4, "LDS ring depth");
     static_assert(!PP || (NS >= 3 && NW % 2 == 0), "ping-pong needs a ring of >= 3 stages and an even wavefront count");
     static_assert(!IL || (NS == 2 && !PP && TM >= 2), "interleaved schedule: double buffer, >= 2 row blocks per wavefront");
@@ -84,6 +80,9 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    const bool loads = !XY || wave >= NW / 2;           // (wave-uniform) this wavefront issues DMAs
+    const int lwave = XY ? (wave & (NL - 1)) : wave;     // its index among the loading wavefronts (the others never issue: any valid index)
+    static_assert(!XY || (NL & (NL - 1)) == 0, "XY: power-of-two loader count");
     int m_idx, n_idx;
     if (!conv_tile_index(p, m_idx, n_idx)) return;
     const int bm0 = m_idx * BM, bn0 = n_idx * BN, g = blockIdx.y;
@@ -108,7 +107,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     int a_iy0[A_IT], a_ix0[A_IT], a_nb[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int m = bm0 + (wave + it * NW) * 16 + lrow;
+        const int m = bm0 + (lwave + it * NL) * 16 + lrow;
         if (m < p.M) {
             const int n_img = m / p.HoWo, rem = m - n_img * p.HoWo;
             const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
@@ -160,7 +159,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     const int w_adv = wil ? 2 * BK : BK;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        const int piece = wave + it * NW, plane = piece / GB, grp = piece % GB;
+        const int piece = lwave + it * NL, plane = piece / GB, grp = piece % GB;
         const int brow = bn0 + grp * 16 + lrow;          // rows past Npad (tiles wider than the 128-row padding): zeros
         wrow[it] = brow < d.Npad ? reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + brow) * (wil ? 2 * d.Kpad : d.Kpad) + kc * 8 + plane * w_ps
                                  : nullptr;
@@ -193,10 +192,10 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
             const int it = j >> 1, plane = j & 1;
             const bool ok = (k_cur < p.K) && ((a_okmask >> it) & 1u);
             const __bf16* src = a_base[it] + ((ci << il_sh) - il_sub) + (plane ? a_ps : 0);
-            glds16(sel(src, ok), st + (wave + it * NW) * 1024 + plane * BM * 64);
+            glds16(sel(src, ok), st + (lwave + it * NL) * 1024 + plane * BM * 64);
         } else {
             const int it = j - 2 * A_IT;
-            const int piece = wave + it * NW, plane = piece / GB, grp = piece % GB;    // wave-uniform
+            const int piece = lwave + it * NL, plane = piece / GB, grp = piece % GB;    // wave-uniform
             const bool bok = BN <= 128 || wrow[it] != nullptr;
             glds16(sel(wrow[it], bok), st + 2 * BM * 64 + plane * BN * 64 + grp * 1024);
             if (bok) wrow[it] += w_adv;
@@ -209,13 +208,13 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
         for (int it = 0; it < A_IT; ++it) {
             const bool ok = kval && ((a_okmask >> it) & 1u);
             const __bf16* src = a_base[it] + ((ci << il_sh) - il_sub);
-            char* dst = st + (wave + it * NW) * 1024;
+            char* dst = st + (lwave + it * NL) * 1024;
             glds16(sel(src, ok), dst);                           // A_hi rows
             glds16(sel(src + a_ps, ok), dst + BM * 64);          // A_lo rows
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            const int piece = wave + it * NW, plane = piece / GB, grp = piece % GB;    // wave-uniform
+            const int piece = lwave + it * NL, plane = piece / GB, grp = piece % GB;    // wave-uniform
             char* dst = st + 2 * BM * 64 + plane * BN * 64 + grp * 1024;
             const bool bok = BN <= 128 || wrow[it] != nullptr;
             glds16(sel(wrow[it], bok), dst);
@@ -245,7 +244,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     constexpr int AHEAD = EA ? 2 : NS - 1;
 #pragma unroll
     for (int t = 0; t < AHEAD; ++t)
-        if (t < p.nk) issue_tile(t);
+        if (t < p.nk && loads) issue_tile(t);
     if (p.nk >= AHEAD) wait_vmcnt<DPT * (AHEAD - 1)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     int slot = 0, slot_in = AHEAD % NS;
@@ -533,7 +532,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
             // (DMAs BEFORE the MFMAs on purpose: the vector-memory pipe is the critical resource and has to be fed as early as the stage
             //  is free.  The opposite order — MFMAs first, DMA issue underneath them — measured 6 % slower on the 3x3 layers:
             //  profiles/r02_run9_split_sweep_mfma_first.txt)
-            if (more) issue_tile(slot);
+            if (more && loads) issue_tile(slot);
             __builtin_amdgcn_sched_barrier(0);
             TR_STAMP(3);
             mfmas(ah, al, bh, bl);
@@ -639,7 +638,319 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2, bool PP = false, bool IL = false, int P8 = 0, int EA = 0>
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Loader-wavefront variant ("lw" tiles).  The timeline of the early-release loop above (tools/conv_trace.py) shows every wavefront parked
+// ~900 cycles per K step in front of the shared vector-memory pipe while it issues its own 4 LDS-DMAs — in FRONT of its MFMAs; issuing the
+// MFMAs first instead starves the pipe (measured, 6 % slower).  Here the two jobs belong to different wavefronts: NW consumer wavefronts
+// (fragment reads + MFMAs + epilogue, no address arithmetic at all) and two loader wavefronts per workgroup — one owns the whole A (im2col)
+// tile, one the B (weight) tile — that do nothing but address arithmetic and LDS-DMA issue.  Same two stages, two barriers per step and
+// two tiles in flight as `EA`:
+//     consumers:  read tile kt (stage kt&1) | lgkmcnt(0) | barrier A | MFMAs                                   | barrier B
+//     loaders:                                             barrier A | issue tile kt+2 -> stage kt&1, vmcnt: tile kt+1 landed | barrier B
+// so between A and B the matrix pipe and the vector-memory pipe both start at once.  Same products in the same order: bit-identical.
+// Measured (profiles/r02_run9_split_sweep_loader_waves.txt, _conv_trace_loader_waves.txt): SLOWER — 262 vs 337 TF algorithmic on the
+// 640->512 3x3 layer.  One wavefront issues a 1-KB LDS-DMA every 70 (weights, 8 cache lines) to 133 cycles (im2col rows, 16 lines): the A
+// loader needs 2 100 cycles for its 16 instructions, the B loader 1 100, and the consumers wait at barrier B.  Saturating the pipe takes
+// the issue parallelism of >= 8 wavefronts, which the register file does not offer on top of 8 consumers (20 wavefronts per CU: 96
+// registers).  `XY` (half of the wavefronts issue everything, the other half starts its MFMAs at once) ties with `EA` (338 vs 342): the
+// 32 instructions of a tile take 800-1 900 cycles whoever issues them — the pipe, not the issue order, is the limit.  Explicit tiles only.
+template <int BM, int BN, int WM, int WN, int MINW>
+__global__ void __launch_bounds__((WM * WN + 2) * 64, MINW) conv_split_lw_kernel(const ConvP p) {
+    constexpr int NW = WM * WN;                         // consumer wavefronts; wavefront NW loads A, NW + 1 loads B
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    constexpr int STAGE = (BM + BN) * LDB;              // floats per stage
+    constexpr int STAGE_B = STAGE * 4;
+    constexpr int GA = BM / 16, GB = BN / 16;           // 16-row DMA groups per plane
+    constexpr int PA = 2 * GA, PB = 2 * GB;             // DMA instructions per tile of the A / the B loader
+    static_assert(TM >= 1 && TN >= 1 && PA <= 32 && PB <= 32, "tile / wavefront geometry");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const fgt_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int m_idx, n_idx;
+    if (!conv_tile_index(p, m_idx, n_idx)) return;
+    const int bm0 = m_idx * BM, bn0 = n_idx * BN, g = blockIdx.y;
+    const int nk = p.nk;
+#ifdef FGT_CONV_TRACE
+    unsigned long long ts[TR_NST] = {};
+    unsigned* const trace_lds = reinterpret_cast<unsigned*>(smem + 2 * STAGE);
+    const unsigned long long tr_t0 = __builtin_readcyclecounter();
+    const unsigned long long tr_r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = tid; i < (NW + 2) * TR_STEPS * TR_NST; i += (NW + 2) * 64) trace_lds[i] = 0;
+    __syncthreads();
+#endif
+
+    if (wave >= NW) {
+        // ================================================================ loaders
+        char* const lds = reinterpret_cast<char*>(smem);
+        const __bf16* const zp = reinterpret_cast<const __bf16*>(p.zero_page);
+        const unsigned long zpi = reinterpret_cast<unsigned long>(zp);
+        auto sel = [&](const __bf16* ptr, bool ok) {      // arithmetic select (one DMA instruction whatever the predicate)
+            const unsigned long a = reinterpret_cast<unsigned long>(ptr);
+            return reinterpret_cast<const void*>(zpi + ((a - zpi) & (ok ? ~0ul : 0ul)));
+        };
+        const int lrow = lane >> 2;
+        const int kc = (lane & 3) ^ ((lane >> 4) & 3);  // swizzle on the source side
+        if (wave == NW) {
+            // ---- A loader: row (lane >> 2) of each of the GA 16-row groups, both planes
+            const __bf16* const x0 = reinterpret_cast<const __bf16*>(p.x0);
+            const __bf16* const x1 = reinterpret_cast<const __bf16*>(p.x1);
+            const bool il = d.in_split == 2;
+            const int ld0 = d.ld0, ld1 = d.ld1;
+            const int chb0 = (d.off0 + g * p.Cg0) << (il ? 1 : 0), chb1 = (d.off1 + g * p.Cg1 - p.Cg0) << (il ? 1 : 0);
+            const long ps0 = il ? 32 : p.ps0, ps1 = il ? 32 : p.ps1;
+            const int Cg0 = p.Cg0, Cg = p.Cg;
+            const int il_sh = il ? 1 : 0, il_sub = il ? kc * 8 : 0;
+            int a_iy0[GA], a_ix0[GA], a_nb[GA];
+#pragma unroll
+            for (int it = 0; it < GA; ++it) {
+                const int m = bm0 + it * 16 + lrow;
+                if (m < p.M) {
+                    const int n_img = m / p.HoWo, rem = m - n_img * p.HoWo;
+                    const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
+                    a_iy0[it] = oy * d.sh - d.ph;
+                    a_ix0[it] = ox * d.sw - d.pw;
+                    a_nb[it] = n_img * d.H * d.W;
+                } else {
+                    a_iy0[it] = 0; a_ix0[it] = 0; a_nb[it] = -1;
+                }
+            }
+            int k_cur = kc * 8;
+            int tap = k_cur / p.Cg;
+            int ci = k_cur - tap * p.Cg;
+            int ky = tap / d.kw, kx = tap - ky * d.kw;
+            const __bf16* a_base[GA];
+            unsigned a_okmask = 0;
+            int seg_end = 0;
+            long a_ps = 0;
+            auto retap = [&]() {
+                const bool in0 = ci < Cg0;
+                const __bf16* src = in0 ? x0 : x1;
+                const int ld = in0 ? ld0 : ld1;
+                const int chb = in0 ? chb0 : chb1;
+                a_ps = in0 ? ps0 : ps1;
+                seg_end = in0 ? Cg0 : Cg;
+                const int dy = ky * d.dh, dx = kx * d.dw;
+                const int ush = d.upsample ? 1 : 0;
+                const bool rep = d.pad_mode != 0;
+                a_okmask = 0;
+#pragma unroll
+                for (int it = 0; it < GA; ++it) {
+                    int iy = a_iy0[it] + dy, ix = a_ix0[it] + dx;
+                    const int cy = min(max(iy, 0), p.Hin - 1), cx = min(max(ix, 0), p.Win - 1);
+                    iy = rep ? cy : iy;
+                    ix = rep ? cx : ix;
+                    const bool ok = a_nb[it] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                    a_okmask |= (ok ? 1u : 0u) << it;
+                    a_base[it] = src + ((long)(a_nb[it] + (iy >> ush) * d.W + (ix >> ush)) * ld + chb);
+                }
+            };
+            retap();
+            auto issue_a = [&](int slot) {
+                char* st = lds + slot * STAGE_B;
+                const bool kval = k_cur < p.K;
+#pragma unroll
+                for (int it = 0; it < GA; ++it) {
+                    const bool ok = kval && ((a_okmask >> it) & 1u);
+                    const __bf16* src = a_base[it] + ((ci << il_sh) - il_sub);
+                    char* dst = st + it * 1024;
+                    glds16(sel(src, ok), dst);                           // A_hi rows
+                    glds16(sel(src + a_ps, ok), dst + BM * 64);          // A_lo rows
+                }
+                k_cur += BK;
+                ci += BK;
+                if (ci >= seg_end) {
+                    while (ci >= Cg) {
+                        ci -= Cg;
+                        if (++kx == d.kw) { kx = 0; ++ky; }
+                    }
+                    retap();
+                }
+            };
+            issue_a(0);
+            if (nk > 1) { issue_a(1); wait_vmcnt<PA>(); } else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                                // P: tile 0 landed
+            for (int kt = 0; kt < nk; ++kt) {
+                __builtin_amdgcn_s_barrier();                            // A: every consumer holds tile kt in registers
+                TR_STAMP(2);
+                const bool more = kt + 2 < nk;
+                if (more) issue_a(kt & 1);
+                TR_STAMP(3);
+                if (more) wait_vmcnt<PA>(); else wait_vmcnt<0>();        // tile kt+1 landed (tile kt+2 may fly)
+                TR_STAMP(5);
+                __builtin_amdgcn_s_barrier();                            // B
+                TR_STAMP(6);
+                TR_STORE(kt);
+            }
+        } else {
+            // ---- B loader: row (lane >> 2) of each of the GB 16-row groups of both weight planes
+            const bool wil = d.w_il != 0;
+            const long w_ps = wil ? 32 : (long)d.groups * d.Npad * d.Kpad;
+            const int w_adv = wil ? 2 * BK : BK;
+            const __bf16* wrow[PB];
+#pragma unroll
+            for (int it = 0; it < PB; ++it) {
+                const int plane = it / GB, grp = it % GB;
+                const int brow = bn0 + grp * 16 + lrow;          // rows past Npad (tiles wider than the 128-row padding): zeros
+                wrow[it] = brow < d.Npad ? reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + brow) * (wil ? 2 * d.Kpad : d.Kpad) + kc * 8 + plane * w_ps
+                                         : nullptr;
+            }
+            auto issue_b = [&](int slot) {
+                char* st = lds + slot * STAGE_B + 2 * BM * 64;
+#pragma unroll
+                for (int it = 0; it < PB; ++it) {
+                    const int plane = it / GB, grp = it % GB;
+                    const bool bok = BN <= 128 || wrow[it] != nullptr;
+                    glds16(sel(wrow[it], bok), st + plane * BN * 64 + grp * 1024);
+                    if (bok) wrow[it] += w_adv;
+                }
+            };
+            issue_b(0);
+            if (nk > 1) { issue_b(1); wait_vmcnt<PB>(); } else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                                // P
+            for (int kt = 0; kt < nk; ++kt) {
+                __builtin_amdgcn_s_barrier();                            // A
+                TR_STAMP(2);
+                const bool more = kt + 2 < nk;
+                if (more) issue_b(kt & 1);
+                TR_STAMP(3);
+                if (more) wait_vmcnt<PB>(); else wait_vmcnt<0>();
+                TR_STAMP(5);
+                __builtin_amdgcn_s_barrier();                            // B
+                TR_STAMP(6);
+                TR_STORE(kt);
+            }
+        }
+        return;
+    }
+
+    // ==================================================================== consumers
+    const int wm = wave / WN, wn = wave % WN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int l31 = lane & 31, lh = lane >> 5;
+#ifdef FGT_CONV_TRACE
+    const unsigned long long tr_t1 = __builtin_readcyclecounter();
+#endif
+    __builtin_amdgcn_s_barrier();                                        // P: tile 0 landed
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+        TR_STAMP(0);
+        {
+            const __bf16* base = reinterpret_cast<const __bf16*>(smem + slot * STAGE);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int so = swz(l31, ks * 2 + lh);
+                const __bf16* Ahi = base + (wm * WTM + l31) * LDB + so;
+                const __bf16* Bhi = base + 2 * BM * LDB + (wn * WTN + l31) * LDB + so;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[ks][i] = *reinterpret_cast<const bf16x8*>(Ahi + i * 32 * LDB);
+                    al[ks][i] = *reinterpret_cast<const bf16x8*>(Ahi + BM * LDB + i * 32 * LDB);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[ks][j] = *reinterpret_cast<const bf16x8*>(Bhi + j * 32 * LDB);
+                    bl[ks][j] = *reinterpret_cast<const bf16x8*>(Bhi + BN * LDB + j * 32 * LDB);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TR_STAMP(1);
+        __builtin_amdgcn_s_barrier();                                    // A: the stage may be refilled
+        TR_STAMP(2);
+        TR_STAMP(3);
+        // same product order as conv_igemm.hip (lo*hi, hi*lo, hi*hi per k-half): bit-identical accumulators
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        TR_STAMP(4);
+        TR_STAMP(5);
+        __builtin_amdgcn_s_barrier();                                    // B: tile kt+1 is in its stage
+        TR_STAMP(6);
+        TR_STORE(kt);
+        slot ^= 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef FGT_CONV_TRACE
+    unsigned* tr_hdr = nullptr;
+    {
+        const unsigned long long tr_t2 = __builtin_readcyclecounter();
+        __syncthreads();                                                 // (the loaders have left: only the consumers count)
+        constexpr int PER_WG = (NW + 2) * (TR_HDR + TR_STEPS * TR_NST);
+        const long wg = (long)blockIdx.y * gridDim.x + blockIdx.x;
+        unsigned* out = g_conv_trace;
+        if (out && (wg + 1) * PER_WG <= g_conv_trace_words) {
+            out += wg * PER_WG;
+            if (lane == 0) {
+                unsigned* h = out + wave * TR_HDR;
+                h[0] = __builtin_amdgcn_s_getreg(63492);
+                h[1] = __builtin_amdgcn_s_getreg(63508);
+                h[2] = (unsigned)tr_t0;
+                h[3] = (unsigned)p.nk;
+                h[4] = (unsigned)tr_t1;
+                h[5] = (unsigned)tr_t2;
+                tr_hdr = h;
+            }
+            for (int i = tid; i < (NW + 2) * TR_STEPS * TR_NST; i += NW * 64) out[(NW + 2) * TR_HDR + i] = trace_lds[i];
+        }
+        __syncthreads();
+    }
+#endif
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
+#ifdef FGT_CONV_TRACE
+    if (tr_hdr) {
+        tr_hdr[8] = (unsigned)__builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tr_hdr[6] = (unsigned)__builtin_readcyclecounter();
+        tr_hdr[7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - tr_r0);
+    }
+#endif
+}
+
+template <int BM, int BN, int WM, int WN, int MINW>
+int launch_lw(const ConvP& p, hipStream_t s) {
+    constexpr int NT = (WM * WN + 2) * 64;
+#ifdef FGT_CONV_TRACE
+    constexpr size_t smem = (size_t)2 * (BM + BN) * LDB * sizeof(float) + (size_t)(WM * WN + 2) * TR_STEPS * TR_NST * 4;
+#else
+    constexpr size_t smem = (size_t)2 * (BM + BN) * LDB * sizeof(float);
+#endif
+    static_assert(smem <= 160 * 1024, "LDS stages do not fit");
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_split_lw_kernel<BM, BN, WM, WN, MINW>), (int)smem, lds_set, "conv_split_lw")) return rc;
+    ConvP q = p;
+    q.mtiles = cdiv(p.M, BM);
+    q.ntiles = cdiv(p.Cout_g, BN);
+    q.mchunk = cdiv(q.mtiles, 8);
+    dim3 grid(q.xcd_swizzle ? 8 * q.mchunk * q.ntiles : q.mtiles * q.ntiles, p.d.groups);
+    hipLaunchKernelGGL((conv_split_lw_kernel<BM, BN, WM, WN, MINW>), grid, dim3(NT), smem, s, q);
+    return fgt_check_launch("conv_split_lw");
+}
+
+template <int BM, int BN, int WM, int WN, int MINW = 2, int NS = 2, bool PP = false, bool IL = false, int P8 = 0, int EA = 0, bool XY = false>
 int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
 #ifdef FGT_CONV_TRACE
@@ -649,13 +960,13 @@ int launch(const ConvP& p, hipStream_t s) {
 #endif
     static_assert(smem <= 160 * 1024, "LDS ring does not fit");
     static std::atomic<unsigned long long> lds_set{0};
-    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL, P8, EA>), (int)smem, lds_set, "conv_split")) return rc;
+    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL, P8, EA, XY>), (int)smem, lds_set, "conv_split")) return rc;
     ConvP q = p;
     q.mtiles = cdiv(p.M, BM);
     q.ntiles = cdiv(p.Cout_g, BN);
     q.mchunk = cdiv(q.mtiles, 8);
     dim3 grid(q.xcd_swizzle ? 8 * q.mchunk * q.ntiles : q.mtiles * q.ntiles, p.d.groups);
-    hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL, P8, EA>), grid, dim3(NT), smem, s, q);
+    hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, MINW, NS, PP, IL, P8, EA, XY>), grid, dim3(NT), smem, s, q);
     return fgt_check_launch("conv_split");
 }
 
@@ -693,6 +1004,12 @@ int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_128x128x8_EA: return launch<128, 128, 2, 4, 4, 2, false, false, 0, 1>(p, s);
         case FGT_TILE_256x128x16_EA: return launch<256, 128, 4, 4, 4, 2, false, false, 0, 1>(p, s);
         case FGT_TILE_256x64x8_EA: return launch<256, 64, 4, 2, 2, 2, false, false, 0, 1>(p, s);
+        // early release with the DMA issue on half of the wavefronts (one per SIMD)
+        case FGT_TILE_128x128x8_XY: return launch<128, 128, 2, 4, 4, 2, false, false, 0, 1, true>(p, s);
+        // loader wavefronts: 8 (or 4) consumer wavefronts + an A loader + a B loader per workgroup, two workgroups per CU
+        case FGT_TILE_128x128x8_LW: return launch_lw<128, 128, 2, 4, 5>(p, s);      // 20 wavefronts per CU: <= 96 registers
+        case FGT_TILE_128x128_LW: return launch_lw<128, 128, 2, 2, 3>(p, s);        // 12 wavefronts per CU
+        case FGT_TILE_128x64_LW: return launch_lw<128, 64, 2, 2, 3>(p, s);
         case FGT_TILE_256x256_P8: return launch<256, 256, 2, 4, 2, 2, false, false, 3>(p, s);     // 8-phase staggered schedule, setprio around the MFMAs
         case FGT_TILE_256x128_P8: return launch<256, 128, 4, 2, 2, 2, false, false, 3>(p, s);
 #ifdef FGT_P8_ABLATIONS   // A/B and timing-only instances behind profiles/r02_run3_split_sweep_p8*.txt (build with -DFGT_P8_ABLATIONS to reproduce)

@@ -138,6 +138,11 @@ typedef struct fgt_conv_desc {
 #define FGT_TILE_128x128x8_EA 29
 #define FGT_TILE_256x128x16_EA 30
 #define FGT_TILE_256x64x8_EA 31
+#define FGT_TILE_128x128x8_XY 35  /* split inputs only: tile 29 where only the upper half of the wavefronts (one per SIMD) issues the LDS-DMAs — all of
+                                   * them — and the lower half goes from the stage-release barrier straight into its MFMAs.  Bit-identical, not faster. */
+#define FGT_TILE_128x128x8_LW 32  /* split inputs only: early-release tiles with two LOADER wavefronts per workgroup (one owns the A tile, one the  */
+#define FGT_TILE_128x128_LW 33    /* B tile: address arithmetic + LDS-DMA issue only) next to the 8 / 4 consumer wavefronts (fragment reads + MFMAs): */
+#define FGT_TILE_128x64_LW 34     /* the DMA issue no longer sits in front of the MFMAs of the same wavefront.  Bit-identical results; measured slower. */
 #define FGT_TILE_256x256_P8N 19   /* 17 without s_setprio (A/B measurements) */
 #define FGT_TILE_256x256_P8L 20   /* 17 with both wavefront groups in lock step (A/B measurements) */
 

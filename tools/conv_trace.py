@@ -24,7 +24,7 @@ LAYERS = {  # name: (N, H, W, C0, C1, Cout, groups, k, stride, pad)
     "b8qkv": (1, 1, 97920, 512, 0, 1536, 1, 1, 1, 0),
     "b8ffn1": (1, 1, 97920, 512, 0, 1960, 1, 1, 1, 0),
 }
-WAVES = {"128x128": 4, "128x128ea": 4, "128x128x8": 8, "128x128x8ea": 8, "256x128x16": 16, "256x128x16ea": 16, "256x64x8": 8, "256x64x8ea": 8, "128x64": 4, "128x64ea": 4}
+WAVES = {"128x128x8xy": 8, "128x128x8lw": 10, "128x128lw": 6, "128x64lw": 6, "128x128": 4, "128x128ea": 4, "128x128x8": 8, "128x128x8ea": 8, "256x128x16": 16, "256x128x16ea": 16, "256x64x8": 8, "256x64x8ea": 8, "128x64": 4, "128x64ea": 4}
 
 
 def main():
