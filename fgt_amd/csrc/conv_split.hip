@@ -531,7 +531,9 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
             const bool more = kt + 2 < p.nk;
             // (DMAs BEFORE the MFMAs on purpose: the vector-memory pipe is the critical resource and has to be fed as early as the stage
             //  is free.  The opposite order — MFMAs first, DMA issue underneath them — measured 6 % slower on the 3x3 layers:
-            //  profiles/r02_run9_split_sweep_mfma_first.txt)
+            //  profiles/r02_run9_split_sweep_mfma_first.txt; moving the DMA issue of HALF of the wavefronts to the top of the next step, so that
+            //  only half of it stands in front of MFMAs: 326 vs 339 TF, profiles/r02_run9_split_sweep_late_half.txt — the 32 instructions of a
+            //  tile take the same time wherever they are issued)
             if (more && loads) issue_tile(slot);
             __builtin_amdgcn_sched_barrier(0);
             TR_STAMP(3);

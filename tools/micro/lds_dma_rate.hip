@@ -67,18 +67,29 @@ __global__ void __launch_bounds__(1024) rate_kernel(const char* src, long row_st
 // (16 instructions per workgroup) plus a 16-KB weight slab that every workgroup shares.  ORDER 0: tap-major (ky, kx, chunk) — the
 // library's K order: the kx re-read of a row comes CHUNKS steps later; ORDER 1: (ky, chunk, kx) — it comes in the very next step.
 template <int ORDER>
-__global__ void __launch_bounds__(512) conv_like_kernel(const char* act, const char* wts, int chunks, int width, unsigned long long* cycles) {
+__global__ void __launch_bounds__(512) conv_like_kernel(const char* act, const char* wts, int chunks, int width, int mtiles, int lds_reads, float* sink,
+                                                        unsigned long long* cycles) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;     // 8 wavefronts: A pieces (plane, 16-row group) = wave + 8*i, i < 2; B 2 pieces
     const int w = blockIdx.x;
-    const long m_tile = (long)(w >> 5) * 8 + (w & 7);
+    // mtiles == 0: 128 M tiles, one round of workgroups (44-MB footprint).  mtiles > 0: the library's XCD-aware order over `mtiles` M tiles
+    // x 4 N tiles (csrc/conv_tile.h) — the whole layer's input is streamed, round after round of workgroups, like the real launch
+    long m_tile = (long)(w >> 5) * 8 + (w & 7);
+    long rows_total = (long)gridDim.x / 4 * 128;
+    if (mtiles > 0) {
+        const int mchunk = (mtiles + 7) / 8, xcd = w & 7, i = w >> 3;
+        m_tile = (long)xcd * mchunk + i / 4;
+        if (m_tile >= mtiles) return;
+        rows_total = (long)mtiles * 128;
+    }
     const long row_bytes = (long)chunks * 64;                       // one plane of a pixel: chunks * 32 channels * 2 B
-    const long plane_bytes = row_bytes * ((long)gridDim.x / 4 * 128 + 4 * width + 256);
+    const long plane_bytes = row_bytes * (rows_total + 4 * width + 256);
     const int r = lane >> 2, c = lane & 3;
     char* dst = lds + wave * 4 * 1024;
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter();
     int step = 0;
+    float facc = 0.f;
     for (int ky = 0; ky < 3; ++ky)
         for (int a = 0; a < (ORDER ? chunks : 3); ++a)
             for (int b = 0; b < (ORDER ? 3 : chunks); ++b, ++step) {
@@ -92,31 +103,40 @@ __global__ void __launch_bounds__(512) conv_like_kernel(const char* act, const c
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                     __builtin_amdgcn_global_load_lds((glb_ptr_t)(wts + ((long)step * 16 + wave * 2 + i) * 1024 + lane * 16), (lds_ptr_t)(dst + (2 + i) * 1024), 16, 0, 0);
+                // the conv's fragment traffic: lds_reads conflict-free ds_read_b128 per wavefront and step (12 in the 128x128 8-wavefront tile)
+                for (int q = 0; q < lds_reads; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(lds + ((wave * 12 + q) * 1024 + lane * 16) % (64 * 1024));
+                    facc += v[0];
+                }
                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) cycles[blockIdx.x] = __builtin_readcyclecounter() - t0;
+    if (sink) sink[blockIdx.x * 512 + threadIdx.x] = facc;
 }
 
 template <int ORDER>
-void run_conv_like(const char* src, int chunks, int width) {
-    const int grid = 512;
+void run_conv_like(const char* src, int chunks, int width, int mtiles = 0, int lds_reads = 0) {
+    const int grid = mtiles ? 8 * ((mtiles + 7) / 8) * 4 : 512;
     unsigned long long* cyc;
     hipMalloc(&cyc, grid * sizeof(unsigned long long));
+    hipMemset(cyc, 0, grid * sizeof(unsigned long long));
     const size_t smem = 79 * 1024;                                   // two workgroups per CU
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_like_kernel<ORDER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const char* wts = src + (768u << 20);                            // weight slabs in the last quarter of the buffer
-    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((conv_like_kernel<ORDER>), dim3(grid), dim3(512), smem, 0, src, wts, chunks, width, cyc);
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((conv_like_kernel<ORDER>), dim3(grid), dim3(512), smem, 0, src, wts, chunks, width, mtiles, lds_reads, (float*)nullptr, cyc);
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(grid);
     hipMemcpy(h.data(), cyc, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     double mean = 0;
-    for (auto v : h) mean += (double)v;
-    mean /= grid;
+    int n = 0;
+    for (auto v : h) if (v) { mean += (double)v; ++n; }
+    mean /= n;
     const int steps = 9 * chunks;
-    printf("conv-like A+B stream, %2d chunks of 32 channels, order %s: %7.0f cycles per step (2 workgroups per CU, 32 KB per step each) = %5.1f B/clk/CU\n",
-           chunks, ORDER ? "(ky, chunk, kx)" : "(ky, kx, chunk)", mean / steps, 2.0 * 32768 * steps / mean);
+    printf("conv-like A+B stream + %2d ds_read_b128 per wavefront and step, %2d chunks of 32 channels, order %s, %s: %7.0f cycles per step (2 workgroups per CU, 32 KB per step each) = %5.1f B/clk/CU\n",
+           lds_reads, chunks, ORDER ? "(ky, chunk, kx)" : "(ky, kx, chunk)", mtiles ? "whole layer (20 frames of 60x108, 4 N tiles)" : "one round of workgroups", mean / steps,
+           2.0 * 32768 * steps / mean);
     hipFree(cyc);
 }
 
@@ -184,6 +204,10 @@ int main() {
         run_conv_like<0>(src, chunks, 108);
         run_conv_like<1>(src, chunks, 108);
     }
+    run_conv_like<0>(src, 10, 108, 1013);      // the e20 enc10 launch per group: 129 600 output pixels, 320 channels per group
+    run_conv_like<0>(src, 20, 108, 1013);
+    for (int r : {6, 12, 24}) run_conv_like<0>(src, 10, 108, 0, r);      // + the fragment reads of the conv (12 per wavefront and step)
+    run_conv_like<0>(src, 10, 108, 1013, 12);
     hipFree(src);
     return 0;
 }
