@@ -211,13 +211,36 @@ __global__ void __launch_bounds__(256) fold_kernel(const float* Y, int ldy, int 
         const int j_lo = max(0, (x + p - k + 1 + s - 1) / s), j_hi = min(tw - 1, (x + p) / s);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         int cnt = 0;
-        for (int i = i_lo; i <= i_hi; ++i) {
-            const int ky = y + p - i * s;
-            for (int j = j_lo; j <= j_hi; ++j) {
-                const int kx = x + p - j * s;
-                const float4 v = *reinterpret_cast<const float4*>(Y + ((long)f * th * tw + i * tw + j) * ldy + (ky * k + kx) * C + c);
-                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
-                ++cnt;
+        if (i_hi >= i_lo && j_hi >= j_lo && i_hi - i_lo < 3 && j_hi - j_lo < 3) {
+            // k <= 3s (the shipped 7 / 3): at most 3 x 3 covering tokens.  Straight-line: the nine loads (clamped to a covering token, so
+            // always in range) are issued back to back, tokens past the range add 0 (acc + 0 == acc) — same sums in the same order as the loop
+            float4 v[9];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const int i = min(i_lo + a, i_hi), j = min(j_lo + b, j_hi);
+                    const int ky = y + p - i * s, kx = x + p - j * s;
+                    v[a * 3 + b] = *reinterpret_cast<const float4*>(Y + ((long)f * th * tw + i * tw + j) * ldy + (ky * k + kx) * C + c);
+                }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const bool in = i_lo + a <= i_hi && j_lo + b <= j_hi;
+                    acc[0] += in ? v[a * 3 + b].x : 0.f; acc[1] += in ? v[a * 3 + b].y : 0.f;
+                    acc[2] += in ? v[a * 3 + b].z : 0.f; acc[3] += in ? v[a * 3 + b].w : 0.f;
+                }
+            cnt = (i_hi - i_lo + 1) * (j_hi - j_lo + 1);
+        } else {
+            for (int i = i_lo; i <= i_hi; ++i) {
+                const int ky = y + p - i * s;
+                for (int j = j_lo; j <= j_hi; ++j) {
+                    const int kx = x + p - j * s;
+                    const float4 v = *reinterpret_cast<const float4*>(Y + ((long)f * th * tw + i * tw + j) * ldy + (ky * k + kx) * C + c);
+                    acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+                    ++cnt;
+                }
             }
         }
         if (normalize) {
