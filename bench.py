@@ -38,8 +38,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 de
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured with a float4 copy)
 KERNELS = {"conv": "conv_split_kernel / conv_igemm_kernel (implicit-GEMM conv + every Linear; all fgt_conv2d MFMA launches)",
-           "attn_temporal": "attn_bf16x3_kernel<8,true> / attn_kernel<4> (temporal zone attention, fgt_attention mode 0)",
-           "attn_spatial": "attn_bf16x3_kernel<2,false> / attn_kernel<2> (spatial window + global-token attention, fgt_attention mode 1)"}
+           "attn_temporal": "attn_split_kernel<8|4> (bf16x3, split q/k/v) / attn_kernel<4> (fp32): temporal zone attention, fgt_attention mode 0",
+           "attn_spatial": "attn_split_kernel<2> (bf16x3, split q/k/v) / attn_kernel<2> (fp32): spatial window + global-token attention, fgt_attention mode 1"}
 
 
 def fgt_flops(t):
