@@ -37,9 +37,14 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured with a float4 copy)
-KERNELS = {"conv": "conv_split_kernel / conv_igemm_kernel (implicit-GEMM conv + every Linear; all fgt_conv2d MFMA launches)",
-           "attn_temporal": "attn_split_kernel<8|4> (bf16x3, split q/k/v) / attn_kernel<4> (fp32): temporal zone attention, fgt_attention mode 0",
-           "attn_spatial": "attn_split_kernel<2> (bf16x3, split q/k/v) / attn_kernel<2> (fp32): spatial window + global-token attention, fgt_attention mode 1"}
+KERNELS = {"conv": "conv_split_kernel (bf16x3) / conv_f16_kernel (f16) / conv_igemm_kernel (fp32 inputs): implicit-GEMM conv + every Linear; all fgt_conv2d MFMA launches",
+           "attn_temporal": "attn_split_kernel<8|4, H> (bf16x3: split q/k/v; f16: H = true) / attn_kernel<4> (fp32): temporal zone attention, fgt_attention mode 0",
+           "attn_spatial": "attn_split_kernel<2, H> (bf16x3 / f16) / attn_kernel<2> (fp32): spatial window + global-token attention, fgt_attention mode 1"}
+
+
+DTYPES = {"fp32": "f32", "bf16x3": "f32 (conv/GEMM/attention products as 3 bf16 MFMAs on hi/lo splits, fp32 accumulate)",
+          "f16": "f16 operands (activations rounded once by their producer, 11 significant bits), one fp16 MFMA per product, fp32 accumulate; "
+                 "norms / softmax / residual stream / blends in fp32"}
 
 
 def fgt_flops(t):
@@ -87,15 +92,17 @@ def cpu_baseline(cfg, sd, frames, flows, masks, sched, model=None, runs=3):
     dt = statistics.median(times)
     total = sum(fgt_flops(len(a) + len(b)) for a, b in sched)
     est_clip_s = dt * total / fgt_flops(len(ids))
-    parity = None
-    if model is not None:      # "PSNR vs ref" of the metric: the same window through the HIP path vs the oracle's output
+    def parity_of(model, what="headline precision"):
+        """"PSNR vs ref" of the metric: the same window through the HIP path (in the arithmetic mode selected right now) vs the oracle's output"""
         dev = frames.device
         got = model(mf.to(dev), fl.to(dev), m.to(dev)).cpu()
         u8 = lambda x: ((x + 1) / 2 * 255).clamp(0, 255).to(torch.uint8).float()
-        parity = {"window": 0, "frames": len(ids), "max_abs_diff": float((got - ref).abs().max()),
-                  "ref_max_abs": float(ref.abs().max()), "psnr_db_uint8": round(O.psnr(u8(got), u8(ref)), 2),
-                  "note": "HIP path (headline precision) vs CPU oracle on window 0; PSNR per FGT/metrics/psnr.py:5-9 on clip((x+1)/2*255) uint8 frames (100 = identical)"}
-    return parity, {"value": round(frames.shape[1] / est_clip_s, 4), "unit": "frames/s", "cores": best, "host_cores": ncpu,
+        return {"window": 0, "frames": len(ids), "max_abs_diff": float((got - ref).abs().max()),
+                "ref_max_abs": float(ref.abs().max()), "psnr_db_uint8": round(O.psnr(u8(got), u8(ref)), 2),
+                "note": f"HIP path ({what}) vs CPU oracle on window 0; PSNR per FGT/metrics/psnr.py:5-9 on clip((x+1)/2*255) uint8 frames (100 = identical)"}
+
+    parity = parity_of(model) if model is not None else None
+    return parity, parity_of, {"value": round(frames.shape[1] / est_clip_s, 4), "unit": "frames/s", "cores": best, "host_cores": ncpu,
                     "kind": "port", "runs_s": [round(x, 3) for x in times],
                     "sample": f"oracle fgt_forward on window 0 (t={len(ids)}) at {frames.shape[-1]}x{frames.shape[-2]}: median of {runs} runs = {dt:.2f} s "
                               f"with {best} threads (fastest of a 2-frame probe); clip time extrapolated by F(t)=147.03t+1.0618t^2 GFLOP over the "
@@ -112,10 +119,12 @@ def main():
     ap.add_argument("--width", type=int, default=432)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event timing of the MFMA kernels")
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
-                    help="arithmetic of the headline: exact fp32 MFMA, or fp32 operands split into hi/lo bf16 with 3 bf16 MFMAs per "
-                         "product and fp32 accumulation (FGT max |diff| vs reference 1.6e-6, bar 1e-3)")
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "f16"],
+                    help="arithmetic of the headline: exact fp32 MFMA; fp32 operands split into hi/lo bf16 with 3 bf16 MFMAs per "
+                         "product and fp32 accumulation (FGT max |diff| vs reference 1.6e-6, bar 1e-3); or f16: GEMM / attention operands "
+                         "rounded once to fp16 by their producer, one fp16 MFMA per product, fp32 accumulation (~1e-4, bar 1e-3)")
     ap.add_argument("--no-fp32-exact", action="store_true", help="N = 1: do not also time the exact-fp32 mode (the `fp32_exact` object)")
+    ap.add_argument("--no-f16", action="store_true", help="N = 1: do not also time the f16 mode (the `f16` object)")
     ap.add_argument("--no-cache", action="store_true", help="recompute the per-frame encoders in every window like the reference")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N>1 headline: strong = one clip sharded by frames/windows over the ranks (default); weak = one clip per rank")
@@ -215,7 +224,7 @@ def main():
         the kernel).  The nominal peaks assume 2.4 GHz; the chip clocks to its power budget, so this is the reachable roof."""
         if prec not in sustained_cache:
             try:
-                tf, ghz = ops.mfma_probe(f32=(prec == "fp32"), device=dev)
+                tf, ghz = ops.mfma_probe(f32=(prec == "fp32"), device=dev)      # (f16: the bf16 probe — same instruction shape and rate)
                 sustained_cache[prec] = {"peak": round(tf, 1), "clock_ghz": round(ghz, 3),
                                          "how": "fgt_mfma_probe: 256 workgroups x 8 wavefronts of independent "
                                                 + ("v_mfma_f32_32x32x2_f32" if prec == "fp32" else "v_mfma_f32_32x32x16_bf16")
@@ -225,10 +234,11 @@ def main():
         return sustained_cache[prec]
 
     def rooflines(kinds, prec, dt):
-        passes = 1 if prec == "fp32" else 3          # MFMA flops issued per algorithmic flop
+        passes = 3 if prec == "bf16x3" else 1        # MFMA flops issued per algorithmic flop (f16 mode: the few GEMMs that still take
+        #                                              fp32 inputs — 4-channel input convs, re-weighting Linear, vec2patch — issue 3; counted as 1)
         peak = PEAK_FP32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
         traffic = kernel_traffic(prec)
-        sus = sustained_peak(prec) if kinds else None
+        sus = sustained_peak("fp32" if prec == "fp32" else "bf16x3") if kinds else None
         out = []
         for k, (ms, fl, n, by) in kinds.items():
             if ms <= 0 or n == 0:
@@ -259,7 +269,7 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
-            "dtype": "f32" if prec == "fp32" else "f32 (conv/GEMM/attention products as 3 bf16 MFMAs on hi/lo splits, fp32 accumulate)",
+            "dtype": DTYPES[prec],
             "data": "synthetic",
             "config": {"workload": f"full FGT forward, random (N(0,0.02)) weights, {args.width}x{args.height}x{args.frames} clip, "
                                    f"reference window schedule (neighbor_stride 5, step 10; sum t = {sum(len(a) + len(b) for a, b in sched)})",
@@ -336,9 +346,23 @@ def main():
     if world == 1 and rank == 0:
         runner = weak_res["runner"]
         frames, flows, masks = weak_res["clip"]
+        parity_of = None
         if not args.no_cpu_baseline:      # CPU baseline: rank 0 at N = 1 only (headline precision still selected)
             ops.DEFAULT_CONV_PRECISION = ops.DEFAULT_ATTN_PRECISION = prec
-            out["parity_vs_cpu_oracle"], out["cpu_baseline"] = cpu_baseline(cfg, sd, frames, flows, masks, runner.sched, model)
+            out["parity_vs_cpu_oracle"], parity_of, out["cpu_baseline"] = cpu_baseline(cfg, sd, frames, flows, masks, runner.sched, model)
+        if prec != "f16" and not args.no_f16:
+            # the third arithmetic mode in the same invocation: operands rounded once to fp16 by their producer, one MFMA per product
+            dt16, host16, comp16, kinds16 = timed(runner, "f16", prof=not args.no_prof)
+            rl = rooflines(kinds16, "f16", dt16)
+            d8 = (comp16.float() - weak_res["comp"].float()).abs()
+            out["f16"] = {"value": round(args.frames * args.steps / dt16, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dt16 / args.steps, 3),
+                          "dtype": DTYPES["f16"], "steps": args.steps, "warmup": args.warmup, "roofline": rl[0] if rl else None, "rooflines": rl,
+                          "effective_tflops": round(sum(fgt_flops(len(a) + len(b)) for a, b in runner.sched) * args.steps / dt16 / 1e12, 2)
+                          if (args.height, args.width) == (240, 432) else None,
+                          "parity_vs_cpu_oracle": parity_of(model, "f16 mode") if parity_of else None,
+                          "composite_vs_headline": {"max_uint8_steps": float(d8.max()), "differing_values": float((d8 > 0).float().mean())},
+                          "output_sane": bool(torch.isfinite(comp16.float()).all())}
+            ops.DEFAULT_CONV_PRECISION = ops.DEFAULT_ATTN_PRECISION = prec
         if prec != "fp32" and not args.no_fp32_exact:
             dt32, host32, comp32, kinds32 = timed(runner, "fp32", prof=not args.no_prof)
             rl = rooflines(kinds32, "fp32", dt32)

@@ -493,7 +493,7 @@ extern "C" int fgt_attention(const fgt_attn_desc* dd, const void* Qv, const void
     p.d = *dd;
     const fgt_attn_desc& d = p.d;
     FGT_REQUIRE(d.heads > 0 && d.nh > 0 && d.nw > 0 && d.b > 0 && d.t > 0, "fgt_attention: bad sizes");
-    FGT_REQUIRE(d.in_split == 0 || d.in_split == 1, "fgt_attention: in_split must be 0 or 1");
+    FGT_REQUIRE(d.in_split >= 0 && d.in_split <= 2, "fgt_attention: in_split must be 0, 1 or 2");
     FGT_REQUIRE(d.ldq % 4 == 0 && d.ldk % 4 == 0 && d.ldv % 4 == 0 && d.ldo % 4 == 0 && d.qoff % 4 == 0 &&
                 d.koff % 4 == 0 && d.voff % 4 == 0, "fgt_attention: strides/offsets must be multiples of 4 floats");
     FGT_REQUIRE((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)KG | (uintptr_t)VG) & 15) == 0,
@@ -523,12 +523,12 @@ extern "C" int fgt_attention(const fgt_attn_desc* dd, const void* Qv, const void
     }
     FGT_REQUIRE(problems <= 65535, "fgt_attention: too many problems (%d) for grid.y", problems);
     hipStream_t s = (hipStream_t)stream;
-    FGT_REQUIRE(d.precision == 0 || d.precision == 1, "fgt_attention: unknown precision %d", d.precision);
-    FGT_REQUIRE(d.out_split == 0 || (d.out_split == 1 && d.pso > 0 && d.pso % 4 == 0), "fgt_attention: bad out_split / pso");
+    FGT_REQUIRE(d.precision == 0 || d.precision == 1 || (d.precision == FGT_PREC_F16 && d.in_split == 2), "fgt_attention: unknown precision %d (FGT_PREC_F16 needs in_split = 2)", d.precision);
+    FGT_REQUIRE(d.out_split == 0 || (d.out_split == 1 && ((d.pso > 0 && d.pso % 4 == 0) || (d.pso == -1 && d.in_split == 2))), "fgt_attention: bad out_split / pso");
     // unique-byte floor: every Q, K, V row of the maps and every global token once, the output once (4 B per value)
     const double rows_in = (double)d.b * d.t * ((d.mode == 1 && d.compact) ? (double)d.h * d.w : (double)d.nh * d.nw), cc = (double)d.heads * HD;
     const double q_frac = (d.mode == 0 && d.tq > 0) ? (double)d.tq / d.t : 1.0;     // Q and O rows that exist
-    const double attn_bytes = 4.0 * cc * ((2.0 + q_frac) * rows_in + (d.mode == 1 ? 2.0 * d.b * d.t * d.n_global + (double)d.b * d.t * d.h * d.w : q_frac * rows_in));
+    const double attn_bytes = (d.in_split == 2 ? 2.0 : 4.0) * cc * ((2.0 + q_frac) * rows_in + (d.mode == 1 ? 2.0 * d.b * d.t * d.n_global + (double)d.b * d.t * d.h * d.w : q_frac * rows_in));
     const int prof = fgt_prof_begin(d.mode == 0 ? FGT_PROF_ATTN_TEMPORAL : FGT_PROF_ATTN_SPATIAL,
                                     4.0 * (double)p.n_q * p.n_k * HD * problems, attn_bytes, s);
     if (d.in_split) {

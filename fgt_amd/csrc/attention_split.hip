@@ -18,6 +18,10 @@
 // 8-byte words read by lanes (i >> 2) + 4k, k = 0..3.  With lane j pointing at V[key0 + (j >> 2)][d0 + 4 (j & 3)] the group reads a
 // [4 keys][16 d] block and lane i gets V[key0 .. key0+3][d0 + i]: the 4 consecutive keys of one d that half an MFMA operand needs.
 // The PV operand of this kernel takes its 8 keys as two such runs: key(e = 8ks + j, h) = 16ks + 4h + (j & 3) + 8 (j >> 2).
+//
+// H = true (FGT_PREC_F16, fgt_attn_desc.in_split = 2): Q, K, V are ONE fp16 plane each (f16_rne of the projection, written by the GEMM
+// epilogue with pso = -1), P is rounded to fp16 in registers, every product is ONE v_mfma_f32_32x32x16_f16.  Same tiles, swizzles,
+// transposing V reads and softmax; a stage is [K | V] (half the LDS-DMA pieces and LDS reads, a third of the MFMAs).
 #include <stdlib.h>
 #include "common.h"
 
@@ -32,7 +36,8 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 constexpr int HD = 128, KT = 32;
 constexpr int PLANE = KT * HD * 2;        // bytes of one 32 x 128 bf16 plane
-constexpr int STAGE = 4 * PLANE;          // K hi, K lo, V hi, V lo
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));   // fp16 mode: a stage is [K | V] instead of [K hi | K lo | V hi | V lo]
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 struct AttnS {
     fgt_attn_desc d;
@@ -74,6 +79,11 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(l, bf16x2));
 }
 
+__device__ __forceinline__ unsigned half2(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+
 struct U4 { unsigned x, y, z, w; };
 __device__ __forceinline__ bf16x8 as_bf16x8(unsigned a, unsigned b, unsigned c, unsigned d) {
     const U4 u = {a, b, c, d};
@@ -89,11 +99,14 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* lds_lo_run, const char* ld
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int NW>
+template <int NW, bool H>
 __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     constexpr int NT = NW * 64;
-    constexpr int PPW = 32 / NW;                 // DMA pieces (4 key rows of one plane) per wavefront and tile
-    static_assert(32 % NW == 0, "pieces per wavefront");
+    constexpr int NPL = H ? 2 : 4;               // planes per stage
+    constexpr int STAGE = NPL * PLANE;           // (shadows the namespace constant: this instance's stage)
+    constexpr int VOFF = (NPL / 2) * PLANE;      // first V plane
+    constexpr int PPW = NPL * 8 / NW;            // DMA pieces (4 key rows of one plane) per wavefront and tile
+    static_assert((NPL * 8) % NW == 0, "pieces per wavefront");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [2 stages][STAGE] tiles, then the row-address tables of the two stages: k / v hi-plane byte addresses of the 32 keys
     unsigned long* ktab = reinterpret_cast<unsigned long*>(smem + 2 * STAGE);
@@ -147,7 +160,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
         for (int i = 0; i < PPW; ++i) {
             const int q = wave + i * NW, plane = q >> 3, grp = q & 7;
             const int R = grp * 4 + rsub;
-            const bool isv = plane >= 2, islo = plane & 1;
+            const bool isv = plane >= NPL / 2, islo = !H && (plane & 1);
             const unsigned long base = (isv ? vtab : ktab)[slot * KT + R];
             const int c = isv ? ((((pc >> 1) ^ ((R & 3) << 1)) << 1) | (pc & 1)) : (pc ^ (R & 15));       // logical 16-byte chunk this lane fetches
             long ps = isv ? p.psv : p.psk;
@@ -160,13 +173,13 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     // ---- Q rows into registers, already split: step s holds d = 16s + 8h + (0..7) of the hi and the lo plane
     const int qi = blockIdx.x * (NW * 32) + wave * 32 + l31;
     const int qpix = local_pix(p, pr, min(qi, p.n_q - 1));
-    bf16x8 qh[8], ql[8];
+    bf16x8 qh[8], ql[H ? 1 : 8];
     {
         const __bf16* qp = p.Q + attn_map_row(d, qpix) * d.ldq + d.qoff + choff + 8 * lh;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             qh[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-            ql[s] = *reinterpret_cast<const bf16x8*>(qp + p.psq + 16 * s);
+            if constexpr (!H) ql[s] = *reinterpret_cast<const bf16x8*>(qp + p.psq + 16 * s);
         }
     }
 
@@ -205,10 +218,14 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
         for (int sx = 0; sx < 8; ++sx) {
             const int off = krow + (((2 * sx + lh) ^ (l31 & 15)) << 4);
             const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(st + off);
-            const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(st + PLANE + off);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, qh[sx], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, ql[sx], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, qh[sx], s, 0, 0, 0);
+            if constexpr (H) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_h), __builtin_bit_cast(f16x8, qh[sx]), s, 0, 0, 0);
+            } else {
+                const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(st + PLANE + off);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, qh[sx], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, ql[sx], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, qh[sx], s, 0, 0, 0);
+            }
         }
         // ---- online softmax in base 2 (scale applied to the fp32 scores), keys of this lane: k0 + (e&3) + 8*(e>>2) + 4*lh
         float mx = -INFINITY;
@@ -242,9 +259,14 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
         // ---- O^T += V^T . P^T
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-            split2(s[8 * ks + 0], s[8 * ks + 1], h0, l0); split2(s[8 * ks + 2], s[8 * ks + 3], h1, l1);
-            split2(s[8 * ks + 4], s[8 * ks + 5], h2, l2); split2(s[8 * ks + 6], s[8 * ks + 7], h3, l3);
+            unsigned h0, h1, h2, h3, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+            if constexpr (H) {     // P in [0, 1]: f16_rne
+                h0 = half2(s[8 * ks + 0], s[8 * ks + 1]); h1 = half2(s[8 * ks + 2], s[8 * ks + 3]);
+                h2 = half2(s[8 * ks + 4], s[8 * ks + 5]); h3 = half2(s[8 * ks + 6], s[8 * ks + 7]);
+            } else {
+                split2(s[8 * ks + 0], s[8 * ks + 1], h0, l0); split2(s[8 * ks + 2], s[8 * ks + 3], h1, l1);
+                split2(s[8 * ks + 4], s[8 * ks + 5], h2, l2); split2(s[8 * ks + 6], s[8 * ks + 7], h3, l3);
+            }
             const bf16x8 p_h = as_bf16x8(h0, h1, h2, h3), p_l = as_bf16x8(l0, l1, l2, l3);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -252,11 +274,15 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
                 const int seg = (t * 2 + (gi & 1)) ^ (vrow_in << 1);        // swizzled 32-byte segment of d block t*32 + 16 (gi & 1)
                 const int r0 = 16 * ks + 4 * (gi >> 1) + vrow_in;
                 const int a0 = r0 * 256 + seg * 32 + vword * 8, a1 = a0 + 8 * 256;
-                const bf16x8 v_h = tr_pair(st + 2 * PLANE + a0, st + 2 * PLANE + a1);
-                const bf16x8 v_l = tr_pair(st + 3 * PLANE + a0, st + 3 * PLANE + a1);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_l, p_h, o[t], 0, 0, 0);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h, p_l, o[t], 0, 0, 0);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h, p_h, o[t], 0, 0, 0);
+                const bf16x8 v_h = tr_pair(st + VOFF + a0, st + VOFF + a1);
+                if constexpr (H) {
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, v_h), __builtin_bit_cast(f16x8, p_h), o[t], 0, 0, 0);
+                } else {
+                    const bf16x8 v_l = tr_pair(st + VOFF + PLANE + a0, st + VOFF + PLANE + a1);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_l, p_h, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h, p_l, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h, p_h, o[t], 0, 0, 0);
+                }
             }
         }
     }
@@ -282,7 +308,9 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4) {
                     const float4 v = make_float4(o[t][4 * e4 + 0] * inv, o[t][4 * e4 + 1] * inv, o[t][4 * e4 + 2] * inv, o[t][4 * e4 + 3] * inv);
-                    if (d.out_split) {
+                    if (d.out_split && d.pso < 0) {          // one fp16 plane
+                        *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(p.O) + ob + t * 32 + 8 * e4) = fgt_half4(v);
+                    } else if (d.out_split) {
                         uint2 hi, lo;
                         fgt_split4(v, hi, lo);
                         __bf16* o16 = reinterpret_cast<__bf16*>(p.O) + ob + t * 32 + 8 * e4;
@@ -296,13 +324,13 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     }
 }
 
-template <int NW>
+template <int NW, bool H>
 int launch(const AttnS& p, int problems, hipStream_t s) {
-    constexpr int smem = 2 * STAGE + 4 * KT * (int)sizeof(unsigned long);
+    constexpr int smem = 2 * (H ? 2 : 4) * PLANE + 4 * KT * (int)sizeof(unsigned long);
     static std::atomic<unsigned long long> lds_set{0};
-    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<NW>), smem, lds_set, "attn_split")) return rc;
+    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<NW, H>), smem, lds_set, "attn_split")) return rc;
     dim3 grid(cdiv(p.n_q, NW * 32), problems);
-    hipLaunchKernelGGL((attn_split_kernel<NW>), grid, dim3(NW * 64), smem, s, p);
+    hipLaunchKernelGGL((attn_split_kernel<NW, H>), grid, dim3(NW * 64), smem, s, p);
     return fgt_check_launch("attn_split_kernel");
 }
 
@@ -314,18 +342,26 @@ int fgt_attention_split(const fgt_attn_desc* dd, const void* Q, const void* K, c
     AttnS p;
     p.d = *dd;
     const fgt_attn_desc& d = p.d;
-    FGT_REQUIRE(d.precision == FGT_PREC_BF16X3, "fgt_attention: split inputs need FGT_PREC_BF16X3");
-    FGT_REQUIRE(d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldv % 8 == 0 && d.qoff % 8 == 0 && d.koff % 8 == 0 && d.voff % 8 == 0 &&
-                d.psq % 8 == 0 && d.psk % 8 == 0 && d.psv % 8 == 0 && d.psq > 0 && d.psk > 0 && d.psv > 0,
-                "fgt_attention: split inputs need strides / offsets / plane strides that are positive multiples of 8 bf16 elements");
-    FGT_REQUIRE(d.n_global == 0 || (d.ldg_k % 8 == 0 && d.ldg_v % 8 == 0 && d.psg_k % 8 == 0 && d.psg_v % 8 == 0 && d.psg_k > 0 && d.psg_v > 0),
+    const bool h16 = d.in_split == 2;
+    FGT_REQUIRE(d.precision == (h16 ? FGT_PREC_F16 : FGT_PREC_BF16X3), "fgt_attention: split inputs need FGT_PREC_BF16X3, fp16 inputs (in_split = 2) FGT_PREC_F16");
+    FGT_REQUIRE(d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldv % 8 == 0 && d.qoff % 8 == 0 && d.koff % 8 == 0 && d.voff % 8 == 0,
+                "fgt_attention: split / fp16 inputs need strides / offsets that are multiples of 8 elements");
+    FGT_REQUIRE(h16 || (d.psq % 8 == 0 && d.psk % 8 == 0 && d.psv % 8 == 0 && d.psq > 0 && d.psk > 0 && d.psv > 0),
+                "fgt_attention: split inputs need plane strides that are positive multiples of 8 bf16 elements");
+    FGT_REQUIRE(d.n_global == 0 || (d.ldg_k % 8 == 0 && d.ldg_v % 8 == 0 && (h16 || (d.psg_k % 8 == 0 && d.psg_v % 8 == 0 && d.psg_k > 0 && d.psg_v > 0))),
                 "fgt_attention: split global tokens need strides / plane strides that are positive multiples of 8");
+    FGT_REQUIRE(d.pso >= 0 || h16, "fgt_attention: an fp16 output (pso = -1) needs fp16 inputs");
     p.Q = static_cast<const __bf16*>(Q); p.K = static_cast<const __bf16*>(K); p.V = static_cast<const __bf16*>(V);
     p.KG = static_cast<const __bf16*>(KG); p.VG = static_cast<const __bf16*>(VG); p.O = O;
     p.psq = d.psq; p.psk = d.psk; p.psv = d.psv; p.psgk = d.psg_k; p.psgv = d.psg_v;
     p.n_q = n_q; p.n_k = n_k; p.n_loc = n_loc; p.zh = zh; p.zw = zw; p.gh = gh; p.gw = gw;
     p.scale_log2e = scale_log2e;
-    if (n_q <= 64) return launch<2>(p, problems, s);
-    if (n_q >= 2048) return launch<8>(p, problems, s);
-    return launch<4>(p, problems, s);
+    if (h16) {
+        if (n_q <= 64) return launch<2, true>(p, problems, s);
+        if (n_q >= 2048) return launch<8, true>(p, problems, s);
+        return launch<4, true>(p, problems, s);
+    }
+    if (n_q <= 64) return launch<2, false>(p, problems, s);
+    if (n_q >= 2048) return launch<8, false>(p, problems, s);
+    return launch<4, false>(p, problems, s);
 }

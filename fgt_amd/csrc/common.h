@@ -74,3 +74,14 @@ __device__ __forceinline__ void fgt_split4(const float4 v, uint2& hi, uint2& lo)
     lo = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(la, fgt_bf16x2)),
                     __builtin_bit_cast(unsigned, __builtin_convertvector(lb, fgt_bf16x2)));
 }
+
+// The fp16 activation format (fgt_conv_desc.in_split = 3, FGT_PREC_F16): ONE plane, h = f16_rne(clamp(x, +-65504)).  The clamp keeps a
+// stray out-of-range activation finite (fp16 has no room above 65504: without it the value would turn into inf and the next GEMM
+// into NaN).  THE definition of the format: every producer uses it (plane stride argument -1).
+typedef _Float16 fgt_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 fgt_half4(const float4 v) {
+    const fgt_f32x2 a = {__builtin_amdgcn_fmed3f(v.x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.y, -65504.f, 65504.f)};
+    const fgt_f32x2 b = {__builtin_amdgcn_fmed3f(v.z, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.w, -65504.f, 65504.f)};
+    return make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(a, fgt_f16x2)),
+                      __builtin_bit_cast(unsigned, __builtin_convertvector(b, fgt_f16x2)));
+}

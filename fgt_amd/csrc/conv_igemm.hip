@@ -332,7 +332,9 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
                 "fgt_conv2d: channels (%d,%d,%d) not divisible by groups %d", d.C0, d.C1, d.Cout, d.groups);
     p.Cg0 = d.C0 / d.groups; p.Cg1 = d.C1 / d.groups; p.Cg = p.Cg0 + p.Cg1; p.Cout_g = d.Cout / d.groups;
     const int gran = d.in_split ? 8 : 4;    // elements per 16-byte gather
-    FGT_REQUIRE(d.in_split >= 0 && d.in_split <= 2, "fgt_conv2d: in_split must be 0, 1 or 2");
+    FGT_REQUIRE(d.in_split >= 0 && d.in_split <= 3, "fgt_conv2d: in_split must be 0, 1, 2 or 3");
+    FGT_REQUIRE(d.precision >= 0 && d.precision <= 2, "fgt_conv2d: unknown precision %d", d.precision);
+    FGT_REQUIRE((d.in_split == 3) == (d.precision == FGT_PREC_F16), "fgt_conv2d: FGT_PREC_F16 and fp16 inputs (in_split = 3) go together");
     if (d.in_split == 2)
         FGT_REQUIRE(p.Cg0 % 32 == 0 && p.Cg1 % 32 == 0 && d.off0 % 32 == 0 && d.off1 % 32 == 0 && d.ld0 % 64 == 0 && (d.C1 == 0 || d.ld1 % 64 == 0),
                     "fgt_conv2d: interleaved split inputs need Cin/groups and offsets multiples of 32, row strides multiples of 64");
@@ -341,16 +343,17 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     FGT_REQUIRE(d.ld0 % gran == 0 && d.off0 % gran == 0 && (d.C1 == 0 || (x1 && d.ld1 % gran == 0 && d.off1 % gran == 0)),
                 "fgt_conv2d: source strides/offsets must be multiples of %d elements", gran);
     if (d.in_split) {
-        FGT_REQUIRE(d.precision == FGT_PREC_BF16X3, "fgt_conv2d: split inputs need FGT_PREC_BF16X3");
+        FGT_REQUIRE(d.in_split == 3 || d.precision == FGT_PREC_BF16X3, "fgt_conv2d: split inputs need FGT_PREC_BF16X3");
         FGT_REQUIRE(d.in_relu == 0, "fgt_conv2d: in_relu cannot be applied to split inputs (the producer applies it)");
-        FGT_REQUIRE(d.in_split == 2 || (d.ps0 % 8 == 0 && d.ps0 > 0 && (d.C1 == 0 || (d.ps1 % 8 == 0 && d.ps1 > 0))), "fgt_conv2d: plane strides must be positive multiples of 8");
+        FGT_REQUIRE(d.in_split >= 2 || (d.ps0 % 8 == 0 && d.ps0 > 0 && (d.C1 == 0 || (d.ps1 % 8 == 0 && d.ps1 > 0))), "fgt_conv2d: plane strides must be positive multiples of 8");
+        FGT_REQUIRE(d.in_split != 3 || (d.w_il == 0 && d.Kpad % 64 == 0), "fgt_conv2d: FGT_PREC_F16 takes the plain fp16 weight image with Kpad %% 64 == 0");
     }
     FGT_REQUIRE(d.out_split >= 0 && d.out_split <= 2, "fgt_conv2d: out_split must be 0, 1 or 2");
     FGT_REQUIRE(d.out_split == 1 || out != nullptr, "fgt_conv2d: null output");
     if (d.out_split) {
         FGT_REQUIRE(out_s != nullptr && ((uintptr_t)out_s & 7) == 0, "fgt_conv2d: out_split needs an 8-byte aligned out_s");
-        FGT_REQUIRE(p.Cout_g % 4 == 0 && !d.out_nchw && d.ldo_s % 4 == 0 && d.ooff_s % 4 == 0 && d.pso % 4 == 0 && d.pso > 0,
-                    "fgt_conv2d: out_split needs Cout/groups, ldo_s, ooff_s, pso multiples of 4 and NHWC output");
+        FGT_REQUIRE(p.Cout_g % 4 == 0 && !d.out_nchw && d.ldo_s % 4 == 0 && d.ooff_s % 4 == 0 && (d.pso == -1 || (d.pso % 4 == 0 && d.pso > 0)),
+                    "fgt_conv2d: out_split needs Cout/groups, ldo_s, ooff_s, pso multiples of 4 (pso = -1: fp16 plane) and NHWC output");
         FGT_REQUIRE(d.out_split == 1 || (d.ldo % 4 == 0 && d.ooff % 4 == 0), "fgt_conv2d: out_split = 2 needs ldo, ooff multiples of 4");
         FGT_REQUIRE(d.pso != 32 || (p.Cout_g % 32 == 0 && d.ooff_s % 32 == 0 && d.ldo_s % 64 == 0),
                     "fgt_conv2d: interleaved out_s (pso = 32) needs Cout/groups, ooff_s multiples of 32 and ldo_s a multiple of 64");
@@ -371,7 +374,7 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     if (d.epi == FGT_EPI_GRU) FGT_REQUIRE(aux2 != nullptr, "fgt_conv2d: GRU epilogue needs aux2");
     const long M = (long)d.N * Ho * Wo;
     FGT_REQUIRE(M < (1l << 31), "fgt_conv2d: M too large");
-    p.M = (int)M; p.HoWo = Ho * Wo; p.nk = d.Kpad / BK;
+    p.M = (int)M; p.HoWo = Ho * Wo; p.nk = d.Kpad / (d.in_split == 3 ? 64 : BK);
     static const int pipe_env = [] { const char* e = getenv("FGT_CONV_PIPE"); return e ? atoi(e) : 1; }();
     p.pipe = pipe_env;
     static const int xcd_env = [] { const char* e = getenv("FGT_CONV_XCD"); return e ? atoi(e) : 1; }();
@@ -396,12 +399,15 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     // roofline accounting is about the MFMA kernels only; algorithmic flops use the UNPADDED K (flow 2 -> 4, RGB 3 -> 4 channel
     // padding is not work the reference does): desc.k_alg = kh*kw*Cin_real/groups, 0 = the padded K
     // unique-byte floor: input map(s) once (4 B per value, fp32 or hi + lo), weights once, every output form once, aux operands once
-    const double conv_bytes = 4.0 * ((double)d.N * d.H * d.W * (d.C0 + d.C1) + (double)d.Cout * p.K +
-                                     (double)M * d.Cout * ((d.out_split == 2 ? 2 : 1) + (d.epi != FGT_EPI_NONE ? 1 : 0) + (d.epi == FGT_EPI_GRU ? 1 : 0)));
+    // (fp16 tensors — in_split = 3, out_s with pso = -1 — are 2 B per value)
+    const double in_b = d.in_split == 3 ? 2.0 : 4.0, os_b = (d.out_split && d.pso < 0) ? 2.0 : 4.0;
+    const double conv_bytes = in_b * ((double)d.N * d.H * d.W * (d.C0 + d.C1) + (double)d.Cout * p.K) +
+                              (double)M * d.Cout * ((d.out_split != 1 ? 4.0 : 0.0) + (d.out_split ? os_b : 0.0) +
+                                                    4.0 * ((d.epi != FGT_EPI_NONE ? 1 : 0) + (d.epi == FGT_EPI_GRU ? 1 : 0)));
     const int prof = direct ? -1 : fgt_prof_begin(FGT_PROF_CONV, 2.0 * (double)M * p.Cout_g * (d.k_alg > 0 ? d.k_alg : p.K) * d.groups, conv_bytes, s);
-    FGT_REQUIRE(d.precision == 0 || d.precision == 1, "fgt_conv2d: unknown precision %d", d.precision);
     int rc;
     if (direct) rc = fgt_conv_direct(p, s);   // Cout <= 4: VALU direct conv (fp32)
+    else if (d.in_split == 3) rc = fgt_conv_f16_launch(tile, p, s);
     else if (d.in_split) rc = fgt_conv_split_launch(tile, p, s);
     else if (tile >= FGT_TILE_256x128x8_S3) { fgt_set_error("fgt_conv2d: tile %d needs split inputs", tile); rc = FGT_EINVAL; }
     else rc = d.precision == 0 ? launch_tile<0>(tile, p, s) : launch_tile<1>(tile, p, s);

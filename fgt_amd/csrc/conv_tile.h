@@ -127,12 +127,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                     if (ok[u0]) {
                         if (want_f32) *reinterpret_cast<float4*>(p.out + (long)m * d.ldo + d.ooff + co) = make_float4(v[0], v[1], v[2], v[3]);
                         if (want_split) {
-                            uint2 hi, lo;
-                            split4(make_float4(v[0], v[1], v[2], v[3]), hi, lo);
                             const int cs = d.ooff_s + co;       // pso == 32: interleaved layout, channel c -> (c/32)*64 + c%32, lo 32 further
-                            __bf16* o = p.out_s + (long)m * d.ldo_s + (p.pso == 32 ? ((cs >> 5) << 6) + (cs & 31) : cs);
-                            *reinterpret_cast<uint2*>(o) = hi;
-                            *reinterpret_cast<uint2*>(o + p.pso) = lo;
+                            if (p.pso < 0) {                    // pso == -1: one fp16 plane (in_split = 3 of the consumer)
+                                *reinterpret_cast<uint2*>(p.out_s + (long)m * d.ldo_s + cs) = fgt_half4(make_float4(v[0], v[1], v[2], v[3]));
+                            } else {
+                                uint2 hi, lo;
+                                split4(make_float4(v[0], v[1], v[2], v[3]), hi, lo);
+                                __bf16* o = p.out_s + (long)m * d.ldo_s + (p.pso == 32 ? ((cs >> 5) << 6) + (cs & 31) : cs);
+                                *reinterpret_cast<uint2*>(o) = hi;
+                                *reinterpret_cast<uint2*>(o + p.pso) = lo;
+                            }
                         }
                     }
                 }
@@ -188,12 +192,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
             if (vec_ok) {
                 if (want_f32) *reinterpret_cast<float4*>(p.out + (long)m * d.ldo + d.ooff + co) = make_float4(v[0], v[1], v[2], v[3]);
                 if (want_split) {       // validated by the host: vec_ok holds whenever out_split is set
-                    uint2 hi, lo;
-                    split4(make_float4(v[0], v[1], v[2], v[3]), hi, lo);
                     const int cs = d.ooff_s + co;       // pso == 32: interleaved layout, channel c -> (c/32)*64 + c%32, lo 32 further
-                    __bf16* o = p.out_s + (long)m * d.ldo_s + (p.pso == 32 ? ((cs >> 5) << 6) + (cs & 31) : cs);
-                    *reinterpret_cast<uint2*>(o) = hi;
-                    *reinterpret_cast<uint2*>(o + p.pso) = lo;
+                    if (p.pso < 0) {                    // pso == -1: one fp16 plane
+                        *reinterpret_cast<uint2*>(p.out_s + (long)m * d.ldo_s + cs) = fgt_half4(make_float4(v[0], v[1], v[2], v[3]));
+                    } else {
+                        uint2 hi, lo;
+                        split4(make_float4(v[0], v[1], v[2], v[3]), hi, lo);
+                        __bf16* o = p.out_s + (long)m * d.ldo_s + (p.pso == 32 ? ((cs >> 5) << 6) + (cs & 31) : cs);
+                        *reinterpret_cast<uint2*>(o) = hi;
+                        *reinterpret_cast<uint2*>(o + p.pso) = lo;
+                    }
                 }
             } else if (d.out_nchw) {
                 const int n_img = m / p.HoWo, rem = m - n_img * p.HoWo;

@@ -11,9 +11,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// fp32 store, or (ps > 0) the split format: `out` then points at the hi plane of a bf16 tensor, offsets / ps in bf16 elements
+// fp32 store, or (ps > 0) the split format: `out` then points at the hi plane of a bf16 tensor, offsets / ps in bf16 elements;
+// ps == -1: `out` is one fp16 plane (offsets in fp16 elements)
 __device__ __forceinline__ void store_f32_or_split(float* out, long off, long ps, const float4 v) {
-    if (ps > 0) {
+    if (ps < 0) {
+        *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(out) + off) = fgt_half4(v);
+    } else if (ps > 0) {
         uint2 hi, lo;
         fgt_split4(v, hi, lo);
         __bf16* o = reinterpret_cast<__bf16*>(out) + off;
@@ -391,6 +394,10 @@ __global__ void split_kernel(const float* __restrict__ x, long rows, int C4, int
         const int c = (int)(i - r * C4) * 4;
         float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
         if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if (ps < 0) {                                                                  // ps == -1: one fp16 plane
+            *reinterpret_cast<uint2*>(out + r * ld_s + c) = fgt_half4(v);
+            continue;
+        }
         uint2 hi, lo;
         fgt_split4(v, hi, lo);
         __bf16* o = out + r * ld_s + (ps == 32 ? ((c >> 5) << 6) + (c & 31) : c);     // ps == 32: interleaved per 32 channels
@@ -408,7 +415,8 @@ extern "C" int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, 
     FGT_REQUIRE(C0 > 0 && C0 % 4 == 0 && C1 % 4 == 0 && (C0 + C1) <= 256 * LN_MAXV, "fgt_layernorm: C=(%d,%d) unsupported", C0, C1);
     FGT_REQUIRE(ld0 % 4 == 0 && (C1 == 0 || (x1 && ld1 % 4 == 0)) && ldA % 4 == 0 && (!outB || (gB && bB && ldB % 4 == 0)),
                 "fgt_layernorm: strides must be multiples of 4 floats");
-    FGT_REQUIRE(psA >= 0 && psB >= 0 && psA % 4 == 0 && psB % 4 == 0, "fgt_layernorm: plane strides must be non-negative multiples of 4");
+    FGT_REQUIRE((psA == -1 || (psA >= 0 && psA % 4 == 0)) && (psB == -1 || (psB >= 0 && psB % 4 == 0)),
+                "fgt_layernorm: plane strides must be non-negative multiples of 4 (or -1: fp16 plane)");
     hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, rows,
                        eps, gA, bA, outA, ldA, gB, bB, outB, ldB, (long)psA, (long)psB);
     return fgt_check_launch("layernorm");
@@ -444,7 +452,7 @@ extern "C" int fgt_fold(const float* Y, int ldy, int frames, int th, int tw, int
     FGT_REQUIRE(Y && out && C % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && (!res || ldres % 4 == 0), "fgt_fold: bad arguments");
     FGT_REQUIRE((Hf + 2 * p - k) / s + 1 == th && (Wf + 2 * p - k) / s + 1 == tw, "fgt_fold: token grid %dx%d does not match output %dx%d", th, tw, Hf, Wf);
     const long total = (long)frames * Hf * Wf * (C / 4);
-    FGT_REQUIRE(ps_out >= 0 && ps_out % 4 == 0, "fgt_fold: plane stride must be a non-negative multiple of 4");
+    FGT_REQUIRE(ps_out == -1 || (ps_out >= 0 && ps_out % 4 == 0), "fgt_fold: plane stride must be a non-negative multiple of 4 (or -1: fp16 plane)");
     hipLaunchKernelGGL(fold_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, Y, ldy, frames, th, tw, C, k, s, p,
                        Hf, Wf, normalize, res, ldres, out, ldo, relu, (long)ps_out);
     return fgt_check_launch("fold");
@@ -532,7 +540,7 @@ extern "C" int fgt_gather_rows(const float* src, long ld_src, const int* ids, in
 
 extern "C" int fgt_split(const float* x, long rows, int C, int ldx, void* out_s, int ld_s, long long ps, int relu, void* stream) {
     FGT_REQUIRE(x && out_s && rows > 0 && C > 0, "fgt_split: bad arguments");
-    FGT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ld_s % 4 == 0 && ps % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out_s & 7) == 0,
+    FGT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ld_s % 4 == 0 && (ps == -1 || (ps > 0 && ps % 4 == 0)) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out_s & 7) == 0,
                 "fgt_split: C, strides must be multiples of 4 and pointers aligned");
     hipLaunchKernelGGL(split_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, rows, C / 4, ldx,
                        static_cast<__bf16*>(out_s), ld_s, (long)ps, relu);

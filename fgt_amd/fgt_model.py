@@ -291,7 +291,7 @@ class FGT(nn.Module):
         """bf16x3 mode: conv -> conv chains hand their activations over pre-split (ops.Split): the producer's epilogue splits
         each value once and the consumer's loader is a plain LDS-DMA copy (csrc/conv_split.hip).  Same arithmetic as feeding
         fp32 tensors to the bf16x3 kernel, bit for bit."""
-        return ops.DEFAULT_CONV_PRECISION == "bf16x3"
+        return ops.DEFAULT_CONV_PRECISION in ("bf16x3", "f16")      # 'f16': the same chains hand over ONE fp16 plane (csrc/conv_f16.hip)
 
     def _block(self, x, packed, act="lrelu", out_split=None, **kw):
         f, g = packed

@@ -14,7 +14,9 @@ import torch
 from . import _lib
 from ._lib import ACT, EPI, PREC, TILE, AttnDesc, ConvDesc, check
 
-# arithmetic mode of fgt_conv2d when the caller does not pass `precision=`: 'fp32' (exact) or 'bf16x3'
+# arithmetic mode of fgt_conv2d when the caller does not pass `precision=`: 'fp32' (exact), 'bf16x3' (16 significant bits per operand,
+# 3 MFMAs per product) or 'f16' (operands rounded once to fp16 by their producer — 11 bits, one MFMA per product, half the activation
+# bytes; GEMMs whose input is still an fp32 tensor run in bf16x3)
 DEFAULT_CONV_PRECISION = os.environ.get("FGT_CONV_PRECISION", "fp32")
 DEFAULT_ATTN_PRECISION = os.environ.get("FGT_ATTN_PRECISION", "fp32")
 
@@ -24,7 +26,8 @@ DEFAULT_ATTN_PRECISION = os.environ.get("FGT_ATTN_PRECISION", "fp32")
 AUTOTUNE = os.environ.get("FGT_AUTOTUNE", "1") != "0"
 TILE_CANDIDATES = ("128x128", "64x64", "128x64", "256x128", "128x32", "128x128x8", "256x128x16", "256x64x8",
                    # split inputs only (rejected, hence skipped, for fp32 inputs): the same tiles with early stage release
-                   "128x128ea", "64x64ea", "128x64ea", "128x128x8ea", "256x128x16ea", "256x64x8ea")
+                   "128x128ea", "64x64ea", "128x64ea", "128x128x8ea", "256x128x16ea", "256x64x8ea",
+                   "256x128ea")     # fp16 kernel only (csrc/conv_f16.hip)
 _tile_cache = {}
 
 
@@ -75,18 +78,27 @@ def _require_dev(*ts):
 
 class Split:
     """A "split" activation tensor (include/fgt_hip.h, fgt_conv_desc.in_split): the bf16 pair hi = bf16_rne(x),
-    lo = bf16_rne(x - hi) of the fp32 tensor `shape` it stands for (same bytes as fp32).  Two layouts:
+    lo = bf16_rne(x - hi) of the fp32 tensor `shape` it stands for (same bytes as fp32) — or, in the 'f16' mode (h = True), the ONE
+    fp16 plane data = f16_rne(x) [*shape] (half the bytes; fgt_conv_desc.in_split = 3).  Two bf16 layouts:
       planes       data = bf16 [2, *shape]: data[0] = hi, data[1] = lo (any channel count that is a multiple of 8);
       interleaved  data = bf16 [*shape[:-1], 2*C]: per 32 channels [hi 32 | lo 32], so the 64 + 64 bytes one K-step of the conv
                    kernel needs from a pixel are ONE 128-byte line (C % 32 == 0).
     Produced once by the kernel that computes x (conv epilogue or ops.split), consumed by fgt_conv2d's LDS-DMA loader."""
 
-    def __init__(self, data, interleaved=False):
-        assert data.dtype == torch.bfloat16 and data.is_cuda and (interleaved or data.shape[0] == 2)
-        self.data, self.il = data, interleaved
+    def __init__(self, data, interleaved=False, h=False):
+        if h:
+            assert data.dtype == torch.float16 and data.is_cuda and not interleaved
+        else:
+            assert data.dtype == torch.bfloat16 and data.is_cuda and (interleaved or data.shape[0] == 2)
+        self.data, self.il, self.h = data, interleaved, h
 
     @staticmethod
-    def empty(shape, device, interleaved=False):
+    def empty(shape, device, interleaved=False, h=None):
+        """h: the fp16 format (one plane); None = follow the arithmetic mode (DEFAULT_CONV_PRECISION == 'f16')."""
+        if h is None:
+            h = DEFAULT_CONV_PRECISION == "f16" and not interleaved
+        if h:
+            return Split(torch.empty(tuple(shape), dtype=torch.float16, device=device), h=True)
         if interleaved:
             assert shape[-1] % 32 == 0, "interleaved split tensors need C % 32 == 0"
             return Split(torch.empty(tuple(shape[:-1]) + (2 * shape[-1],), dtype=torch.bfloat16, device=device), True)
@@ -94,6 +106,8 @@ class Split:
 
     @property
     def shape(self):
+        if self.h:
+            return self.data.shape
         return torch.Size(tuple(self.data.shape[:-1]) + (self.data.shape[-1] // 2,)) if self.il else self.data.shape[1:]
 
     @property
@@ -103,20 +117,26 @@ class Split:
     @property
     def hi(self):
         """The tensor whose data_ptr / strides describe the hi values (planes: plane 0; interleaved: the 2*C-wide rows)."""
-        return self.data if self.il else self.data[0]
+        return self.data if (self.il or self.h) else self.data[0]
 
     @property
     def ps(self):
-        return 32 if self.il else self.data.stride(0)
+        """Plane stride argument of the C ABI: bf16 elements between hi and lo, 32 = interleaved, -1 = one fp16 plane."""
+        return -1 if self.h else (32 if self.il else self.data.stride(0))
 
     def view(self, *shape):
+        if self.h:
+            return Split(self.data.view(*shape), h=True)
         return Split(self.data.view(*shape[:-1], 2 * shape[-1]), True) if self.il else Split(self.data.view(2, *shape))
 
     def __getitem__(self, idx):            # leading-dimension slices (rows / frames)
+        if self.h:
+            return Split(self.data[idx], h=True)
         return Split(self.data[idx], True) if self.il else Split(self.data[:, idx])
 
     def planes(self):
         """(hi, lo) as bf16 tensors of the logical shape (tests / debugging)."""
+        assert not self.h, "an fp16 Split has one plane"
         if not self.il:
             return self.data[0], self.data[1]
         d = self.data.reshape(*self.data.shape[:-1], -1, 2, 32)
@@ -124,16 +144,19 @@ class Split:
 
     def float(self):
         """hi + lo as fp32 (tests / debugging: 16 mantissa bits of the original)."""
+        if self.h:
+            return self.data.float()
         hi, lo = self.planes()
         return hi.float() + lo.float()
 
 
-def split(x, relu=False, out=None, interleave=False):
-    """fp32 [rows, C] / [N,H,W,C] -> Split (fgt_split)."""
+def split(x, relu=False, out=None, interleave=False, h=None):
+    """fp32 [rows, C] / [N,H,W,C] -> Split (fgt_split); the format follows the arithmetic mode unless `out` or `h` (True: one fp16
+    plane, False: the bf16 pair) is given."""
     _require_dev(x)
     x4, N, H, W, Cc, ld = _as_map(x)
     if out is None:
-        out = Split.empty(x.shape, x.device, interleave)
+        out = Split.empty(x.shape, x.device, interleave, h=h)
     o4, oN, oH, oW, oC, ldo = _as_map(out.hi)
     assert (oN * oH * oW, oC) == (N * H * W, Cc * (2 if out.il else 1))
     check(_lib.lib().fgt_split(_ptr(x4), N * H * W, Cc, ld, _ptr(out.data), ldo, out.ps, int(relu), _stream()), "fgt_split")
@@ -198,6 +221,18 @@ class PackedConv:
 WEIGHTS_INTERLEAVED = os.environ.get("FGT_W_IL", "1") != "0"
 
 
+def _f16_weights(pc):
+    """The fp16 kernel's weight image: f16_rne(w) as [groups, Npad, Kpad64], K zero-padded to the 64-channel K-step of csrc/conv_f16.hip."""
+    cache = pc.__dict__.setdefault("_w_split_cache", {})
+    if "h" not in cache:
+        G, Np, Kp = pc.w.shape
+        Kp64 = ceil_to(Kp, 64)
+        w = torch.zeros(G, Np, Kp64, dtype=torch.float16, device=pc.w.device)
+        w[:, :, :Kp] = pc.w.clamp(-65504.0, 65504.0).to(torch.float16)
+        cache["h"] = w
+    return cache["h"]
+
+
 def _split_weights(pc, interleaved=None):
     """The bf16x3 kernels' weight image: hi = bf16_rne(w), lo = bf16_rne(w - hi), as two planes [2, groups, Npad, Kpad] or
     (fgt_conv_desc.w_il) interleaved per K-step [groups, Npad, Kpad/32, (hi 32 | lo 32)] — one 128-byte line per row and step."""
@@ -221,7 +256,7 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     returns/outputs a channels-last map (or NCHW).  out_split: None -> fp32 result; "only" -> a Split; "both" -> (fp32, Split)."""
     in_split = isinstance(x, Split)
     if in_split:
-        assert x1 is None or (isinstance(x1, Split) and x1.il == x.il), "conv2d: both sources must be split the same way"
+        assert x1 is None or (isinstance(x1, Split) and x1.il == x.il and x1.h == x.h), "conv2d: both sources must be split the same way"
         xs, x1s = x, x1
         x, x1 = xs.hi, (None if x1s is None else x1s.hi)
     else:
@@ -264,14 +299,19 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     d.out_scale = float(out_scale)
     d.Kpad, d.Npad, d.tile = pc.Kpad, pc.Npad, TILE[tile]
     d.k_alg = getattr(pc, "k_alg", 0)
-    d.precision = PREC[precision if precision is not None else DEFAULT_CONV_PRECISION]
+    prec = precision if precision is not None else DEFAULT_CONV_PRECISION
+    if prec == "f16" and not (in_split and xs.h):
+        prec = "bf16x3"                      # 'f16' = fp16 where the operand arrives as fp16; fp32 inputs are not rounded to 11 bits here
+    d.precision = PREC[prec]
     if pc.Cout // pc.groups <= 4 and d.tile == 0 and not in_split and not osp:
         d.precision = 0                      # Cout <= 4 layers run the fp32 VALU direct-conv kernels
-    d.in_split = (2 if xs.il else 1) if in_split else 0
+    d.in_split = (3 if xs.h else (2 if xs.il else 1)) if in_split else 0
     if in_split:
-        if d.precision != PREC["bf16x3"]:
+        if xs.h:
+            d.precision = PREC["f16"]        # the format decides: fp16 tensors feed the fp16 kernel
+        elif d.precision != PREC["bf16x3"]:
             raise RuntimeError("conv2d: Split inputs need precision='bf16x3'")
-        d.ps0, d.ps1 = xs.ps, (0 if x1s is None else x1s.ps)
+        d.ps0, d.ps1 = (0, 0) if xs.h else (xs.ps, (0 if x1s is None else x1s.ps))
     d.out_split = osp
     if osp:
         if out_s is None:
@@ -281,6 +321,9 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
         d.ldo_s, d.ooff_s, d.pso = ldo_s, 0, out_s.ps
     if d.precision == 0:
         wbuf = pc.w
+    elif d.precision == PREC["f16"]:
+        wbuf = _f16_weights(pc)
+        d.Kpad = wbuf.shape[-1]
     else:
         wbuf, wil = _split_weights(pc)
         d.w_il = int(wil)
@@ -288,7 +331,7 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
             _ptr(None if out_s is None else out_s.data))
     if d.tile == 0 and AUTOTUNE and pc.Cout // pc.groups > 4:
         key = (N, H, W, C0, C1, pc.Cout, pc.groups, pc.kh, pc.kw, sh, sw, ph, pw, dh, dw, d.upsample, d.epi, d.out_nchw, d.precision,
-               d.in_split, d.out_split, d.w_il, int(bool(osp) and out_s.il))
+               d.in_split, d.out_split, d.w_il, int(bool(osp) and out_s.il) + 2 * int(bool(osp) and out_s.h))
         best = _tile_cache.get(key)
         if best is None and not torch.cuda.is_current_stream_capturing() and not _aliases(out, out_s, x, x1, aux1, aux2):
             # (tuning re-launches the kernel into the caller's buffers and synchronises: illegal under stream capture, and it would
@@ -371,7 +414,7 @@ def linear(x, pc, **kw):
 def _out_desc(t):
     """(pointer-holding tensor, row stride, plane stride) of an fp32 tensor (ps = 0) or a planes-layout Split."""
     if isinstance(t, Split):
-        assert not t.il, "fused split outputs use the planes layout"
+        assert not t.il, "fused split outputs use the planes layout (or fp16)"
         return t.hi, t.hi.stride(0), t.ps
     return t, (0 if t is None else t.stride(0)), 0
 
@@ -393,8 +436,17 @@ def layernorm(x0, gA, bA, x1=None, gB=None, bB=None, outA=None, outB=None, eps=1
     return (outA, outB) if gB is not None else outA
 
 
-def _attn_out(rows, c, device, out_split, d):
-    out = Split.empty((rows, c), device) if out_split else torch.empty(rows, c, dtype=torch.float32, device=device)
+def _attn_prec(insp, h16, precision):
+    """Arithmetic of an attention call: the input format decides for Splits; fp32 inputs in the 'f16' mode run in bf16x3."""
+    if insp:
+        return PREC["f16" if h16 else "bf16x3"]
+    prec = precision if precision is not None else DEFAULT_ATTN_PRECISION
+    return PREC["bf16x3" if prec == "f16" else prec]
+
+
+def _attn_out(rows, c, device, out_split, d, h16=False):
+    # an fp16 output needs fp16 inputs (csrc/attention_split.hip); with other inputs the split output is the bf16 pair
+    out = Split.empty((rows, c), device, h=bool(h16)) if out_split else torch.empty(rows, c, dtype=torch.float32, device=device)
     t, ld, ps = _out_desc(out)
     d.ldo, d.out_split, d.pso = ld, int(bool(out_split)), ps
     return out, t
@@ -403,7 +455,7 @@ def _attn_out(rows, c, device, out_split, d):
 def _attn_in(t):
     """(tensor holding the data pointer, row stride, plane stride) of an fp32 tensor or a planes-layout Split input."""
     if isinstance(t, Split):
-        assert not t.il, "attention takes the planes layout"
+        assert not t.il, "attention takes the planes layout (or fp16)"
         return t.hi, t.hi.stride(0), t.ps
     return t, (0 if t is None else t.stride(0)), 0
 
@@ -422,12 +474,13 @@ def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None, out_s
     d.ldq = d.ldk = d.ldv = ld
     d.qoff, d.koff, d.voff = 0, c, 2 * c
     d.ldg_k = d.ldg_v = 0
-    d.in_split, d.psq, d.psk, d.psv = int(insp), ps, ps, ps
+    h16 = insp and qkv.h
+    d.in_split, d.psq, d.psk, d.psv = (2 if h16 else int(insp)), ps, ps, ps
     tq = t if tq is None else int(tq)
     assert 0 < tq <= t
     d.tq = 0 if tq == t else tq
-    out, optr = _attn_out(b * tq * nh * nw, c, src.device, out_split, d)
-    d.precision = PREC["bf16x3" if insp else (precision if precision is not None else DEFAULT_ATTN_PRECISION)]
+    out, optr = _attn_out(b * tq * nh * nw, c, src.device, out_split, d, h16)
+    d.precision = _attn_prec(insp, h16, precision)
     check(_lib.lib().fgt_attention(C.byref(d), _ptr(src), _ptr(src), _ptr(src), None, None, _ptr(optr), _stream()),
           "fgt_attention(temporal)")
     return out
@@ -449,12 +502,14 @@ def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, pr
     (qt, d.ldq, d.psq), (kt, d.ldk, d.psk), (vt, d.ldv, d.psv) = _attn_in(q), _attn_in(k), _attn_in(v)
     (kgt, d.ldg_k, d.psg_k), (vgt, d.ldg_v, d.psg_v) = _attn_in(kg), _attn_in(vg)
     d.qoff = d.koff = d.voff = 0
-    d.in_split = int(insp)
+    h16 = insp and q.h
+    assert not insp or all(x.h == h16 for x in (k, v, kg, vg)), "attention_spatial: one Split format for all inputs"
+    d.in_split = 2 if h16 else int(insp)
     if pad_row is not None:
         assert 0 <= pad_row < min(x.shape[0] for x in (q, k, v))
         d.compact, d.pad_row = 1, int(pad_row)
-    out, optr = _attn_out(bt * h * w, c, qt.device, out_split, d)
-    d.precision = PREC["bf16x3" if insp else (precision if precision is not None else DEFAULT_ATTN_PRECISION)]
+    out, optr = _attn_out(bt * h * w, c, qt.device, out_split, d, h16)
+    d.precision = _attn_prec(insp, h16, precision)
     check(_lib.lib().fgt_attention(C.byref(d), _ptr(qt), _ptr(kt), _ptr(vt), _ptr(kgt), _ptr(vgt), _ptr(optr), _stream()),
           "fgt_attention(spatial)")
     return out

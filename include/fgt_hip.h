@@ -85,10 +85,13 @@ typedef struct fgt_conv_desc {
     float out_scale;        /* multiplies the value after act (before epi); 1.0f = off                */
     int Kpad, Npad;         /* packed-weight geometry: w is [groups, Npad, Kpad], k = (ky*kw+kx)*Cg+ci */
     int tile;               /* 0 = auto; otherwise a FGT_TILE_* override (tuning / tests)             */
-    int precision;          /* FGT_PREC_FP32 (exact fp32 MFMA) | FGT_PREC_BF16X3 (hi/lo bf16 split, 3 MFMAs).
+    int precision;          /* FGT_PREC_FP32 (exact fp32 MFMA) | FGT_PREC_BF16X3 (hi/lo bf16 split, 3 MFMAs) | FGT_PREC_F16.
                              * With FGT_PREC_BF16X3 `w_packed` must be the PRE-SPLIT bf16 image of the packed weights:
                              * [2][groups][Npad][Kpad] bf16, plane 0 = hi = bf16_rne(w), plane 1 = lo = bf16_rne(w - hi)
-                             * (same byte count as the fp32 image).                                                  */
+                             * (same byte count as the fp32 image).
+                             * FGT_PREC_F16 (in_split = 3 only): ONE v_mfma_f32_32x32x16_f16 per product on operands rounded once
+                             * to fp16 (11 significant bits, fp32 accumulate); `w_packed` = [groups][Npad][Kpad] fp16 = f16_rne(w),
+                             * Kpad a multiple of 64 (a K-step is 64 channels: one 128-byte line per row).                     */
     /* "Split" activation tensors (FGT_PREC_BF16X3 only): two bf16 planes with the layout of the fp32 tensor they stand for,
      * hi = bf16_rne(x) at the pointer and lo = bf16_rne(x - hi) `ps` ELEMENTS further (same bytes as fp32).  A producer
      * splits each value once (conv epilogue, fgt_layernorm, fgt_fold, fgt_attention, fgt_split); a consumer conv then moves
@@ -99,11 +102,15 @@ typedef struct fgt_conv_desc {
                              * 2: as 1 but hi/lo INTERLEAVED per 32 channels: channel c of a pixel lives at element
                              *    (c/32)*64 + c%32 (hi) and +32 (lo) of a row of 2*C elements, so the 32 hi and 32 lo values of
                              *    one K-step are ONE 128-byte line (planes: two half-used lines).  ld* = row stride in elements
-                             *    (>= 2*C), off* = LOGICAL first channel; needs Cin/groups and off % 32 == 0; ps* unused.    */
+                             *    (>= 2*C), off* = LOGICAL first channel; needs Cin/groups and off % 32 == 0; ps* unused.
+                             * 3: (FGT_PREC_F16) x0/x1 point to fp16 tensors = f16_rne(x), ONE plane with the layout of the fp32 tensor
+                             *    (half the bytes); ld/off in fp16 elements, Cin/groups, ld, off % 8 == 0, in_relu == 0; ps* unused.
+                             *    Written by the same producers as the split format when their plane stride argument is -1.        */
     int out_split;          /* 0: fp32 `out` only | 1: split `out_s` only | 2: both (needs Cout/groups, ldo_s, ooff_s % 4 == 0,
                              *    out_nchw == 0)                                                                         */
     int ldo_s, ooff_s;      /* row stride / first channel of out_s (bf16 elements; out_split with pso == 32 writes the
-                             * interleaved layout of in_split = 2: ldo_s >= 2*Cout, needs Cout/groups % 32 == 0)          */
+                             * interleaved layout of in_split = 2: ldo_s >= 2*Cout, needs Cout/groups % 32 == 0;
+                             * pso == -1 writes the single fp16 plane of in_split = 3, whatever `precision` computed it)   */
     int w_il;               /* 1: w_packed is [groups][Npad][Kpad/32][hi 32 | lo 32] (interleaved) instead of two planes   */
     int k_alg;              /* profiling only: kh*kw*Cin/groups BEFORE zero-padding of the input channels (flow 2 -> 4, RGB 3 -> 4),
                              * the K that fgt_prof_* credits as algorithmic work; 0 = use the padded K                        */
@@ -112,6 +119,7 @@ typedef struct fgt_conv_desc {
 
 #define FGT_PREC_FP32 0
 #define FGT_PREC_BF16X3 1
+#define FGT_PREC_F16 2    /* fp16 operands (rounded once by the producer), one MFMA per product, fp32 accumulate: pre-split inputs only */
 
 #define FGT_TILE_128x128 1
 #define FGT_TILE_128x64 2
@@ -143,6 +151,9 @@ typedef struct fgt_conv_desc {
 #define FGT_TILE_128x128x8_LW 32  /* split inputs only: early-release tiles with two LOADER wavefronts per workgroup (one owns the A tile, one the  */
 #define FGT_TILE_128x128_LW 33    /* B tile: address arithmetic + LDS-DMA issue only) next to the 8 / 4 consumer wavefronts (fragment reads + MFMAs): */
 #define FGT_TILE_128x64_LW 34     /* the DMA issue no longer sits in front of the MFMAs of the same wavefront.  Bit-identical results; measured slower. */
+#define FGT_TILE_256x256x16 36   /* FGT_PREC_F16 only: 256x256 on 16 wavefronts of 64x64, one workgroup per CU (128 KB of LDS stages) */
+#define FGT_TILE_256x256x16_EA 37
+#define FGT_TILE_256x128_EA 38   /* FGT_PREC_F16 only: 256x128 on 8 wavefronts of 64x64 with early stage release */
 #define FGT_TILE_256x256_P8N 19   /* 17 without s_setprio (A/B measurements) */
 #define FGT_TILE_256x256_P8L 20   /* 17 with both wavefront groups in lock step (A/B measurements) */
 
@@ -152,7 +163,8 @@ int fgt_conv2d(const fgt_conv_desc* d, const void* x0, const void* x1, const flo
                void* out_s /* split output or NULL */, void* stream);
 
 /* fp32 [rows, C] (row stride ldx floats) -> split tensor (hi plane at out_s, lo plane `ps` bf16 elements further, row stride
- * ld_s); relu = 1 applies max(x, 0) first.  For activations whose producer is not one of the fused ones.  C % 4 == 0. */
+ * ld_s); relu = 1 applies max(x, 0) first.  For activations whose producer is not one of the fused ones.  C % 4 == 0.
+ * ps == -1: out_s is ONE fp16 plane = f16_rne(x) (fgt_conv_desc.in_split = 3). */
 int fgt_split(const float* x, long rows, int C, int ldx, void* out_s, int ld_s, long long ps, int relu, void* stream);
 
 /* Row LayerNorm over the concatenation [x0 | x1] (C1 = 0: single source), eps inside rsqrt.
@@ -161,7 +173,7 @@ int fgt_split(const float* x, long rows, int C, int ldx, void* out_s, int ld_s, 
  * Replaces nn.LayerNorm at FGT/models/model.py:126,128,147 and attention_flow.py:84-85,96 (q_norm/k_norm
  * share statistics for window tokens; v_norm).
  * psA / psB > 0: that output is written as a split tensor for the next GEMM (fgt_conv_desc.in_split): the pointer is the bf16 hi
- * plane, ld in bf16 elements, the lo plane ps elements further; 0 = fp32. */
+ * plane, ld in bf16 elements, the lo plane ps elements further; 0 = fp32; -1 = one fp16 plane (fgt_conv_desc.in_split = 3). */
 int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, long rows, float eps,
                   const float* gA, const float* bA, float* outA, int ldA,
                   const float* gB, const float* bB, float* outB, int ldB, long long psA, long long psB, void* stream);
@@ -184,13 +196,15 @@ typedef struct fgt_attn_desc {
     int group;              /* mode 0: zones per side                                                 */
     int ws, n_global;       /* mode 1                                                                 */
     int ldq, qoff, ldk, koff, ldv, voff, ldg_k, ldg_v, ldo;
-    int precision;          /* FGT_PREC_FP32 | FGT_PREC_BF16X3 (Q, K, P, V split into hi/lo bf16, 3 MFMAs per product) */
+    int precision;          /* FGT_PREC_FP32 | FGT_PREC_BF16X3 (Q, K, P, V split into hi/lo bf16, 3 MFMAs per product) |
+                             * FGT_PREC_F16 (in_split = 2: Q, K, V arrive as fp16, P is rounded to fp16, one MFMA per product) */
     int out_split;          /* 1: O is a split tensor (see fgt_conv_desc): pointer to the bf16 hi plane, ldo in bf16 elements */
-    long long pso;          /* plane stride of O in bf16 elements (out_split = 1)                                            */
+    long long pso;          /* plane stride of O in bf16 elements (out_split = 1); -1 = O is one fp16 plane (in_split = 2 only) */
     int in_split;           /* 1 (FGT_PREC_BF16X3 only): Q, K, V (and KG, VG) point to the bf16 hi planes of split tensors written by
                              * the projection GEMMs (fgt_conv_desc.out_split); ld* / *off in bf16 elements (multiples of 8), lo planes
                              * ps* elements further.  K / V tiles then travel global -> LDS by LDS-DMA and nothing is converted in the
-                             * kernel (csrc/attention_split.hip); Q is stored unscaled and 1/sqrt(d) multiplies the fp32 scores.   */
+                             * kernel (csrc/attention_split.hip); Q is stored unscaled and 1/sqrt(d) multiplies the fp32 scores.
+                             * 2 (FGT_PREC_F16 only): the same with ONE fp16 plane per tensor (ps* unused).                      */
     int tq;                 /* mode 0: 0 = every frame queries; 0 < tq <= t: only the first tq frames of each batch element do (K / V still
                              * span all t frames) and O holds b * tq frames compactly — the clip scheduler's last temporal block, whose
                              * other frames nobody reads (tool/video_inpainting.py:727 consumes the neighbour frames only)            */
@@ -225,7 +239,8 @@ int fgt_dw3x3_residual(const float* x, int bt, int h, int w, int C, const float*
 int fgt_fold(const float* Y, int ldy, int frames, int th, int tw, int C, int k, int s, int p, int Hf, int Wf,
              int normalize, const float* res, int ldres, float* out, int ldo,
              int relu /* max(.,0) last: the FFN's ReLU in front of its second Linear, ffn_base.py:40 */,
-             long long ps_out /* > 0: `out` is the hi plane of a split tensor (bf16 elements), lo plane ps_out further */, void* stream);
+             long long ps_out /* > 0: `out` is the hi plane of a split tensor (bf16 elements), lo plane ps_out further; -1: one fp16 plane */,
+             void* stream);
 
 /* NCHW -> channels-last slice: dst[n, y, x, coff + c] = src[n, c, y, x] * scale + shift for c < C;
  * zero_to > C additionally zero-fills channels [C, zero_to).  (input packing: model.py:253-257) */

@@ -16,29 +16,48 @@ _ACT = {None: lambda v, s: v, "none": lambda v, s: v, "lrelu": lambda v, s: F.le
         "sigmoid": lambda v, s: torch.sigmoid(v), "tanh": lambda v, s: torch.tanh(v)}
 
 
-DEFAULT_CONV_PRECISION = "fp32"      # tests flip it to "bf16x3" to walk the split-chain plumbing of the host code
+DEFAULT_CONV_PRECISION = "fp32"      # tests flip it to "bf16x3" / "f16" to walk the split-chain plumbing of the host code
+
+
+def _f16_mode():
+    return DEFAULT_CONV_PRECISION == "f16"
+
+
+def f16_round(x):
+    """The fp16 activation / weight format of the 'f16' mode (csrc/common.h fgt_half4): f16_rne(clamp(x, +-65504)), as fp32 values."""
+    return x.clamp(-65504.0, 65504.0).to(torch.float16).float()
 
 
 class Split:
     """Stand-in for ops.Split: carries the fp32 tensor the split planes stand for (the CPU spec is exact; the 2^-16 rounding of the
-    real format is a kernel property, pinned on the GPU in tests/test_split_gpu.py)."""
+    real format is a kernel property, pinned on the GPU in tests/test_split_gpu.py).  In the 'f16' mode the tensor holds the values
+    ROUNDED to fp16 (h = True; writers go through `put`): there the rounding is 2^-11 and part of the specification — this file is
+    then the numerical model of that mode (operands rounded once by their producer, exact products, fp32-or-better accumulation)."""
 
-    def __init__(self, x):
-        self.x = x
+    def __init__(self, x, h=None):
+        self.h = _f16_mode() if h is None else h
+        self.x = f16_round(x) if self.h else x
 
     @staticmethod
-    def empty(shape, device=None):
-        return Split(torch.empty(tuple(shape)))
+    def empty(shape, device=None, h=None):
+        return Split(torch.zeros(tuple(shape)), h)
+
+    def put(self, val):
+        self.x.copy_(f16_round(val) if self.h else val)
 
     @property
     def shape(self):
         return self.x.shape
 
     def __getitem__(self, idx):
-        return Split(self.x[idx])
+        s = Split.__new__(Split)            # a view of the same storage (writers fill slices in place), already rounded
+        s.h, s.x = self.h, self.x[idx]
+        return s
 
     def view(self, *shape):
-        return Split(self.x.view(*shape))
+        s = Split.__new__(Split)
+        s.h, s.x = self.h, self.x.view(*shape)
+        return s
 
 
 def split(x, relu=False, out=None):
@@ -59,9 +78,11 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
         assert not out_nchw and out_s is None
         y = conv2d(x, pc, x1, stride, pad, dil, upsample, pad_mode, in_relu, act, slope, epi, aux1, aux2, act2, out_scale, out)
         return Split(y) if out_split == "only" else (y, Split(y))
+    h16 = False
     if isinstance(x, Split):
-        assert DEFAULT_CONV_PRECISION == "bf16x3" or precision == "bf16x3", "Split inputs need the bf16x3 mode"
-        assert not in_relu and (x1 is None or isinstance(x1, Split))
+        assert DEFAULT_CONV_PRECISION in ("bf16x3", "f16") or precision == "bf16x3", "Split inputs need the bf16x3 / f16 mode"
+        assert not in_relu and (x1 is None or (isinstance(x1, Split) and x1.h == x.h))
+        h16 = x.h                                  # fp16 operands: the weights are rounded to fp16 as well (ops._f16_weights)
         x, x1 = x.x, (None if x1 is None else x1.x)
     else:
         assert not isinstance(x1, Split), "sources must both be split"
@@ -82,7 +103,8 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     if pad_mode == "replicate":
         inp = F.pad(inp, (pw, pw, ph, ph), mode="replicate")
         ph = pw = 0
-    y = F.conv2d(inp, _dense_weight(pc), None, stride, (ph, pw), dil, G)
+    wd = _dense_weight(pc)
+    y = F.conv2d(inp, f16_round(wd) if h16 else wd, None, stride, (ph, pw), dil, G)
     if pc.scale is not None:
         y = y * pc.scale.view(1, -1, 1, 1)
     if pc.bias is not None:
@@ -113,12 +135,12 @@ def linear(x, pc, **kw):
     rows = x.shape[0]
     out = kw.pop("out", None)
     x1 = kw.pop("x1", None)
-    img = lambda t: None if t is None else (Split(t.x.unsqueeze(0).unsqueeze(0)) if isinstance(t, Split) else t.unsqueeze(0).unsqueeze(0))
+    img = lambda t: None if t is None else (t.view(1, 1, *t.shape) if isinstance(t, Split) else t.unsqueeze(0).unsqueeze(0))
     y = conv2d(img(x), pc, x1=img(x1), **kw)
     if isinstance(y, Split):                      # out_split = "only"
-        return Split(y.x.reshape(rows, pc.Cout))
+        return y.view(rows, pc.Cout)
     if isinstance(y, tuple):                      # out_split = "both"
-        return y[0].reshape(rows, pc.Cout), Split(y[1].x.reshape(rows, pc.Cout))
+        return y[0].reshape(rows, pc.Cout), y[1].view(rows, pc.Cout)
     y = y.reshape(rows, pc.Cout)
     if out is not None:
         out.copy_(y)
@@ -130,7 +152,10 @@ def _emit(val, out, as_split):
     """Write `val` into `out` (fp32 tensor or Split) if given, else return it (wrapped when as_split)."""
     if out is None:
         return Split(val) if as_split else val
-    (out.x if isinstance(out, Split) else out).copy_(val)
+    if isinstance(out, Split):
+        out.put(val)
+    else:
+        out.copy_(val)
     return out
 
 
@@ -143,21 +168,27 @@ def layernorm(x0, gA, bA, x1=None, gB=None, bB=None, outA=None, outB=None, eps=1
     return a, _emit(F.layer_norm(cat, (C,), gB, bB, eps), outB, splitB)
 
 
-def _sdpa(q, k, v):
+def _sdpa(q, k, v, h16=False):
     s = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(q.size(-1))
-    return torch.matmul(F.softmax(s, dim=-1), v)
+    if not h16:
+        return torch.matmul(F.softmax(s, dim=-1), v)
+    # fp16 mode (csrc/attention_split.hip, H = true): the un-normalised probabilities exp(s - max) are rounded to fp16 for the PV
+    # product, the normaliser is the fp32 sum of the unrounded ones (the kernel's online rescaling does the same per tile)
+    p = torch.exp(s - s.amax(-1, keepdim=True))
+    return torch.matmul(f16_round(p), v) / p.sum(-1, keepdim=True)
 
 
 def _unsplit(*ts):
-    """attention inputs: all fp32, or all Splits (then only in the bf16x3 mode) -> the fp32 tensors"""
+    """attention inputs: all fp32, or all Splits of one format (then only in the bf16x3 / f16 mode) -> (fp32 tensors, fp16 format?)"""
     if any(isinstance(t, Split) for t in ts):
-        assert all(isinstance(t, Split) for t in ts) and DEFAULT_CONV_PRECISION == "bf16x3", "Split attention inputs need the bf16x3 mode, all together"
-        return tuple(t.x for t in ts)
-    return ts
+        assert all(isinstance(t, Split) for t in ts) and DEFAULT_CONV_PRECISION in ("bf16x3", "f16"), "Split attention inputs need the bf16x3 / f16 mode, all together"
+        assert all(t.h == ts[0].h for t in ts), "one Split format per call"
+        return tuple(t.x for t in ts), ts[0].h
+    return ts, False
 
 
 def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None, out_split=False, tq=None):
-    (qkv,) = _unsplit(qkv)
+    (qkv,), h16 = _unsplit(qkv)
     zh, zw, d = nh // group, nw // group, c // heads
     tq = t if tq is None else tq
 
@@ -165,8 +196,9 @@ def attention_temporal(qkv, b, t, nh, nw, heads, group, c, precision=None, out_s
         return y.reshape(b, tt, group, zh, group, zw, heads, d).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, group * group, heads, -1, d)
 
     q = qkv[:, :c].reshape(b, t, nh * nw, c)[:, :tq].reshape(b * tq * nh * nw, c)        # queries: the first tq frames of each batch element
-    a = _sdpa(zones(q, tq), zones(qkv[:, c:2 * c]), zones(qkv[:, 2 * c:3 * c]))
-    return _emit(a.view(b, group, group, heads, tq, zh, zw, d).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(b * tq * nh * nw, c), None, out_split)
+    a = _sdpa(zones(q, tq), zones(qkv[:, c:2 * c]), zones(qkv[:, 2 * c:3 * c]), h16)
+    a = a.view(b, group, group, heads, tq, zh, zw, d).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(b * tq * nh * nw, c)
+    return Split(a, h16) if out_split else a             # (an fp16 output needs fp16 inputs: ops._attn_out)
 
 
 def _uncompact(m, bt, h, w, nh, nw, pad_row):
@@ -178,7 +210,7 @@ def _uncompact(m, bt, h, w, nh, nw, pad_row):
 
 
 def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, precision=None, out_split=False, pad_row=None):
-    q, k, v, kg, vg = _unsplit(q, k, v, kg, vg)
+    (q, k, v, kg, vg), h16 = _unsplit(q, k, v, kg, vg)
     if pad_row is not None:
         q, k, v = (_uncompact(m, bt, h, w, nh, nw, pad_row) for m in (q, k, v))
     c = q.shape[1]
@@ -192,9 +224,10 @@ def attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, heads, ws, n_global, pr
 
     K = torch.cat([windows(k), kg.reshape(bt, 1, n_global, c).expand(-1, gh * gw, -1, -1)], 2)
     V = torch.cat([windows(v), vg.reshape(bt, 1, n_global, c).expand(-1, gh * gw, -1, -1)], 2)
-    a = _sdpa(split(windows(q)), split(K), split(V))
+    a = _sdpa(split(windows(q)), split(K), split(V), h16)
     a = a.transpose(2, 3).reshape(bt, gh, gw, ws, ws, c).transpose(2, 3).reshape(bt, nh, nw, c)
-    return _emit(a[:, :h, :w].reshape(bt * h * w, c), None, out_split)
+    a = a[:, :h, :w].reshape(bt * h * w, c)
+    return Split(a, h16) if out_split else a
 
 
 def dw_pool(x0, x1, bt, nh, nw, k, w, bias, out, h=None, w_real=None):
