@@ -204,7 +204,11 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     for (int it = 0; it < ntiles; ++it) {
         const int slot = it & 1;
         if (it + 1 < ntiles) key_pointers(it + 1, slot ^ 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wavefront's pieces of tile `it` have landed
+        // this wavefront's pieces of tile `it` have landed, and (wavefront 0) its table writes above are COMPLETE: a ds_write that is merely
+        // issued when its wavefront reaches the barrier can still be overtaken by another SIMD's table read behind the barrier — the
+        // fp16 variant (shorter tiles) read a stale / unwritten row address under load (memory fault at address 0 in the spatial call
+        // of a batched window group), the bf16x3 variant had the same hazard without ever showing it
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                       // ... everyone's have; tile it-1 is fully consumed; table slot^1 is visible
         if (it + 1 < ntiles) issue_tile(it + 1, slot ^ 1);                  // streams under the MFMAs below
         const char* st = smem + slot * STAGE;

@@ -191,10 +191,11 @@ def test_f16_rejections(dev):
     rc = _lib.lib().fgt_attention(C.byref(d), p(qkv.hi), p(qkv.hi), p(qkv.hi), None, None, p(d_out.data),
                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == -1                                                                        # FGT_EINVAL
-    d.pso = qkv.ps                                                                         # (the same call with a bf16-pair output is fine)
-    o2 = ops.Split.empty((128, 512), dev, h=False)
+    o2 = ops.Split.empty((128, 512), dev, h=False)                                         # (the same call with a bf16-pair output is fine)
+    d.pso = o2.ps
     assert _lib.lib().fgt_attention(C.byref(d), p(qkv.hi), p(qkv.hi), p(qkv.hi), None, None, p(o2.data),
                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
 
 
 def test_producers_write_f16(dev, f16_mode):
