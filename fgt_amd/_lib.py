@@ -56,7 +56,7 @@ SIGNATURES = {
     "fgt_attention": [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P],
     "fgt_dw_pool": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "fgt_dw3x3_residual": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
-    "fgt_fold": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, C.c_longlong, _P],
+    "fgt_fold": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, C.c_longlong, _I, _P],
     "fgt_nchw_to_nhwc": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _F, _P],
     "fgt_nhwc_to_nchw": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
     "fgt_pad_tokens": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],

@@ -199,6 +199,19 @@ __global__ void __launch_bounds__(256) dw_pool4_kernel(const float* x0, int C0, 
 }
 
 // ------------------------------------------------------------------ fold as a gather
+// 4 consecutive channels of a token row: fp32, or (YH) the fp16 plane a GEMM wrote with pso = -1 (half the bytes of the largest
+// tensor of a transformer block; the values are summed in fp32 either way)
+template <bool YH> __device__ __forceinline__ float4 fold_load4(const float* Y, long off) {
+    if constexpr (YH) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 v = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(Y) + off);
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    } else {
+        return *reinterpret_cast<const float4*>(Y + off);
+    }
+}
+
+template <bool YH>
 __global__ void __launch_bounds__(256) fold_kernel(const float* Y, int ldy, int frames, int th, int tw, int C, int k, int s,
                                                    int p, int Hf, int Wf, int normalize, const float* res, int ldres,
                                                    float* out, int ldo, int relu, long ps_out) {
@@ -224,7 +237,7 @@ __global__ void __launch_bounds__(256) fold_kernel(const float* Y, int ldy, int 
                 for (int b = 0; b < 3; ++b) {
                     const int i = min(i_lo + a, i_hi), j = min(j_lo + b, j_hi);
                     const int ky = y + p - i * s, kx = x + p - j * s;
-                    v[a * 3 + b] = *reinterpret_cast<const float4*>(Y + ((long)f * th * tw + i * tw + j) * ldy + (ky * k + kx) * C + c);
+                    v[a * 3 + b] = fold_load4<YH>(Y, ((long)f * th * tw + i * tw + j) * ldy + (ky * k + kx) * C + c);
                 }
 #pragma unroll
             for (int a = 0; a < 3; ++a)
@@ -240,7 +253,7 @@ __global__ void __launch_bounds__(256) fold_kernel(const float* Y, int ldy, int 
                 const int ky = y + p - i * s;
                 for (int j = j_lo; j <= j_hi; ++j) {
                     const int kx = x + p - j * s;
-                    const float4 v = *reinterpret_cast<const float4*>(Y + ((long)f * th * tw + i * tw + j) * ldy + (ky * k + kx) * C + c);
+                    const float4 v = fold_load4<YH>(Y, ((long)f * th * tw + i * tw + j) * ldy + (ky * k + kx) * C + c);
                     acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
                     ++cnt;
                 }
@@ -448,13 +461,18 @@ extern "C" int fgt_dw3x3_residual(const float* x, int bt, int h, int w, int C, c
 }
 
 extern "C" int fgt_fold(const float* Y, int ldy, int frames, int th, int tw, int C, int k, int s, int p, int Hf, int Wf,
-                        int normalize, const float* res, int ldres, float* out, int ldo, int relu, long long ps_out, void* stream) {
+                        int normalize, const float* res, int ldres, float* out, int ldo, int relu, long long ps_out, int y_f16, void* stream) {
     FGT_REQUIRE(Y && out && C % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && (!res || ldres % 4 == 0), "fgt_fold: bad arguments");
     FGT_REQUIRE((Hf + 2 * p - k) / s + 1 == th && (Wf + 2 * p - k) / s + 1 == tw, "fgt_fold: token grid %dx%d does not match output %dx%d", th, tw, Hf, Wf);
     const long total = (long)frames * Hf * Wf * (C / 4);
     FGT_REQUIRE(ps_out == -1 || (ps_out >= 0 && ps_out % 4 == 0), "fgt_fold: plane stride must be a non-negative multiple of 4 (or -1: fp16 plane)");
-    hipLaunchKernelGGL(fold_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, Y, ldy, frames, th, tw, C, k, s, p,
-                       Hf, Wf, normalize, res, ldres, out, ldo, relu, (long)ps_out);
+    FGT_REQUIRE(y_f16 == 0 || y_f16 == 1, "fgt_fold: y_f16 must be 0 or 1");
+    if (y_f16)
+        hipLaunchKernelGGL(fold_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, Y, ldy, frames, th, tw, C, k, s, p,
+                           Hf, Wf, normalize, res, ldres, out, ldo, relu, (long)ps_out);
+    else
+        hipLaunchKernelGGL(fold_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, Y, ldy, frames, th, tw, C, k, s, p,
+                           Hf, Wf, normalize, res, ldres, out, ldo, relu, (long)ps_out);
     return fgt_check_launch("fold");
 }
 

@@ -293,6 +293,10 @@ class FGT(nn.Module):
         fp32 tensors to the bf16x3 kernel, bit for bit."""
         return ops.DEFAULT_CONV_PRECISION in ("bf16x3", "f16")      # 'f16': the same chains hand over ONE fp16 plane (csrc/conv_f16.hip)
 
+    @staticmethod
+    def _f16():
+        return ops.DEFAULT_CONV_PRECISION == "f16"
+
     def _block(self, x, packed, act="lrelu", out_split=None, **kw):
         f, g = packed
         if g is None:
@@ -305,7 +309,8 @@ class FGT(nn.Module):
         """x_res + FusionFeedForward(y)  (ffn_base.py:53-77).  y may be a Split (bf16x3 mode)."""
         k, s, p = self.cfg["k"][0], self.cfg["s"][0], self.cfg["p"][0]
         sc = self._split_chain()
-        Y = ops.linear(y, P["conv1"])                                       # [bt*n, k*k*cc] tap-major
+        # [bt*n, k*k*cc] tap-major; f16 mode: the hidden (the largest tensor of the block, 768 MB per batched launch as fp32) as fp16
+        Y = ops.linear(y, P["conv1"], out_split="only" if self._f16() else None)
         # fold(x) / fold(ones); in split mode the ReLU in front of the second Linear is applied here, once per value,
         # and the map is handed over pre-split (otherwise it is applied on the gathered values inside the conv)
         F = ops.fold(Y, bt, th, tw, P["cc"], k, s, p, Hf, Wf, normalize=True, relu=sc, out_split=sc)
@@ -496,12 +501,16 @@ class FGT(nn.Module):
             assert b == 1, "n_out needs a single clip (frames of one batch element are contiguous); use keep= for b > 1"
             bt = n_out
             x, enc = x[: bt * n], enc[:bt]
-        Y = ops.linear(x, P["v2p"])
-        feat = ops.fold(Y, bt, th, tw, P["v2p_c"], cfg["k"][0], cfg["s"][0], cfg["p"][0], Hf, Wf, normalize=False, res=enc)
-        D = P["dec"]
         sc = "only" if self._split_chain() else None
-        if sc:
-            feat = ops.split(feat)
+        if self._f16():
+            # the token stream is fp32; rounding it once here (one pass over [rows, 512]) lets the widest GEMM of the path (512 -> 6272) run
+            # on the fp16 kernel and hand fold() an fp16 patch matrix (1.6 GB per clip pass as fp32)
+            Y = ops.linear(ops.split(x), P["v2p"], out_split="only")
+        else:
+            Y = ops.linear(x, P["v2p"])
+        # soft composition + encoder residual; split mode: written pre-split for the decoder's first conv (its only consumer)
+        feat = ops.fold(Y, bt, th, tw, P["v2p_c"], cfg["k"][0], cfg["s"][0], cfg["p"][0], Hf, Wf, normalize=False, res=enc, out_split=bool(sc))
+        D = P["dec"]
         y = self._block(feat, D[0], stride=1, pad=1, upsample=True, out_split=sc)
         y = self._block(y, D[1], stride=1, pad=1, out_split=sc)
         y = self._block(y, D[2], stride=1, pad=1, upsample=True)              # fp32: the Cout = 3 kernel below gathers fp32

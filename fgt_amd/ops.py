@@ -537,8 +537,15 @@ def dw3x3_residual(x, bt, h, w, wgt, bias):
 
 def fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize, res=None, out=None, relu=False, out_split=False):
     """Overlap-add of [frames*th*tw, k*k*Cc] (tap-major columns) to [frames, Hf, Wf, Cc]; relu: max(., 0) last;
-    out_split: write the result pre-split (the FFN's second Linear consumes it as a conv over this map)."""
-    _require_dev(Y, res)
+    out_split: write the result pre-split (the FFN's second Linear consumes it as a conv over this map).
+    Y: fp32, or the fp16 Split a GEMM wrote in the 'f16' mode (half the bytes of the block's largest tensor; fp32 sums)."""
+    y_h = isinstance(Y, Split)
+    if y_h:
+        assert Y.h, "fold: a Split input must be the fp16 format"
+        Y = Y.data
+    else:
+        _require_dev(Y)
+    _require_dev(res)
     if out is None:
         out = Split.empty((frames, Hf, Wf, Cc), Y.device) if out_split else torch.empty(frames, Hf, Wf, Cc, dtype=torch.float32, device=Y.device)
     ldres = 0 if res is None else _as_map(res)[5]
@@ -548,7 +555,7 @@ def fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize, res=None, out=None, 
         _require_dev(out)
         optr, ldo, ps = out, _as_map(out)[5], 0
     check(_lib.lib().fgt_fold(_ptr(Y), Y.stride(0), frames, th, tw, Cc, k, s, p, Hf, Wf, int(normalize), _ptr(res), ldres,
-                              _ptr(optr), ldo, int(relu), ps, _stream()), "fgt_fold")
+                              _ptr(optr), ldo, int(relu), ps, int(y_h), _stream()), "fgt_fold")
     return out
 
 

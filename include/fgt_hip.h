@@ -240,7 +240,7 @@ int fgt_fold(const float* Y, int ldy, int frames, int th, int tw, int C, int k, 
              int normalize, const float* res, int ldres, float* out, int ldo,
              int relu /* max(.,0) last: the FFN's ReLU in front of its second Linear, ffn_base.py:40 */,
              long long ps_out /* > 0: `out` is the hi plane of a split tensor (bf16 elements), lo plane ps_out further; -1: one fp16 plane */,
-             void* stream);
+             int y_f16 /* 1: Y is the fp16 plane a GEMM wrote with pso = -1 (ldy in fp16 elements); the sums stay fp32 */, void* stream);
 
 /* NCHW -> channels-last slice: dst[n, y, x, coff + c] = src[n, c, y, x] * scale + shift for c < C;
  * zero_to > C additionally zero-fills channels [C, zero_to).  (input packing: model.py:253-257) */

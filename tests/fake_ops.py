@@ -247,6 +247,9 @@ def dw3x3_residual(x, bt, h, w, wgt, bias):
 
 
 def fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize, res=None, out=None, relu=False, out_split=False):
+    if isinstance(Y, Split):
+        assert Y.h, "fold: a Split input must be the fp16 format"
+        Y = Y.x
     cols = Y.reshape(frames, th * tw, k * k, Cc).permute(0, 3, 2, 1).reshape(frames, Cc * k * k, th * tw)  # back to (c, tap)
     f = F.fold(cols, (Hf, Wf), k, stride=s, padding=p)
     if normalize:

@@ -215,6 +215,14 @@ def test_producers_write_f16(dev, f16_mode):
     f32 = ops.fold(Y, frames, th, tw, Cc, k, s_, p, Hf, Wf, normalize=True, relu=True)
     f16 = ops.fold(Y, frames, th, tw, Cc, k, s_, p, Hf, Wf, normalize=True, relu=True, out_split=True)
     assert f16.h and torch.equal(f16.data, f32.to(torch.float16))
+    # fp16 INPUT (the FFN hidden / the vec2patch patch matrix as written by a GEMM with pso = -1): the same fp32 sums of the same values
+    Yh = ops.split(Y)
+    assert Yh.h and torch.equal(ops.fold(Yh, frames, th, tw, Cc, k, s_, p, Hf, Wf, normalize=True, relu=True),
+                                ops.fold(Yh.float(), frames, th, tw, Cc, k, s_, p, Hf, Wf, normalize=True, relu=True))
+    res = _rand(frames, Hf, Wf, Cc, seed=8).to(dev)
+    a = ops.fold(Yh, frames, th, tw, Cc, k, s_, p, Hf, Wf, normalize=False, res=res, out_split=True)
+    b = ops.fold(Yh.float(), frames, th, tw, Cc, k, s_, p, Hf, Wf, normalize=False, res=res)
+    assert a.h and torch.equal(a.data, b.to(torch.float16))
 
 
 @pytest.mark.parametrize("b,t,nh,nw", [(1, 3, 20, 36), (2, 2, 6, 8), (1, 5, 22, 36), (1, 13, 20, 36), (2, 17, 20, 36), (1, 26, 40, 72)])

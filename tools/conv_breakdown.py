@@ -46,15 +46,18 @@ def main():
         xs = x.shape
         x1 = kw.get("x1")
         o = out[0] if isinstance(out, tuple) else out
-        key = (tuple(xs), 0 if x1 is None else x1.shape[-1], pc.Cout, pc.groups, f"{pc.kh}x{pc.kw}", kw.get("stride", 1), "split" if isinstance(x, ops.Split) else "fp32",
+        key = (tuple(xs), 0 if x1 is None else x1.shape[-1], pc.Cout, pc.groups, f"{pc.kh}x{pc.kw}", kw.get("stride", 1), ("f16" if x.h else "split") if isinstance(x, ops.Split) else "fp32",
                {None: "f32", "only": "split", "both": "f32+split"}[kw.get("out_split")], kw.get("epi") or "-")
         osh = tuple(o.shape)
         M = osh[0] * osh[1] * osh[2] if len(osh) == 4 else osh[0]
         cin = (xs[-1] + (0 if x1 is None else x1.shape[-1]))
         flops = 2.0 * M * (pc.Cout // pc.groups) * pc.k_alg * pc.groups
-        in_b = 4.0 * xs[0] * xs[1] * xs[2] * cin
-        out_b = 4.0 * M * pc.Cout * (2 if kw.get("out_split") == "both" else 1) + (4.0 * M * pc.Cout if kw.get("epi") else 0)
-        w_b = 4.0 * pc.Cout * pc.K
+        h_in = isinstance(x, ops.Split) and x.h                        # fp16 tensors: 2 B per value
+        osp = kw.get("out_split")
+        h_out = bool(osp) and a.precision == "f16"
+        in_b = (2.0 if h_in else 4.0) * xs[0] * xs[1] * xs[2] * cin
+        out_b = M * pc.Cout * ((4.0 if osp != "only" else 0.0) + ((2.0 if h_out else 4.0) if osp else 0.0)) + (4.0 * M * pc.Cout if kw.get("epi") else 0)
+        w_b = (2.0 if h_in else 4.0) * pc.Cout * pc.K
         recs.append((key, e0, e1, flops, in_b + out_b + w_b))
         return out
 
