@@ -29,16 +29,17 @@ if has bench; then
 import sys,json; d=json.loads(sys.stdin.read())
 print(d['value'],'fps', d['ms_per_step'],'ms; cpu', d.get('cpu_baseline',{}).get('value'), 'parity', d.get('parity_vs_cpu_oracle',{}).get('max_abs_diff'))
 for r in d.get('rooflines',[]): print('  ', r['kind'], r['frac'], r['algorithmic_tflops'],'TF alg', r['kernel_ms_per_step'],'ms/step', r['avg_launch_us'],'us/launch')
-f=d.get('fp32_exact')
-if f:
-    print('fp32_exact', f['value'],'fps', f['ms_per_step'],'ms')
-    for r in f.get('rooflines',[]): print('  ', r['kind'], r['frac'], r['algorithmic_tflops'],'TF alg', r['kernel_ms_per_step'],'ms/step')
+for name in ('f16', 'fp32_exact'):
+    f=d.get(name)
+    if f:
+        print(name, f['value'],'fps', f['ms_per_step'],'ms', 'parity', (f.get('parity_vs_cpu_oracle') or {}).get('max_abs_diff'), f.get('composite_vs_headline'))
+        for r in f.get('rooflines',[]): print('  ', r['kind'], r['frac'], r['algorithmic_tflops'],'TF alg', r['kernel_ms_per_step'],'ms/step')
 " || tail -5 gpurun_out/bench.log
 fi
 if has pmc; then
   echo "== PMC HBM traffic of the MFMA kernels over bench.py (tiles pre-seeded: only clip-pass launches in the trace)"
   for c in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmcb_$c" -o pmc -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-prof --no-fp32-exact > "$R/gpurun_out/pmcb_$c.log" 2>&1)
+    (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmcb_$c" -o pmc -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-prof --no-fp32-exact --no-f16 > "$R/gpurun_out/pmcb_$c.log" 2>&1)
     echo "pmc $c exit $?"
   done
   python tools/pmc_traffic.py gpurun_out/pmcb_FETCH_SIZE gpurun_out/pmcb_WRITE_SIZE bf16x3 gpurun_out/kernel_traffic.json
@@ -46,10 +47,16 @@ fi
 if has stats; then
   echo "== rocprofv3 kernel stats (same command as the bench headline)"
   rm -rf gpurun_out/prof
-  (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o fgt -- python "$R/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --no-prof --no-fp32-exact > "$R/gpurun_out/rocprof.log" 2>&1)
+  (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o fgt -- python "$R/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --no-prof --no-fp32-exact --no-f16 > "$R/gpurun_out/rocprof.log" 2>&1)
   echo "rocprof exit: $?"
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" gpurun_out/kernel_stats.csv && cut -c1-170 "$f" | head -22
+  echo "== rocprofv3 kernel stats, f16 mode"
+  rm -rf gpurun_out/prof_f16
+  (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_f16" -o fgt -- python "$R/bench.py" --precision f16 --steps 2 --warmup 0 --no-cpu-baseline --no-prof --no-fp32-exact > "$R/gpurun_out/rocprof_f16.log" 2>&1)
+  echo "rocprof f16 exit: $?"
+  f=$(find gpurun_out/prof_f16 -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" gpurun_out/kernel_stats_f16.csv && cut -c1-170 "$f" | head -12
 fi
 if has attn; then
   echo "== attention kernels (algorithmic TFLOP/s; fp32 peak 157.3, bf16x3 issues 3x)"
@@ -64,7 +71,15 @@ fi
 if has c5; then
   echo "== BASELINE config #5 clip on one GPU (864x480x160)"
   timeout 900 python bench.py --frames 160 --height 480 --width 864 --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-exact > gpurun_out/bench_c5_1gpu.log 2>&1
-  grep '^{' gpurun_out/bench_c5_1gpu.log | cut -c1-1800
+  grep '^{' gpurun_out/bench_c5_1gpu.log | python -c "
+import sys,json; d=json.loads(sys.stdin.read())
+print(d['value'],'fps', d['ms_per_step'],'ms')
+for r in d.get('rooflines',[]): print('  ', r['kind'], r['frac'], r['algorithmic_tflops'],'TF alg', r['kernel_ms_per_step'],'ms/step')
+f=d.get('f16')
+if f:
+    print('f16', f['value'],'fps', f['ms_per_step'],'ms', f.get('composite_vs_headline'))
+    for r in f.get('rooflines',[]): print('  ', r['kind'], r['frac'], r['algorithmic_tflops'],'TF alg', r['kernel_ms_per_step'],'ms/step')
+"
 fi
 if has flow; then
   echo "== flow bench (LAFC / RAFT / config-5 window)"
