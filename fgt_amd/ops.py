@@ -27,7 +27,9 @@ AUTOTUNE = os.environ.get("FGT_AUTOTUNE", "1") != "0"
 TILE_CANDIDATES = ("128x128", "64x64", "128x64", "256x128", "128x32", "128x128x8", "256x128x16", "256x64x8",
                    # split inputs only (rejected, hence skipped, for fp32 inputs): the same tiles with early stage release
                    "128x128ea", "64x64ea", "128x64ea", "128x128x8ea", "256x128x16ea", "256x64x8ea",
-                   "256x128ea")     # fp16 kernel only (csrc/conv_f16.hip)
+                   # fp16 kernel only (csrc/conv_f16.hip): one more early-release tile, and every tile on the wide LDS image
+                   "256x128ea", "128x128w", "64x64w", "128x64w", "256x128w", "128x32w", "128x128x8w", "256x128x16w", "256x64x8w",
+                   "128x128eaw", "64x64eaw", "128x64eaw", "128x128x8eaw", "256x128x16eaw", "256x64x8eaw", "256x128eaw")
 _tile_cache = {}
 
 

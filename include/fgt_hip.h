@@ -151,9 +151,10 @@ typedef struct fgt_conv_desc {
 #define FGT_TILE_128x128x8_LW 32  /* split inputs only: early-release tiles with two LOADER wavefronts per workgroup (one owns the A tile, one the  */
 #define FGT_TILE_128x128_LW 33    /* B tile: address arithmetic + LDS-DMA issue only) next to the 8 / 4 consumer wavefronts (fragment reads + MFMAs): */
 #define FGT_TILE_128x64_LW 34     /* the DMA issue no longer sits in front of the MFMAs of the same wavefront.  Bit-identical results; measured slower. */
-#define FGT_TILE_256x256x16 36   /* FGT_PREC_F16 only: 256x256 on 16 wavefronts of 64x64, one workgroup per CU (128 KB of LDS stages) */
-#define FGT_TILE_256x256x16_EA 37
 #define FGT_TILE_256x128_EA 38   /* FGT_PREC_F16 only: 256x128 on 8 wavefronts of 64x64 with early stage release */
+#define FGT_TILE_F16_WIDE 100    /* FGT_PREC_F16 only: tile code + 100 = the same tile on the "wide" LDS image (a stage row is the pixel's whole
+                                  * 128-byte line of the 64-channel K-step; an LDS-DMA instruction copies 8 full cache lines instead of 16 half
+                                  * lines).  Codes 1-8, 26-31 and 38.  Bit-identical results. */
 #define FGT_TILE_256x256_P8N 19   /* 17 without s_setprio (A/B measurements) */
 #define FGT_TILE_256x256_P8L 20   /* 17 with both wavefront groups in lock step (A/B measurements) */
 

@@ -26,6 +26,7 @@ torch.set_grad_enabled(False)
 ABS_TOL = 1e-3          # north-star bar
 F16_TILES = ["128x128", "128x64", "64x64", "128x32", "256x128", "128x128x8", "256x128x16", "256x64x8",
              "128x128ea", "128x64ea", "64x64ea", "256x128ea", "128x128x8ea", "256x128x16ea", "256x64x8ea"]
+F16_TILES += [t + "w" for t in F16_TILES]      # the same tiles on the wide LDS image (128-byte rows, full-line LDS-DMA pieces)
 
 
 def _rand(*shape, seed=0, scale=1.0):
