@@ -93,7 +93,9 @@ int launch_direct(const ConvP& p, int lpp_log2, hipStream_t s) {
 // Input bytes are read from HBM/L2 once per tile (halo overhead 1.33x) instead of 9x.
 constexpr int TH = 8, TW = 32, CCH = 16, PLD = CCH + 4;
 
-template <int COUT>
+// XH: the input map is an fp16 tensor (fgt_conv_desc.in_split = 3: ld / off in fp16 elements) — the f16 mode hands the decoder's last
+// feature map (64 channels at full resolution: the largest activation of the path) over at 2 B per value; weights and arithmetic stay fp32.
+template <int COUT, bool XH>
 __global__ void __launch_bounds__(256) conv3x3_tiled_kernel(const ConvP p) {
     __shared__ __attribute__((aligned(16))) float tile[(TH + 2) * (TW + 2) * PLD];
     const fgt_conv_desc& d = p.d;
@@ -114,7 +116,14 @@ __global__ void __launch_bounds__(256) conv3x3_tiled_kernel(const ConvP p) {
                 const int ci = c0 + c4 * 4;
                 const float* src; int ld, ch;
                 if (ci < p.Cg0) { src = p.x0; ld = d.ld0; ch = d.off0 + ci; } else { src = p.x1; ld = d.ld1; ch = d.off1 + ci - p.Cg0; }
-                v = *reinterpret_cast<const float4*>(src + ((long)(n_img * d.H + gy) * d.W + gx) * ld + ch);
+                const long off = ((long)(n_img * d.H + gy) * d.W + gx) * ld + ch;
+                if constexpr (XH) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    const h4 hv = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(src) + off);
+                    v = make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
+                } else {
+                    v = *reinterpret_cast<const float4*>(src + off);
+                }
                 if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             }
             *reinterpret_cast<float4*>(tile + pix * PLD + c4 * 4) = v;
@@ -153,7 +162,8 @@ __global__ void __launch_bounds__(256) conv3x3_tiled_kernel(const ConvP p) {
 template <int COUT>
 int launch_tiled(const ConvP& p, hipStream_t s) {
     dim3 grid(cdiv(p.d.W, TW), cdiv(p.d.H, TH), p.d.N);
-    hipLaunchKernelGGL((conv3x3_tiled_kernel<COUT>), grid, dim3(256), 0, s, p);
+    if (p.d.in_split == 3) hipLaunchKernelGGL((conv3x3_tiled_kernel<COUT, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_tiled_kernel<COUT, false>), grid, dim3(256), 0, s, p);
     return fgt_check_launch("conv3x3_tiled");
 }
 
@@ -167,6 +177,7 @@ bool tiled_eligible(const ConvP& p) {
 
 bool fgt_conv_direct_eligible(const ConvP& p) {
     const int taps = p.d.kh * p.d.kw;
+    if (p.d.in_split == 3) return p.d.groups == 1 && p.Cout_g <= 4 && tiled_eligible(p);      // fp16 inputs: the LDS-tiled 3x3 kernel only
     return p.d.groups == 1 && p.Cout_g <= 4 && (taps == 9 || taps == 1) && p.Cg <= 256 && p.Cg >= 4;
 }
 

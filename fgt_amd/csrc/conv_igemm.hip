@@ -346,7 +346,7 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
         FGT_REQUIRE(d.in_split == 3 || d.precision == FGT_PREC_BF16X3, "fgt_conv2d: split inputs need FGT_PREC_BF16X3");
         FGT_REQUIRE(d.in_relu == 0, "fgt_conv2d: in_relu cannot be applied to split inputs (the producer applies it)");
         FGT_REQUIRE(d.in_split >= 2 || (d.ps0 % 8 == 0 && d.ps0 > 0 && (d.C1 == 0 || (d.ps1 % 8 == 0 && d.ps1 > 0))), "fgt_conv2d: plane strides must be positive multiples of 8");
-        FGT_REQUIRE(d.in_split != 3 || (d.w_il == 0 && d.Kpad % 64 == 0), "fgt_conv2d: FGT_PREC_F16 takes the plain fp16 weight image with Kpad %% 64 == 0");
+        FGT_REQUIRE(d.in_split != 3 || (d.w_il == 0 && (d.Kpad % 64 == 0 || (p.Cout_g <= 4 && d.tile == 0))), "fgt_conv2d: FGT_PREC_F16 takes the plain fp16 weight image with Kpad %% 64 == 0");
     }
     FGT_REQUIRE(d.out_split >= 0 && d.out_split <= 2, "fgt_conv2d: out_split must be 0, 1 or 2");
     FGT_REQUIRE(d.out_split == 1 || out != nullptr, "fgt_conv2d: null output");
@@ -395,7 +395,10 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    const bool direct = d.tile == 0 && d.precision == 0 && d.out_split == 0 && fgt_conv_direct_eligible(p);
+    // Cout <= 4: fp32 VALU kernels (conv_direct.hip).  With fp16 inputs (in_split = 3) only the LDS-tiled 3x3 kernel exists; w_packed is then
+    // the fp32 weight image (arithmetic and weights stay fp32: what is fp16 is the feature map in HBM)
+    const bool direct = d.tile == 0 && d.out_split == 0 && (d.precision == 0 || (d.in_split == 3 && p.Cout_g <= 4)) && fgt_conv_direct_eligible(p);
+    FGT_REQUIRE(!(d.in_split == 3 && p.Cout_g <= 4 && d.tile == 0) || direct, "fgt_conv2d: fp16 inputs with Cout/groups <= 4 need the 3x3 / stride 1 / pad 1 geometry of the LDS-tiled kernel and fp32 output");
     // roofline accounting is about the MFMA kernels only; algorithmic flops use the UNPADDED K (flow 2 -> 4, RGB 3 -> 4 channel
     // padding is not work the reference does): desc.k_alg = kh*kw*Cin_real/groups, 0 = the padded K
     // unique-byte floor: input map(s) once (4 B per value, fp32 or hi + lo), weights once, every output form once, aux operands once

@@ -513,7 +513,10 @@ class FGT(nn.Module):
         D = P["dec"]
         y = self._block(feat, D[0], stride=1, pad=1, upsample=True, out_split=sc)
         y = self._block(y, D[1], stride=1, pad=1, out_split=sc)
-        y = self._block(y, D[2], stride=1, pad=1, upsample=True)              # fp32: the Cout = 3 kernel below gathers fp32
+        # the Cout = 3 kernel below gathers fp32 — or, in the f16 mode, the fp16 map (64 channels at full resolution: the largest activation
+        # of the path, 2.3 GB per clip pass as fp32); its LDS-tiled form needs an 8 x 32 output tile
+        h_last = self._f16() and 4 * Hf >= 8 and 4 * Wf >= 32 and D[3][0].Cg % 16 == 0 and D[3][0].Cout <= 4
+        y = self._block(y, D[2], stride=1, pad=1, upsample=True, out_split="only" if h_last else None)
         if D[3][1] is None:
             return ops.conv2d(y, D[3][0], stride=1, pad=1, act="tanh", out_nchw=True)   # final conv + torch.tanh
         y = self._block(y, D[3], act=None, stride=1, pad=1)

@@ -321,8 +321,8 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
         s4, sN, sH, sW, sC, ldo_s = _as_map(out_s.hi)
         assert (sN * sH * sW, sC) == (N * Ho * Wo, pc.Cout * (2 if out_s.il else 1)), f"conv2d: out_s shape {tuple(out_s.shape)}"
         d.ldo_s, d.ooff_s, d.pso = ldo_s, 0, out_s.ps
-    if d.precision == 0:
-        wbuf = pc.w
+    if d.precision == 0 or (in_split and xs.h and pc.Cout // pc.groups <= 4 and d.tile == 0):
+        wbuf = pc.w                          # (fp16 map into a Cout <= 4 layer: fp32 weights and arithmetic, csrc/conv_direct.hip)
     elif d.precision == PREC["f16"]:
         wbuf = _f16_weights(pc)
         d.Kpad = wbuf.shape[-1]

@@ -105,7 +105,9 @@ typedef struct fgt_conv_desc {
                              *    (>= 2*C), off* = LOGICAL first channel; needs Cin/groups and off % 32 == 0; ps* unused.
                              * 3: (FGT_PREC_F16) x0/x1 point to fp16 tensors = f16_rne(x), ONE plane with the layout of the fp32 tensor
                              *    (half the bytes); ld/off in fp16 elements, Cin/groups, ld, off % 8 == 0, in_relu == 0; ps* unused.
-                             *    Written by the same producers as the split format when their plane stride argument is -1.        */
+                             *    Written by the same producers as the split format when their plane stride argument is -1.
+                             *    Cout/groups <= 4 with tile = 0 (3x3 / stride 1 / pad 1 only): the fp32 VALU kernel reads the fp16 map;
+                             *    `w_packed` is then the fp32 image [groups][Npad][Kpad] and the arithmetic fp32.                     */
     int out_split;          /* 0: fp32 `out` only | 1: split `out_s` only | 2: both (needs Cout/groups, ldo_s, ooff_s % 4 == 0,
                              *    out_nchw == 0)                                                                         */
     int ldo_s, ooff_s;      /* row stride / first channel of out_s (bf16 elements; out_split with pso == 32 writes the

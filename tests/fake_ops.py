@@ -104,7 +104,8 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
         inp = F.pad(inp, (pw, pw, ph, ph), mode="replicate")
         ph = pw = 0
     wd = _dense_weight(pc)
-    y = F.conv2d(inp, f16_round(wd) if h16 else wd, None, stride, (ph, pw), dil, G)
+    # (Cout <= 4 layers read the fp16 map with fp32 weights and arithmetic: csrc/conv_direct.hip)
+    y = F.conv2d(inp, f16_round(wd) if (h16 and pc.Cout // G > 4) else wd, None, stride, (ph, pw), dil, G)
     if pc.scale is not None:
         y = y * pc.scale.view(1, -1, 1, 1)
     if pc.bias is not None:

@@ -168,6 +168,28 @@ def test_conv_f16_slices_and_out_formats(dev, f16_mode):
     assert torch.equal(a, bsp)
 
 
+@pytest.mark.parametrize("Cin,Cout,act,epi,nchw_out", [(64, 3, "tanh", None, True), (64, 3, None, "mul", False), (32, 2, "sigmoid", None, False)])
+def test_conv3x3_small_cout_reads_f16_map(Cin, Cout, act, epi, nchw_out, dev):
+    """Cout <= 4 (FGT decoder.final 64 -> 3): the LDS-tiled fp32 VALU kernel reading an fp16 feature map; fp32 weights and arithmetic."""
+    from fgt_amd import ops
+    N, H, W = 2, 37, 70
+    x = _rand(N, H, W, Cin, seed=1)
+    w, b = _rand(Cout, Cin, 3, 3, seed=2, scale=0.05), _rand(Cout, seed=3)
+    aux = _rand(N, H, W, Cout, seed=4)
+    pc = ops.PackedConv(w.to(dev), b.to(dev))
+    got = ops.conv2d(ops.split(x.to(dev), h=True), pc, pad=1, act=act, epi=epi, aux1=aux.to(dev) if epi else None, out_nchw=nchw_out)
+    y = F.conv2d(r16(x).double().permute(0, 3, 1, 2), w.double(), b.double(), 1, 1)
+    y = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, None: lambda v: v}[act](y)
+    if epi == "mul":
+        y = y * aux.double().permute(0, 3, 1, 2)
+    ref = (y if nchw_out else y.permute(0, 2, 3, 1)).float()
+    assert tuple(got.shape) == tuple(ref.shape)
+    assert (got.cpu() - ref).abs().max().item() < 1e-5 * max(ref.abs().max().item(), 1.0)
+    # geometries the tiled kernel does not serve are rejected, not silently computed otherwise
+    with pytest.raises(RuntimeError):
+        ops.conv2d(ops.split(x.to(dev), h=True), pc, pad=1, stride=2)
+
+
 def test_f16_rejections(dev):
     """fp16 tensors feed the fp16 kernel only; formats cannot be mixed."""
     from fgt_amd import ops
