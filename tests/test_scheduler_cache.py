@@ -45,6 +45,24 @@ def test_cached_equals_uncached_equals_oracle(monkeypatch):
         fgt_model.ops, fgt_model.PackedConv = real_ops, real_pc
 
 
+def test_f16_mode_clip_over_its_cpu_model(monkeypatch):
+    """The 'f16' arithmetic mode through the whole clip scheduler (cache, batched windows, pruned last pair) over its CPU model
+    (fake_ops rounds every Split and the weights of the GEMMs that consume one to fp16): the composite stays within one uint8 step of
+    the oracle clip with a flip rate that matches an error of ~1e-4 * 127.5 steps (tests/test_f16_gpu.py holds the kernels to the same)."""
+    real_ops, real_pc = fgt_model.ops, fgt_model.PackedConv
+    try:
+        m, sd, fr, fl, ms = _setup()
+        monkeypatch.setattr(fake_ops, "DEFAULT_CONV_PRECISION", "f16")
+        got = ClipRunner(m, fr, fl, ms, cache_features=True, encode_chunk=5, window_batch=4).run()
+        ref = O.fgt_clip(sd, DEFAULT_CONFIG, fr, fl, ms)
+        d = (got - ref).abs()
+        rate = (d > 0).float().mean().item()
+        print(f"[parity] f16 mode (CPU model) clip {N}x{H}x{W}: max {d.max().item()} uint8 steps, differing values {rate:.3e}")
+        assert d.max().item() <= 1.0 and 0 < rate < 2e-2
+    finally:
+        fgt_model.ops, fgt_model.PackedConv = real_ops, real_pc
+
+
 def test_last_pair_pruning_is_exact():
     """The last temporal + spatial block computed only for the frames the tool consumes (transform_decode tq / keep_q) == all frames."""
     real_ops, real_pc = fgt_model.ops, fgt_model.PackedConv
