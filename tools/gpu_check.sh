@@ -2,7 +2,7 @@
 # One GPU-box visit: parity tests, smoke, bench (headline + fp32_exact + cpu baseline in one line), PMC traffic of the MFMA
 # kernels with pre-seeded tiles, rocprofv3 kernel stats, attention micro-benchmarks, 2-rank rehearsal.  Everything lands in
 # gpurun_out/.   usage (from the repo root on the GPU box):  bash tools/gpu_check.sh [stages]
-#   stages: any of  test smoke bench pmc stats attn rehearse c5 flow   (default: test smoke bench pmc stats attn rehearse)
+#   stages: any of  test smoke bench pmc pmc16 stats attn rehearse c5 flow   (default: test smoke bench pmc stats attn rehearse)
 set -u
 STAGES="${*:-test smoke bench pmc stats attn rehearse}"
 has() { [[ " $STAGES " == *" $1 "* ]]; }
@@ -43,6 +43,14 @@ if has pmc; then
     echo "pmc $c exit $?"
   done
   python tools/pmc_traffic.py gpurun_out/pmcb_FETCH_SIZE gpurun_out/pmcb_WRITE_SIZE bf16x3 gpurun_out/kernel_traffic.json
+fi
+if has pmc16; then
+  echo "== PMC HBM traffic of the MFMA kernels, f16 mode (needs gpurun_out/tuning.json from the bench stage of this visit)"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmcf_$c" -o pmc -- python "$R/bench.py" --precision f16 --steps 1 --warmup 0 --no-cpu-baseline --no-prof --no-fp32-exact > "$R/gpurun_out/pmcf_$c.log" 2>&1)
+    echo "pmc f16 $c exit $?"
+  done
+  python tools/pmc_traffic.py gpurun_out/pmcf_FETCH_SIZE gpurun_out/pmcf_WRITE_SIZE f16 gpurun_out/kernel_traffic.json "bench.py --precision f16 --steps 1 --warmup 0 --no-prof --no-cpu-baseline --no-fp32-exact (prepare pass + 1 step, tiles pre-seeded)"
 fi
 if has stats; then
   echo "== rocprofv3 kernel stats (same command as the bench headline)"
