@@ -350,6 +350,18 @@ def test_fgt_forward_f16_trained_grid_240x432(dev, f16_mode):
     assert e < ABS_TOL / 3 and r < 5e-3
 
 
+@pytest.mark.parametrize("H,W,t", [(256, 432, 2), (480, 864, 2)])
+def test_fgt_inference_grids_f16(H, W, t, dev, f16_mode):
+    """The tool's default 256x432 (22x36 tokens: spatial padding to 24x40, compact maps) and BASELINE config #5's 864x480 (40x72 tokens,
+    45 windows, 180 global tokens per frame) in the f16 mode vs the CPU oracle."""
+    m, sd = _model(dev)
+    mf, fl, ms = fgt_inputs(H, W, t, 31)
+    ref = O.fgt_forward(sd, DEFAULT_CONFIG, mf, fl, ms)
+    out = m(mf.to(dev), fl.to(dev), ms.to(dev))
+    e, r = report(f"fgt {W}x{H}x{t} f16", out, ref)
+    assert e < ABS_TOL / 3 and r < 5e-3
+
+
 def test_config2_spatial_block_t10_f16(dev, f16_mode):
     """BASELINE config #2 (one SpatialTransformer, t = 10, N(0,1) tokens) in the f16 mode.  Plain bf16 operands give 2.3e-3 on the
     block and 4.5e-4 on the attention branch here: fp16's three extra bits must bring both under the 1e-3 bar."""
