@@ -23,6 +23,7 @@
 // epilogue with pso = -1), P is rounded to fp16 in registers, every product is ONE v_mfma_f32_32x32x16_f16.  Same tiles, swizzles,
 // transposing V reads and softmax; a stage is [K | V] (half the LDS-DMA pieces and LDS reads, a third of the MFMAs).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -99,7 +100,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* lds_lo_run, const char* ld
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int NW, bool H>
+template <int NW, bool H, bool TEMPORAL>
 __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     constexpr int NT = NW * 64;
     constexpr int NPL = H ? 2 : 4;               // planes per stage
@@ -107,10 +108,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     constexpr int VOFF = (NPL / 2) * PLANE;      // first V plane
     constexpr int PPW = NPL * 8 / NW;            // DMA pieces (4 key rows of one plane) per wavefront and tile
     static_assert((NPL * 8) % NW == 0, "pieces per wavefront");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [2 stages][STAGE] tiles, then the row-address tables of the two stages: k / v hi-plane byte addresses of the 32 keys
-    unsigned long* ktab = reinterpret_cast<unsigned long*>(smem + 2 * STAGE);
-    unsigned long* vtab = ktab + 2 * KT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 stages][STAGE] tiles
 
     const fgt_attn_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -133,40 +131,83 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     }
     const int choff = pr.hd * HD;
 
-    // row addresses of tile `tile` into table slot `slot` (threads 0..31; keys past the end clamp to the last one and are masked later)
-    auto key_pointers = [&](int tile, int slot) {
-        if (tid < KT) {
-            const int key = min(tile * KT + tid, p.n_k - 1);
-            const __bf16 *kr, *vr;
-            if (key < p.n_loc) {
-                const long pix = attn_map_row(d, local_pix(p, pr, key));
-                kr = p.K + pix * d.ldk + d.koff + choff;
-                vr = p.V + pix * d.ldv + d.voff + choff;
-            } else {
-                const long gr = (long)pr.frame0 * d.n_global + (key - p.n_loc);
-                kr = p.KG + gr * d.ldg_k + choff;
-                vr = p.VG + gr * d.ldg_v + choff;
-            }
-            ktab[slot * KT + tid] = reinterpret_cast<unsigned long>(kr);
-            vtab[slot * KT + tid] = reinterpret_cast<unsigned long>(vr);
+    // ---- row addresses of the K / V tiles, per lane.  Piece i of this wavefront is plane i / NR of key row R_r = 4 * ((wave + r NW) & 7) + (lane >> 4),
+    // r = i % NR: a lane needs the addresses of NR = 8 / NW key rows per tile.  It keeps them itself and moves them 32 keys on per tile —
+    // for the temporal zones without a division: key = (tt * zh + ti) * zw + tj is carried as (tt, ti, tj).  (Round 1-2 kept a per-tile address
+    // table in LDS that wavefront 0 filled with two integer divisions per key: ~150 VALU instructions per tile that the other wavefronts
+    // issued as well, exec-masked — half of the loop's VALU work in the fp16 instance, which is VALU-bound — plus an LDS hand-over that
+    // needed its own wait.)  Keys past the end read the last key's row and are masked in the softmax.
+    constexpr int NR = 8 / NW;
+    static_assert(8 % NW == 0 && PPW % NR == 0, "key rows per lane");
+    const int rsub = lane >> 4, pc = lane & 15;
+    constexpr bool temporal = TEMPORAL;               // (a template parameter: the other mode's address arithmetic is compiled out of the loop)
+    auto row_ptrs = [&](int key, unsigned long& kr, unsigned long& vr, bool& glob) __attribute__((always_inline)) {          // any mode, with divisions
+        glob = key >= p.n_loc;
+        if (!glob) {
+            const long pix = attn_map_row(d, local_pix(p, pr, key));
+            kr = reinterpret_cast<unsigned long>(p.K + pix * d.ldk + d.koff + choff);
+            vr = reinterpret_cast<unsigned long>(p.V + pix * d.ldv + d.voff + choff);
+        } else {
+            const long gr = (long)pr.frame0 * d.n_global + (key - p.n_loc);
+            kr = reinterpret_cast<unsigned long>(p.KG + gr * d.ldg_k + choff);
+            vr = reinterpret_cast<unsigned long>(p.VG + gr * d.ldg_v + choff);
         }
     };
-    const bool glob_tile_possible = d.mode == 1;
-    // this wavefront's DMA pieces of a tile: piece q = wave + i * NW -> plane q / 8 (K hi, K lo, V hi, V lo), rows 4 (q % 8) .. + 3
-    auto issue_tile = [&](int tile, int slot) {
+    unsigned long k_last, v_last;
+    bool g_last;
+    row_ptrs(p.n_k - 1, k_last, v_last, g_last);
+    // temporal zones: pixel of key (tt, ti, tj) = pix0 + (tt * nh + ti) * nw + tj
+    const int pix0 = (pr.frame0 * d.nh + pr.zi * p.zh) * d.nw + pr.zj * p.zw;
+    const unsigned long kz = reinterpret_cast<unsigned long>(p.K + d.koff + choff), vz = reinterpret_cast<unsigned long>(p.V + d.voff + choff);
+    const long ldk2 = 2l * d.ldk, ldv2 = 2l * d.ldv;
+    int r_key[NR], r_tt[NR], r_ti[NR], r_tj[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        r_key[r] = ((wave + r * NW) & 7) * 4 + rsub;
+        r_tt[r] = r_ti[r] = r_tj[r] = 0;
+        if constexpr (temporal) {
+            const int zsz = p.zh * p.zw;
+            r_tt[r] = r_key[r] / zsz;
+            const int rem = r_key[r] - r_tt[r] * zsz;
+            r_ti[r] = rem / p.zw;
+            r_tj[r] = rem - r_ti[r] * p.zw;
+        }
+    }
+    // this wavefront's DMA pieces of the NEXT tile (the one its row state points at) into stage `slot`; then the rows move 32 keys on
+    auto issue_tile = [&](int slot) __attribute__((always_inline)) {
         char* st = smem + slot * STAGE;
-        const int rsub = lane >> 4, pc = lane & 15;
+        unsigned long rk[NR], rv[NR];
+        bool rg[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (r_key[r] >= p.n_k) {
+                rk[r] = k_last; rv[r] = v_last; rg[r] = g_last;
+            } else if constexpr (temporal) {
+                const long pix = pix0 + (r_tt[r] * d.nh + r_ti[r]) * d.nw + r_tj[r];
+                rk[r] = kz + pix * ldk2; rv[r] = vz + pix * ldv2; rg[r] = false;
+            } else {
+                row_ptrs(r_key[r], rk[r], rv[r], rg[r]);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            const int q = wave + i * NW, plane = q >> 3, grp = q & 7;
+            const int r = i % NR, plane = i / NR;
+            const int grp = (wave + r * NW) & 7;                         // = (wave + i * NW) & 7
             const int R = grp * 4 + rsub;
             const bool isv = plane >= NPL / 2, islo = !H && (plane & 1);
-            const unsigned long base = (isv ? vtab : ktab)[slot * KT + R];
             const int c = isv ? ((((pc >> 1) ^ ((R & 3) << 1)) << 1) | (pc & 1)) : (pc ^ (R & 15));       // logical 16-byte chunk this lane fetches
-            long ps = isv ? p.psv : p.psk;
-            if (glob_tile_possible && min(tile * KT + R, p.n_k - 1) >= p.n_loc) ps = isv ? p.psgv : p.psgk;   // global tokens live in their own tensors
-            const unsigned long src = base + (unsigned long)c * 16 + (islo ? (unsigned long)ps * 2 : 0ul);
+            const long ps = rg[r] ? (isv ? p.psgv : p.psgk) : (isv ? p.psv : p.psk);                        // global tokens live in their own tensors
+            const unsigned long src = (isv ? rv[r] : rk[r]) + (unsigned long)c * 16 + (islo ? (unsigned long)ps * 2 : 0ul);
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(st + plane * PLANE + grp * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            r_key[r] += KT;
+            if constexpr (temporal) {
+                r_tj[r] += KT;
+                while (r_tj[r] >= p.zw) { r_tj[r] -= p.zw; ++r_ti[r]; }
+                while (r_ti[r] >= p.zh) { r_ti[r] -= p.zh; ++r_tt[r]; }
+            }
         }
     };
 
@@ -191,9 +232,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (p.n_k + KT - 1) / KT;
-    key_pointers(0, 0);
-    __syncthreads();
-    issue_tile(0, 0);
+    issue_tile(0);
 
     // per-lane LDS offsets of the operand reads (stage-relative)
     const int krow = l31 * 256;                                             // K: row l31, chunk (2 st + lh) ^ (l31 & 15)
@@ -201,16 +240,14 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     const int gi = lane >> 4, j16 = lane & 15;
     const int vrow_in = j16 >> 2, vword = j16 & 3;
 
-    for (int it = 0; it < ntiles; ++it) {
+    // one key tile; MASKED = the last, partial tile (keys past n_k get -inf scores): peeled out of the loop so that the full tiles carry no
+    // compare / select per score
+    auto tile_step = [&](const int it, auto masked_tag) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const int slot = it & 1;
-        if (it + 1 < ntiles) key_pointers(it + 1, slot ^ 1);
-        // this wavefront's pieces of tile `it` have landed, and (wavefront 0) its table writes above are COMPLETE: a ds_write that is merely
-        // issued when its wavefront reaches the barrier can still be overtaken by another SIMD's table read behind the barrier — the
-        // fp16 variant (shorter tiles) read a stale / unwritten row address under load (memory fault at address 0 in the spatial call
-        // of a batched window group), the bf16x3 variant had the same hazard without ever showing it
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                       // ... everyone's have; tile it-1 is fully consumed; table slot^1 is visible
-        if (it + 1 < ntiles) issue_tile(it + 1, slot ^ 1);                  // streams under the MFMAs below
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wavefront's pieces of tile `it` have landed
+        __builtin_amdgcn_s_barrier();                                       // ... everyone's have, and tile it-1 is fully consumed
+        if (it + 1 < ntiles) issue_tile(slot ^ 1);                          // tile it+1 streams under the MFMAs below
         const char* st = smem + slot * STAGE;
         const int k0 = it * KT;
 
@@ -231,26 +268,33 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, qh[sx], s, 0, 0, 0);
             }
         }
-        // ---- online softmax in base 2 (scale applied to the fp32 scores), keys of this lane: k0 + (e&3) + 8*(e>>2) + 4*lh
-        float mx = -INFINITY;
+        // ---- online softmax in base 2 on the RAW scores (the scale c = log2(e) / sqrt(d) > 0 commutes with the maximum and is folded into the
+        // exponent: p = exp2(s c - m c), one FMA per score); keys of this lane: k0 + (e&3) + 8*(e>>2) + 4*lh, masked in the last tile only
+        if constexpr (MASKED) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            const float v = key < p.n_k ? s[e] * p.scale_log2e : -INFINITY;
-            s[e] = v;
-            mx = fmaxf(mx, v);
+            for (int e = 0; e < 16; ++e)
+                if (k0 + (e & 3) + 8 * (e >> 2) + 4 * lh >= p.n_k) s[e] = -INFINITY;
         }
+        float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+        for (int e = 2; e < 16; e += 2) mx = fmaxf(mx, fmaxf(s[e], s[e + 1]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float psum = 0.f;
+        const float mc = m_new * p.scale_log2e;
+        const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, p.scale_log2e, -mc));
+        // exponents and row sum two scores at a time (v_pk_fma_f32 / v_pk_add_f32)
+        const f32x2 c2 = {p.scale_log2e, p.scale_log2e}, mc2 = {mc, mc};
+        f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float pe = __builtin_amdgcn_exp2f(s[e] - m_new);
-            s[e] = pe;
-            psum += pe;
+        for (int e = 0; e < 16; e += 2) {
+            const f32x2 sv = {s[e], s[e + 1]};
+            const f32x2 x = __builtin_elementwise_fma(sv, c2, -mc2);
+            const f32x2 pe = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+            s[e] = pe[0];
+            s[e + 1] = pe[1];
+            ps2 += pe;
         }
-        l_run = l_run * alpha + psum;
+        l_run = l_run * alpha + (ps2[0] + ps2[1]);
         m_run = m_new;
         // the running maximum settles after a few tiles: when NO query of this wavefront saw a new one, alpha is exactly 1 for all of
         // them and the 64 multiplies are skipped (bit-identical: x * 1.0f == x)
@@ -289,7 +333,10 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
                 }
             }
         }
-    }
+    };
+    const int nfull = p.n_k / KT;                                           // tiles whose 32 keys all exist
+    for (int it = 0; it < nfull; ++it) tile_step(it, std::false_type{});
+    if (nfull < ntiles) tile_step(nfull, std::true_type{});
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / l_tot;
@@ -328,14 +375,19 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     }
 }
 
+template <int NW, bool H, bool TEMPORAL>
+int launch_mode(const AttnS& p, int problems, hipStream_t s) {
+    constexpr int smem = 2 * (H ? 2 : 4) * PLANE;
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<NW, H, TEMPORAL>), smem, lds_set, "attn_split")) return rc;
+    dim3 grid(cdiv(p.n_q, NW * 32), problems);
+    hipLaunchKernelGGL((attn_split_kernel<NW, H, TEMPORAL>), grid, dim3(NW * 64), smem, s, p);
+    return fgt_check_launch("attn_split_kernel");
+}
+
 template <int NW, bool H>
 int launch(const AttnS& p, int problems, hipStream_t s) {
-    constexpr int smem = 2 * (H ? 2 : 4) * PLANE + 4 * KT * (int)sizeof(unsigned long);
-    static std::atomic<unsigned long long> lds_set{0};
-    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<NW, H>), smem, lds_set, "attn_split")) return rc;
-    dim3 grid(cdiv(p.n_q, NW * 32), problems);
-    hipLaunchKernelGGL((attn_split_kernel<NW, H>), grid, dim3(NW * 64), smem, s, p);
-    return fgt_check_launch("attn_split_kernel");
+    return p.d.mode == 0 ? launch_mode<NW, H, true>(p, problems, s) : launch_mode<NW, H, false>(p, problems, s);
 }
 
 }  // namespace
