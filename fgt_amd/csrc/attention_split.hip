@@ -92,17 +92,32 @@ __device__ __forceinline__ bf16x8 as_bf16x8(unsigned a, unsigned b, unsigned c, 
 }
 
 struct S8 { s16x4 a, b; };
+// Two transposing reads: keys run 0 (j = 0..3) and run 1 (j = 4..7) of this lane's d.  Issued as INLINE ASSEMBLY on purpose: behind the
+// __builtin_amdgcn_ds_read_tr16_b64 intrinsic the compiler cannot tell that the read does not alias the LDS-DMA copies in flight and puts an
+// `s_waitcnt vmcnt(0)` in front of it — in the middle of every tile, so the K / V tile requested at the top of the tile had to land before its
+// PV product: the loop ran at one global -> LDS round trip per tile whatever the rest of it did (rounds 1-2; found in the ISA after halving
+// the VALU work, batching the LDS reads and changing the occupancy had all left the kernel's time unchanged).  The reads return through
+// lgkmcnt, which the compiler does not track for inline assembly: tr_wait() is the matching wait and ties the registers it covers.
 __device__ __forceinline__ bf16x8 tr_pair(const char* lds_lo_run, const char* lds_hi_run) {
-    // two transposing reads: keys run 0 (j = 0..3) and run 1 (j = 4..7) of this lane's d
     S8 r;
-    r.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_lo_run);
-    r.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_hi_run);
+    const unsigned a0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)lds_lo_run;
+    const unsigned a1 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)lds_hi_run;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r.a) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r.b) : "v"(a1));
     return __builtin_bit_cast(bf16x8, r);
 }
+__device__ __forceinline__ void tr_wait(bf16x8& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
+__device__ __forceinline__ void tr_wait(bf16x8& a, bf16x8& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void tr_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 
-template <int NW, bool H, bool TEMPORAL>
+// NS: depth of the LDS stage ring.  A K / V tile is requested NS - 1 tiles before it is used.  The 8-wavefront instances (long temporal
+// zones) run ONE workgroup per CU (164-228 registers per lane), so a tile of the double-buffered loop took exactly one global -> LDS round
+// trip (~1 us under load: the loop was latency-bound — halving its VALU instructions, batching its LDS reads and the 4-wavefront instance at
+// three workgroups per CU all left its time unchanged); with the LDS of the whole CU to themselves they keep NS - 1 = 3 tiles in flight.
+template <int NW, bool H, bool TEMPORAL, int NS>
 __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     constexpr int NT = NW * 64;
+    static_assert(NS >= 2 && NS <= 4, "stage ring depth");
     constexpr int NPL = H ? 2 : 4;               // planes per stage
     constexpr int STAGE = NPL * PLANE;           // (shadows the namespace constant: this instance's stage)
     constexpr int VOFF = (NPL / 2) * PLANE;      // first V plane
@@ -232,7 +247,9 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (p.n_k + KT - 1) / KT;
-    issue_tile(0);
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < ntiles) issue_tile(t);
 
     // per-lane LDS offsets of the operand reads (stage-relative)
     const int krow = l31 * 256;                                             // K: row l31, chunk (2 st + lh) ^ (l31 & 15)
@@ -244,10 +261,16 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     // compare / select per score
     auto tile_step = [&](const int it, auto masked_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        const int slot = it & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wavefront's pieces of tile `it` have landed
+        const int slot = it % NS;
+        // this wavefront's pieces of tile `it` have landed; the (up to NS - 2) younger tiles stay in flight across the barrier
+        {
+            const int ahead = min(NS - 2, ntiles - 1 - it);
+            if (NS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            else if (NS >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();                                       // ... everyone's have, and tile it-1 is fully consumed
-        if (it + 1 < ntiles) issue_tile(slot ^ 1);                          // tile it+1 streams under the MFMAs below
+        if (it + NS - 1 < ntiles) issue_tile((it + NS - 1) % NS);          // its stage held tile it-1; streams under the MFMAs of NS - 1 tiles
         const char* st = smem + slot * STAGE;
         const int k0 = it * KT;
 
@@ -255,8 +278,21 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
         f32x16 s;
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        if constexpr (H) {
+            // all eight K fragments in flight before the first MFMA (one LDS round trip instead of eight: the per-tile chain of a
+            // wavefront is latency-bound, not issue-bound — halving its VALU instructions did not move the kernel)
+            bf16x8 kf[8];
 #pragma unroll
-        for (int sx = 0; sx < 8; ++sx) {
+            for (int sx = 0; sx < 8; ++sx) kf[sx] = *reinterpret_cast<const bf16x8*>(st + krow + (((2 * sx + lh) ^ (l31 & 15)) << 4));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sx = 0; sx < 8; ++sx)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf[sx]), __builtin_bit_cast(f16x8, qh[sx]), s, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int sx = 0; sx < (H ? 0 : 8); ++sx) {
             const int off = krow + (((2 * sx + lh) ^ (l31 & 15)) << 4);
             const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(st + off);
             if constexpr (H) {
@@ -316,17 +352,34 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
                 split2(s[8 * ks + 4], s[8 * ks + 5], h2, l2); split2(s[8 * ks + 6], s[8 * ks + 7], h3, l3);
             }
             const bf16x8 p_h = as_bf16x8(h0, h1, h2, h3), p_l = as_bf16x8(l0, l1, l2, l3);
+            if constexpr (H) {
+                bf16x8 vf[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < 4; ++t) {
+                    const int seg = (t * 2 + (gi & 1)) ^ (vrow_in << 1);
+                    const int r0 = 16 * ks + 4 * (gi >> 1) + vrow_in;
+                    const int a0 = r0 * 256 + seg * 32 + vword * 8, a1 = a0 + 8 * 256;
+                    vf[t] = tr_pair(st + VOFF + a0, st + VOFF + a1);
+                }
+                tr_wait(vf[0], vf[1], vf[2], vf[3]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vf[t]), __builtin_bit_cast(f16x8, p_h), o[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < (H ? 0 : 4); ++t) {
                 // run 0: keys 16ks + 4lh + (0..3); run 1: + 8.  row & 3 = vrow_in for both (16ks, 4lh, 8 are multiples of 4)
                 const int seg = (t * 2 + (gi & 1)) ^ (vrow_in << 1);        // swizzled 32-byte segment of d block t*32 + 16 (gi & 1)
                 const int r0 = 16 * ks + 4 * (gi >> 1) + vrow_in;
                 const int a0 = r0 * 256 + seg * 32 + vword * 8, a1 = a0 + 8 * 256;
-                const bf16x8 v_h = tr_pair(st + VOFF + a0, st + VOFF + a1);
+                bf16x8 v_h = tr_pair(st + VOFF + a0, st + VOFF + a1);
                 if constexpr (H) {
                     o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, v_h), __builtin_bit_cast(f16x8, p_h), o[t], 0, 0, 0);
                 } else {
-                    const bf16x8 v_l = tr_pair(st + VOFF + PLANE + a0, st + VOFF + PLANE + a1);
+                    bf16x8 v_l = tr_pair(st + VOFF + PLANE + a0, st + VOFF + PLANE + a1);
+                    tr_wait(v_h, v_l);
                     o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_l, p_h, o[t], 0, 0, 0);
                     o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h, p_l, o[t], 0, 0, 0);
                     o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h, p_h, o[t], 0, 0, 0);
@@ -377,11 +430,13 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
 
 template <int NW, bool H, bool TEMPORAL>
 int launch_mode(const AttnS& p, int problems, hipStream_t s) {
-    constexpr int smem = 2 * (H ? 2 : 4) * PLANE;
+    constexpr int NS = NW == 8 ? 4 : 2;          // long zones (one workgroup per CU): four stages = three tiles in flight
+    constexpr int smem = NS * (H ? 2 : 4) * PLANE;
+    static_assert(smem <= 160 * 1024, "LDS ring does not fit");
     static std::atomic<unsigned long long> lds_set{0};
-    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<NW, H, TEMPORAL>), smem, lds_set, "attn_split")) return rc;
+    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<NW, H, TEMPORAL, NS>), smem, lds_set, "attn_split")) return rc;
     dim3 grid(cdiv(p.n_q, NW * 32), problems);
-    hipLaunchKernelGGL((attn_split_kernel<NW, H, TEMPORAL>), grid, dim3(NW * 64), smem, s, p);
+    hipLaunchKernelGGL((attn_split_kernel<NW, H, TEMPORAL, NS>), grid, dim3(NW * 64), smem, s, p);
     return fgt_check_launch("attn_split_kernel");
 }
 
@@ -412,12 +467,16 @@ int fgt_attention_split(const fgt_attn_desc* dd, const void* Q, const void* K, c
     p.psq = d.psq; p.psk = d.psk; p.psv = d.psv; p.psgk = d.psg_k; p.psgv = d.psg_v;
     p.n_q = n_q; p.n_k = n_k; p.n_loc = n_loc; p.zh = zh; p.zw = zw; p.gh = gh; p.gw = gw;
     p.scale_log2e = scale_log2e;
+    // long zones: 8 wavefronts share each K / V tile (FGT_ATTN_SPLIT_NW=4: A/B switch — the 4-wavefront instance runs three workgroups per CU
+    // where the register count of the 8-wavefront one allows a single workgroup)
+    static const int nw_long = [] { const char* e = getenv("FGT_ATTN_SPLIT_NW"); return e ? atoi(e) : 8; }();
+    const bool big = n_q >= 2048 && nw_long == 8;
     if (h16) {
         if (n_q <= 64) return launch<2, true>(p, problems, s);
-        if (n_q >= 2048) return launch<8, true>(p, problems, s);
+        if (big) return launch<8, true>(p, problems, s);
         return launch<4, true>(p, problems, s);
     }
     if (n_q <= 64) return launch<2, false>(p, problems, s);
-    if (n_q >= 2048) return launch<8, false>(p, problems, s);
+    if (big) return launch<8, false>(p, problems, s);
     return launch<4, false>(p, problems, s);
 }
