@@ -47,7 +47,15 @@ struct AttnS {
     long psq, psk, psv, psgk, psgv;
     int n_q, n_k, zh, zw, gh, gw, n_loc;
     float scale_log2e;
+#ifdef FGT_ATTN_ABLATE
+    int dbg;   // diagnostic build only (tools/attn_ablate.py): timing-only ablations of the tile loop, results are WRONG
+#endif
 };
+#ifdef FGT_ATTN_ABLATE
+#define ABL(bit) (p.dbg & (bit))
+#else
+#define ABL(bit) 0
+#endif
 
 struct Prob { int frame0, zi, zj, hd; };
 
@@ -269,8 +277,8 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
             else if (NS >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();                                       // ... everyone's have, and tile it-1 is fully consumed
-        if (it + NS - 1 < ntiles) issue_tile((it + NS - 1) % NS);          // its stage held tile it-1; streams under the MFMAs of NS - 1 tiles
+        if (!ABL(16)) __builtin_amdgcn_s_barrier();                         // ... everyone's have, and tile it-1 is fully consumed
+        if (it + NS - 1 < ntiles && !ABL(8)) issue_tile((it + NS - 1) % NS);   // its stage held tile it-1; streams under the MFMAs of NS - 1 tiles
         const char* st = smem + slot * STAGE;
         const int k0 = it * KT;
 
@@ -278,7 +286,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
         f32x16 s;
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
-        if constexpr (H) {
+        if constexpr (H) if (!ABL(1)) {
             // all eight K fragments in flight before the first MFMA (one LDS round trip instead of eight: the per-tile chain of a
             // wavefront is latency-bound, not issue-bound — halving its VALU instructions did not move the kernel)
             bf16x8 kf[8];
@@ -292,7 +300,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int sx = 0; sx < (H ? 0 : 8); ++sx) {
+        for (int sx = 0; sx < ((H || ABL(1)) ? 0 : 8); ++sx) {
             const int off = krow + (((2 * sx + lh) ^ (l31 & 15)) << 4);
             const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(st + off);
             if constexpr (H) {
@@ -325,7 +333,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
         for (int e = 0; e < 16; e += 2) {
             const f32x2 sv = {s[e], s[e + 1]};
             const f32x2 x = __builtin_elementwise_fma(sv, c2, -mc2);
-            const f32x2 pe = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+            const f32x2 pe = ABL(2) ? x : f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
             s[e] = pe[0];
             s[e + 1] = pe[1];
             ps2 += pe;
@@ -342,7 +350,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
         }
         // ---- O^T += V^T . P^T
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < (ABL(4) ? 0 : 2); ++ks) {
             unsigned h0, h1, h2, h3, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
             if constexpr (H) {     // P in [0, 1]: f16_rne
                 h0 = half2(s[8 * ks + 0], s[8 * ks + 1]); h1 = half2(s[8 * ks + 2], s[8 * ks + 3]);
@@ -467,6 +475,9 @@ int fgt_attention_split(const fgt_attn_desc* dd, const void* Q, const void* K, c
     p.psq = d.psq; p.psk = d.psk; p.psv = d.psv; p.psgk = d.psg_k; p.psgv = d.psg_v;
     p.n_q = n_q; p.n_k = n_k; p.n_loc = n_loc; p.zh = zh; p.zw = zw; p.gh = gh; p.gw = gw;
     p.scale_log2e = scale_log2e;
+#ifdef FGT_ATTN_ABLATE
+    { const char* e = getenv("FGT_ATTN_ABLATE"); p.dbg = e ? atoi(e) : 0; }
+#endif
     // long zones: 8 wavefronts share each K / V tile (FGT_ATTN_SPLIT_NW=4: A/B switch — the 4-wavefront instance runs three workgroups per CU
     // where the register count of the 8-wavefront one allows a single workgroup)
     static const int nw_long = [] { const char* e = getenv("FGT_ATTN_SPLIT_NW"); return e ? atoi(e) : 8; }();
