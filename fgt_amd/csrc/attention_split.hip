@@ -122,10 +122,15 @@ __device__ __forceinline__ void tr_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8&
 // zones) run ONE workgroup per CU (164-228 registers per lane), so a tile of the double-buffered loop took exactly one global -> LDS round
 // trip (~1 us under load: the loop was latency-bound — halving its VALU instructions, batching its LDS reads and the 4-wavefront instance at
 // three workgroups per CU all left its time unchanged); with the LDS of the whole CU to themselves they keep NS - 1 = 3 tiles in flight.
-template <int NW, bool H, bool TEMPORAL, int NS>
+// PF (fp16, NS = 4 only; FGT_ATTN_PREFETCH=1 — BUILT IN ROUND 2 AFTER THE GPU BUDGET WAS SPENT, NOT YET RUN ON HARDWARE, off by default): operand
+// prefetch one phase ahead in registers, the lever the ablations point at (profiles/r02_run12_attn_ablate.txt: each matrix phase waits for its
+// own fragment reads).  The V fragments of a tile are requested before its softmax, the K fragments of tile i+1 under the PV MFMAs of tile i;
+// for that, tile i+1 has landed when tile i starts (two tiles ahead of the MFMAs instead of three).
+template <int NW, bool H, bool TEMPORAL, int NS, bool PF = false>
 __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     constexpr int NT = NW * 64;
     static_assert(NS >= 2 && NS <= 4, "stage ring depth");
+    static_assert(!PF || (H && NS == 4), "fragment prefetch: fp16 instance on the 4-stage ring");
     constexpr int NPL = H ? 2 : 4;               // planes per stage
     constexpr int STAGE = NPL * PLANE;           // (shadows the namespace constant: this instance's stage)
     constexpr int VOFF = (NPL / 2) * PLANE;      // first V plane
@@ -258,6 +263,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < ntiles) issue_tile(t);
+    bf16x8 kf_pf[PF ? 8 : 1];                                               // PF: K fragments of the tile about to be multiplied
 
     // per-lane LDS offsets of the operand reads (stage-relative)
     const int krow = l31 * 256;                                             // K: row l31, chunk (2 st + lh) ^ (l31 & 15)
@@ -265,13 +271,24 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     const int gi = lane >> 4, j16 = lane & 15;
     const int vrow_in = j16 >> 2, vword = j16 & 3;
 
+    if constexpr (PF) {                                                     // (the launcher guarantees ntiles >= 4)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");     // tile 0 has landed (tiles 1, 2 in flight)
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int sx = 0; sx < 8; ++sx) kf_pf[sx] = *reinterpret_cast<const bf16x8*>(smem + krow + (((2 * sx + lh) ^ (l31 & 15)) << 4));
+    }
+
     // one key tile; MASKED = the last, partial tile (keys past n_k get -inf scores): peeled out of the loop so that the full tiles carry no
     // compare / select per score
     auto tile_step = [&](const int it, auto masked_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const int slot = it % NS;
         // this wavefront's pieces of tile `it` have landed; the (up to NS - 2) younger tiles stay in flight across the barrier
-        {
+        if constexpr (PF) {
+            // tile it+1 has landed as well (its K fragments are read during this tile); only tile it+2 may stay in flight
+            if (it + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
             const int ahead = min(NS - 2, ntiles - 1 - it);
             if (NS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
             else if (NS >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
@@ -286,7 +303,23 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
         f32x16 s;
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
-        if constexpr (H) if (!ABL(1)) {
+        bf16x8 vf_pf[PF ? 8 : 1];
+        if constexpr (PF) {
+            // K fragments were requested during the previous tile's PV product; V fragments of this tile are requested now, ahead of the softmax
+#pragma unroll
+            for (int sx = 0; sx < 8; ++sx)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf_pf[sx]), __builtin_bit_cast(f16x8, qh[sx]), s, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int seg = (t * 2 + (gi & 1)) ^ (vrow_in << 1);
+                    const int r0 = 16 * ks + 4 * (gi >> 1) + vrow_in;
+                    const int a0 = r0 * 256 + seg * 32 + vword * 8, a1 = a0 + 8 * 256;
+                    vf_pf[ks * 4 + t] = tr_pair(st + VOFF + a0, st + VOFF + a1);
+                }
+        }
+        if constexpr (H && !PF) if (!ABL(1)) {
             // all eight K fragments in flight before the first MFMA (one LDS round trip instead of eight: the per-tile chain of a
             // wavefront is latency-bound, not issue-bound — halving its VALU instructions did not move the kernel)
             bf16x8 kf[8];
@@ -349,8 +382,26 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
                 for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
         }
         // ---- O^T += V^T . P^T
+        if constexpr (PF) {
+            tr_wait(vf_pf[0], vf_pf[1], vf_pf[2], vf_pf[3]);
+            tr_wait(vf_pf[4], vf_pf[5], vf_pf[6], vf_pf[7]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 1 < ntiles) {                                          // K fragments of the next tile: in flight under the MFMAs below
+                const char* sn = smem + ((it + 1) % NS) * STAGE;
 #pragma unroll
-        for (int ks = 0; ks < (ABL(4) ? 0 : 2); ++ks) {
+                for (int sx = 0; sx < 8; ++sx) kf_pf[sx] = *reinterpret_cast<const bf16x8*>(sn + krow + (((2 * sx + lh) ^ (l31 & 15)) << 4));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 p_h = as_bf16x8(half2(s[8 * ks + 0], s[8 * ks + 1]), half2(s[8 * ks + 2], s[8 * ks + 3]),
+                                             half2(s[8 * ks + 4], s[8 * ks + 5]), half2(s[8 * ks + 6], s[8 * ks + 7]));
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vf_pf[ks * 4 + t]), __builtin_bit_cast(f16x8, p_h), o[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < ((PF || ABL(4)) ? 0 : 2); ++ks) {
             unsigned h0, h1, h2, h3, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
             if constexpr (H) {     // P in [0, 1]: f16_rne
                 h0 = half2(s[8 * ks + 0], s[8 * ks + 1]); h1 = half2(s[8 * ks + 2], s[8 * ks + 3]);
@@ -448,6 +499,16 @@ int launch_mode(const AttnS& p, int problems, hipStream_t s) {
     return fgt_check_launch("attn_split_kernel");
 }
 
+// fp16, long temporal zones, FGT_ATTN_PREFETCH=1 (experimental, see the kernel's header comment)
+int launch_prefetch(const AttnS& p, int problems, hipStream_t s) {
+    constexpr int smem = 4 * 2 * PLANE;
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<8, true, true, 4, true>), smem, lds_set, "attn_split")) return rc;
+    dim3 grid(cdiv(p.n_q, 8 * 32), problems);
+    hipLaunchKernelGGL((attn_split_kernel<8, true, true, 4, true>), grid, dim3(8 * 64), smem, s, p);
+    return fgt_check_launch("attn_split_kernel");
+}
+
 template <int NW, bool H>
 int launch(const AttnS& p, int problems, hipStream_t s) {
     return p.d.mode == 0 ? launch_mode<NW, H, true>(p, problems, s) : launch_mode<NW, H, false>(p, problems, s);
@@ -483,7 +544,9 @@ int fgt_attention_split(const fgt_attn_desc* dd, const void* Q, const void* K, c
     static const int nw_long = [] { const char* e = getenv("FGT_ATTN_SPLIT_NW"); return e ? atoi(e) : 8; }();
     const bool big = n_q >= 2048 && nw_long == 8;
     if (h16) {
+        static const int prefetch = [] { const char* e = getenv("FGT_ATTN_PREFETCH"); return e ? atoi(e) : 0; }();
         if (n_q <= 64) return launch<2, true>(p, problems, s);
+        if (big && prefetch && d.mode == 0 && n_k >= 4 * KT) return launch_prefetch(p, problems, s);
         if (big) return launch<8, true>(p, problems, s);
         return launch<4, true>(p, problems, s);
     }
