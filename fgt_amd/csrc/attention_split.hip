@@ -122,10 +122,12 @@ __device__ __forceinline__ void tr_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8&
 // zones) run ONE workgroup per CU (164-228 registers per lane), so a tile of the double-buffered loop took exactly one global -> LDS round
 // trip (~1 us under load: the loop was latency-bound — halving its VALU instructions, batching its LDS reads and the 4-wavefront instance at
 // three workgroups per CU all left its time unchanged); with the LDS of the whole CU to themselves they keep NS - 1 = 3 tiles in flight.
-// PF (fp16, NS = 4 only; FGT_ATTN_PREFETCH=1 — BUILT IN ROUND 2 AFTER THE GPU BUDGET WAS SPENT, NOT YET RUN ON HARDWARE, off by default): operand
-// prefetch one phase ahead in registers, the lever the ablations point at (profiles/r02_run12_attn_ablate.txt: each matrix phase waits for its
-// own fragment reads).  The V fragments of a tile are requested before its softmax, the K fragments of tile i+1 under the PV MFMAs of tile i;
-// for that, tile i+1 has landed when tile i starts (two tiles ahead of the MFMAs instead of three).
+// PF (fp16, NS = 4 only; FGT_ATTN_PREFETCH=1, off by default): operand prefetch one phase ahead in registers, the lever the ablations seemed to
+// point at (profiles/r02_run12_attn_ablate.txt).  The V fragments of a tile are requested before its softmax, the K fragments of tile i+1
+// under the PV MFMAs of tile i; for that, tile i+1 has landed when tile i starts (two tiles ahead of the MFMAs instead of three).
+// Measured once, with the last GPU seconds of round 2 (tools/attn_prefetch_check.py, profiles/r02_run12_attn_prefetch_check.txt): bit-identical
+// to the default kernel in all four cases — and 0...5 % SLOWER (b = 8, t = 17: 1 142 -> 1 200 us).  Kept as an explicit variant; the next step is a
+// timeline of the tile loop (s_memtime stamps as in tools/conv_trace.py), not another schedule.
 template <int NW, bool H, bool TEMPORAL, int NS, bool PF = false>
 __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     constexpr int NT = NW * 64;
@@ -499,7 +501,7 @@ int launch_mode(const AttnS& p, int problems, hipStream_t s) {
     return fgt_check_launch("attn_split_kernel");
 }
 
-// fp16, long temporal zones, FGT_ATTN_PREFETCH=1 (experimental, see the kernel's header comment)
+// fp16, long temporal zones, FGT_ATTN_PREFETCH=1 (explicit variant: bit-identical, measured slower — see the kernel's header comment)
 int launch_prefetch(const AttnS& p, int problems, hipStream_t s) {
     constexpr int smem = 4 * 2 * PLANE;
     static std::atomic<unsigned long long> lds_set{0};

@@ -1,9 +1,9 @@
 #!/usr/bin/env python
-"""Bring-up check of the fp16 attention's fragment-prefetch variant (FGT_ATTN_PREFETCH=1: attn_split_kernel<8, true, true, 4, PF = true>,
-built at the end of round 2 and NOT YET RUN ON HARDWARE).  Runs the same temporal calls in two child processes (the switch is read once per
-process) and compares: the variant issues the same MFMAs in the same order, so the outputs must be bit-identical; prints both timings.
+"""Check of the fp16 attention's fragment-prefetch variant (FGT_ATTN_PREFETCH=1: attn_split_kernel<8, true, true, 4, PF = true>).  Runs the same
+temporal calls in two child processes (the switch is read once per process) and compares: the variant issues the same MFMAs in the same
+order, so the outputs must be bit-identical; prints both timings (profiles/r02_run12_attn_prefetch_check.txt: identical, 0...5 % slower).
 
-    timeout 120 python tools/attn_prefetch_check.py        (on the MI355X; wrap in `timeout`: an untested kernel can hang)
+    timeout 120 python tools/attn_prefetch_check.py        (on the MI355X)
 """
 import os
 import subprocess
@@ -48,7 +48,7 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         for pf in ("0", "1"):
             path = os.path.join(d, f"pf{pf}.pt")
-            r = subprocess.run([sys.executable, __file__, "--child", path], env=dict(os.environ, FGT_ATTN_PREFETCH=pf), timeout=100)
+            r = subprocess.run([sys.executable, __file__, "--child", path], env=dict(os.environ, FGT_ATTN_PREFETCH=pf), timeout=45)
             if r.returncode != 0:
                 print(f"FGT_ATTN_PREFETCH={pf}: child failed with {r.returncode}")
                 sys.exit(1)
