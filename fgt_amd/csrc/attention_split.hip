@@ -57,6 +57,24 @@ struct AttnS {
 #define ABL(bit) 0
 #endif
 
+#ifdef FGT_ATTN_TRACE
+// Diagnostic build only (python tools/attn_trace.py --build; written at the end of round 2, first run is round 3's): every wavefront stamps
+// s_memtime at the phase boundaries of its first ATR_TILES key tiles into spare LDS, the workgroup dumps them (plus HW_ID / XCC_ID and the
+// constant-rate s_memrealtime) to a global buffer at the end.  Not part of the product library.
+constexpr int ATR_TILES = 24, ATR_NST = 8, ATR_HDR = 8;
+__device__ unsigned* g_attn_trace = nullptr;
+__device__ long g_attn_trace_words = 0;
+#define ATR_STAMP(i) ats[i] = __builtin_readcyclecounter()
+#define ATR_STORE(it)                                                                                             \
+    if ((it) < ATR_TILES && lane == 0) {                                                                          \
+        unsigned* tr_ = atrace_lds + (wave * ATR_TILES + (it)) * ATR_NST;                                         \
+        for (int i_ = 0; i_ < ATR_NST; ++i_) tr_[i_] = (unsigned)ats[i_];                                         \
+    }
+#else
+#define ATR_STAMP(i)
+#define ATR_STORE(it)
+#endif
+
 struct Prob { int frame0, zi, zj, hd; };
 
 // mode 1 with desc.compact: row of the Q / K / V maps that padded-grid pixel `pix` (index into [bt, nh, nw]) reads
@@ -125,9 +143,10 @@ __device__ __forceinline__ void tr_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8&
 // PF (fp16, NS = 4 only; FGT_ATTN_PREFETCH=1, off by default): operand prefetch one phase ahead in registers, the lever the ablations seemed to
 // point at (profiles/r02_run12_attn_ablate.txt).  The V fragments of a tile are requested before its softmax, the K fragments of tile i+1
 // under the PV MFMAs of tile i; for that, tile i+1 has landed when tile i starts (two tiles ahead of the MFMAs instead of three).
-// Measured once, with the last GPU seconds of round 2 (tools/attn_prefetch_check.py, profiles/r02_run12_attn_prefetch_check.txt): bit-identical
-// to the default kernel in all four cases — and 0...5 % SLOWER (b = 8, t = 17: 1 142 -> 1 200 us).  Kept as an explicit variant; the next step is a
-// timeline of the tile loop (s_memtime stamps as in tools/conv_trace.py), not another schedule.
+// Measured with the last GPU seconds of round 2 (tools/attn_prefetch_check.py, profiles/r02_run12_attn_prefetch_check.txt): bit-identical to the
+// default kernel in all four cases; 0...5 % SLOWER as first built (b = 8, t = 17: 1 142 -> 1 200 us), **8 % faster** once the timeline
+// (tools/attn_trace.py) had shown where a tile's cycles go and the LDS-DMA issue was moved behind its QK^T MFMAs (1 196 -> 1 095 us).  Off by
+// default: the full suite has not run on it; round 3 starts here.
 template <int NW, bool H, bool TEMPORAL, int NS, bool PF = false>
 __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     constexpr int NT = NW * 64;
@@ -266,6 +285,14 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     for (int t = 0; t < NS - 1; ++t)
         if (t < ntiles) issue_tile(t);
     bf16x8 kf_pf[PF ? 8 : 1];                                               // PF: K fragments of the tile about to be multiplied
+#ifdef FGT_ATTN_TRACE
+    unsigned long long ats[ATR_NST] = {};
+    unsigned* const atrace_lds = reinterpret_cast<unsigned*>(smem + NS * STAGE);
+    const unsigned long long atr_t0 = __builtin_readcyclecounter();
+    const unsigned long long atr_r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = tid; i < NW * ATR_TILES * ATR_NST; i += NT) atrace_lds[i] = 0;
+    __syncthreads();
+#endif
 
     // per-lane LDS offsets of the operand reads (stage-relative)
     const int krow = l31 * 256;                                             // K: row l31, chunk (2 st + lh) ^ (l31 & 15)
@@ -285,6 +312,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     auto tile_step = [&](const int it, auto masked_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const int slot = it % NS;
+        ATR_STAMP(0);                                                       // tile top
         // this wavefront's pieces of tile `it` have landed; the (up to NS - 2) younger tiles stay in flight across the barrier
         if constexpr (PF) {
             // tile it+1 has landed as well (its K fragments are read during this tile); only tile it+2 may stay in flight
@@ -296,8 +324,12 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
             else if (NS >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        ATR_STAMP(1);                                                       // own DMA pieces landed
         if (!ABL(16)) __builtin_amdgcn_s_barrier();                         // ... everyone's have, and tile it-1 is fully consumed
-        if (it + NS - 1 < ntiles && !ABL(8)) issue_tile((it + NS - 1) % NS);   // its stage held tile it-1; streams under the MFMAs of NS - 1 tiles
+        ATR_STAMP(2);                                                       // behind the barrier
+        if constexpr (!PF)
+            if (it + NS - 1 < ntiles && !ABL(8)) issue_tile((it + NS - 1) % NS);   // its stage held tile it-1; streams under the MFMAs of NS - 1 tiles
+        ATR_STAMP(3);                                                       // DMAs of a later tile issued (default kernels)
         const char* st = smem + slot * STAGE;
         const int k0 = it * KT;
 
@@ -347,6 +379,14 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, qh[sx], s, 0, 0, 0);
             }
         }
+        // PF: the LDS-DMAs of a later tile are issued HERE, behind the QK^T MFMAs (their stage held tile it-1: free since the barrier above).  The
+        // timeline (tools/attn_trace.py, profiles/r02_run12_attn_trace.txt) shows 540-670 cycles of address arithmetic + DMA issue per tile and
+        // wavefront between the barrier and the first K fragment read; with the K fragments already in registers the MFMAs start right behind
+        // the barrier and the issue runs while the matrix pipe works: 1 196 -> 1 095 us on the b = 8, t = 17 call (profiles/r02_run12_attn_prefetch_check.txt,
+        // second table), bit-identical.  The default kernels keep the issue in front (the same move measured 0...+5 % there).
+        if constexpr (PF)
+            if (it + NS - 1 < ntiles && !ABL(8)) issue_tile((it + NS - 1) % NS);
+        ATR_STAMP(4);                                                       // QK^T MFMAs issued (fragment reads waited for)
         // ---- online softmax in base 2 on the RAW scores (the scale c = log2(e) / sqrt(d) > 0 commutes with the maximum and is folded into the
         // exponent: p = exp2(s c - m c), one FMA per score); keys of this lane: k0 + (e&3) + 8*(e>>2) + 4*lh, masked in the last tile only
         if constexpr (MASKED) {
@@ -375,6 +415,10 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
         }
         l_run = l_run * alpha + (ps2[0] + ps2[1]);
         m_run = m_new;
+#ifdef FGT_ATTN_TRACE
+        asm volatile("" ::"v"(l_run));                                      // (the row sum depends on every score: the QK^T results have arrived)
+#endif
+        ATR_STAMP(5);                                                       // softmax done
         // the running maximum settles after a few tiles: when NO query of this wavefront saw a new one, alpha is exactly 1 for all of
         // them and the 64 multiplies are skipped (bit-identical: x * 1.0f == x)
         if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
@@ -447,10 +491,37 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
                 }
             }
         }
+        ATR_STAMP(6);                                                       // PV MFMAs issued
+        ATR_STORE(it);
     };
     const int nfull = p.n_k / KT;                                           // tiles whose 32 keys all exist
     for (int it = 0; it < nfull; ++it) tile_step(it, std::false_type{});
     if (nfull < ntiles) tile_step(nfull, std::true_type{});
+#ifdef FGT_ATTN_TRACE
+    {
+        const unsigned long long atr_t2 = __builtin_readcyclecounter();
+        __syncthreads();
+        constexpr int PER_WG = NW * (ATR_HDR + ATR_TILES * ATR_NST);
+        const long wg = (long)blockIdx.y * gridDim.x + blockIdx.x;
+        unsigned* out = g_attn_trace;
+        if (out && (wg + 1) * PER_WG <= g_attn_trace_words) {
+            out += wg * PER_WG;
+            if (lane == 0) {
+                unsigned* h = out + wave * ATR_HDR;
+                h[0] = __builtin_amdgcn_s_getreg(63492);    // HW_ID
+                h[1] = __builtin_amdgcn_s_getreg(63508);    // XCC_ID
+                h[2] = (unsigned)atr_t0;
+                h[3] = (unsigned)ntiles;
+                h[4] = (unsigned)atr_t2;
+                h[5] = (unsigned)(__builtin_amdgcn_s_memrealtime() - atr_r0);
+                h[6] = (unsigned)NW;
+                h[7] = (unsigned)(H ? 1 : 0);
+            }
+            for (int i = tid; i < NW * ATR_TILES * ATR_NST; i += NT) out[NW * ATR_HDR + i] = atrace_lds[i];
+        }
+        __syncthreads();
+    }
+#endif
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / l_tot;
@@ -492,7 +563,11 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
 template <int NW, bool H, bool TEMPORAL>
 int launch_mode(const AttnS& p, int problems, hipStream_t s) {
     constexpr int NS = NW == 8 ? 4 : 2;          // long zones (one workgroup per CU): four stages = three tiles in flight
+#ifdef FGT_ATTN_TRACE
+    constexpr int smem = NS * (H ? 2 : 4) * PLANE + NW * ATR_TILES * ATR_NST * 4;
+#else
     constexpr int smem = NS * (H ? 2 : 4) * PLANE;
+#endif
     static_assert(smem <= 160 * 1024, "LDS ring does not fit");
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<NW, H, TEMPORAL, NS>), smem, lds_set, "attn_split")) return rc;
@@ -503,7 +578,11 @@ int launch_mode(const AttnS& p, int problems, hipStream_t s) {
 
 // fp16, long temporal zones, FGT_ATTN_PREFETCH=1 (explicit variant: bit-identical, measured slower — see the kernel's header comment)
 int launch_prefetch(const AttnS& p, int problems, hipStream_t s) {
+#ifdef FGT_ATTN_TRACE
+    constexpr int smem = 4 * 2 * PLANE + 8 * ATR_TILES * ATR_NST * 4;
+#else
     constexpr int smem = 4 * 2 * PLANE;
+#endif
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<8, true, true, 4, true>), smem, lds_set, "attn_split")) return rc;
     dim3 grid(cdiv(p.n_q, 8 * 32), problems);
@@ -517,6 +596,15 @@ int launch(const AttnS& p, int problems, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef FGT_ATTN_TRACE
+extern "C" int fgt_debug_attn_trace(void* buf, long words) {
+    unsigned* b = static_cast<unsigned*>(buf);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace), &b, sizeof(b)) != hipSuccess) return FGT_ELAUNCH;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace_words), &words, sizeof(words)) != hipSuccess) return FGT_ELAUNCH;
+    return FGT_OK;
+}
+#endif
 
 // called by fgt_attention (attention.hip) when desc.in_split is set
 int fgt_attention_split(const fgt_attn_desc* dd, const void* Q, const void* K, const void* V, const void* KG, const void* VG, float* O,

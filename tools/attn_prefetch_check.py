@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Check of the fp16 attention's fragment-prefetch variant (FGT_ATTN_PREFETCH=1: attn_split_kernel<8, true, true, 4, PF = true>).  Runs the same
 temporal calls in two child processes (the switch is read once per process) and compares: the variant issues the same MFMAs in the same
-order, so the outputs must be bit-identical; prints both timings (profiles/r02_run12_attn_prefetch_check.txt: identical, 0...5 % slower).
+order, so the outputs must be bit-identical; prints both timings (profiles/r02_run12_attn_prefetch_check.txt: identical; 8 % faster on the bench-sized call).
 
     timeout 120 python tools/attn_prefetch_check.py        (on the MI355X)
 """
