@@ -222,6 +222,27 @@ class FGT(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def prepack(self, dev=None):
+        """Fill every lazily built cache of the forward pass on the CURRENT stream: the packed weights, their bf16 hi/lo (and, in the
+        'f16' mode, fp16) images for the arithmetic mode selected now, and the zero rows of the spatial attention.  ClipRunner calls
+        this before it forks the window groups onto side streams, so that no group reads a cache another stream is still writing."""
+        P = self.packed()
+        mode = ops.DEFAULT_CONV_PRECISION
+
+        def walk(o):
+            if isinstance(o, PackedConv):
+                ops.prepack_weights(o, mode)
+            elif isinstance(o, dict):
+                for v in o.values():
+                    walk(v)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    walk(v)
+        walk(P)
+        dev = dev if dev is not None else next(self.parameters()).device
+        self._zero_row(dev, self.cfg["c"] + self.cfg["cf"])
+        return self
+
     def _pack_block(self, blk):
         """ConvBlockParams -> (feature PackedConv, gating PackedConv | None)"""
         f = PackedConv(blk.featureConv.weight, blk.featureConv.bias)
@@ -472,6 +493,10 @@ class FGT(nn.Module):
         bt = b * t
         n = th * tw
         Hf, Wf = enc.shape[1], enc.shape[2]
+        if keep is not None and keep.dtype != torch.int32:
+            keep = keep.to(torch.int32)                                 # (the row gathers take int32 indices; int64 was the documented type)
+        if keep_q is not None and keep_q.dtype != torch.int32:
+            keep_q = keep_q.to(torch.int32)
         if n_out is not None and tq is None:
             tq = n_out                                                  # b == 1: the consumed frames are the prefix itself
         prune = tq is not None and 0 < tq < t and (keep is not None or n_out is not None) and len(P["blocks"]) > 0

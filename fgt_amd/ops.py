@@ -251,6 +251,19 @@ def _split_weights(pc, interleaved=None):
     return cache[il], il
 
 
+def prepack_weights(pc, mode=None):
+    """Build the weight images fgt_conv2d would otherwise create lazily on its first launch in arithmetic `mode` (default: the
+    current one): the bf16 hi/lo image for 'bf16x3' (and for the GEMMs that still take fp32 inputs in the 'f16' mode) and the fp16
+    image for 'f16'.  Called on the main stream before work is forked onto side streams (scheduler.ClipRunner)."""
+    mode = DEFAULT_CONV_PRECISION if mode is None else mode
+    if pc.Cout // pc.groups <= 4:
+        return
+    if mode in ("bf16x3", "f16"):
+        _split_weights(pc)
+    if mode == "f16":
+        _f16_weights(pc)
+
+
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
            epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None,
            out_split=None, out_s=None, out_il=False):
@@ -355,9 +368,12 @@ def _aliases(out, out_s, *ins):
             return None
         lo = t.storage_offset()
         hi = lo + sum((n - 1) * st for n, st in zip(t.shape, t.stride())) + 1             # element range inside the storage
-        ld = max([st for n, st in zip(t.shape[:-1], t.stride()[:-1]) if n > 1 and st > 0], default=0)
-        ld = min([st for n, st in zip(t.shape[:-1], t.stride()[:-1]) if n > 1 and st > 0], default=0) if ld else 0
-        return (t.untyped_storage().data_ptr(), t.element_size(), lo, hi, ld, t.shape[-1] if t.dim() else 1)
+        outer = [st for n, st in zip(t.shape[:-1], t.stride()[:-1]) if n > 1 and st > 0]
+        ld = min(outer, default=0)
+        # the channel-window shortcut below is only valid when EVERY outer stride is a multiple of the pixel stride (padded rows /
+        # frames break it): otherwise the tensor counts as overlapping whatever shares its element range (conservative)
+        regular = bool(ld) and all(st % ld == 0 for st in outer)
+        return (t.untyped_storage().data_ptr(), t.element_size(), lo, hi, ld, t.shape[-1] if t.dim() else 1, regular)
 
     def overlap(a, b):
         if a[0] != b[0] or a[1] != b[1]:
@@ -367,7 +383,7 @@ def _aliases(out, out_s, *ins):
             return a0 < b1 and b0 < a1
         if not (a[2] < b[3] and b[2] < a[3]):
             return False
-        if a[4] and a[4] == b[4] and a[5] <= a[4] and b[5] <= b[4]:                       # same pixel stride: compare channel windows
+        if a[4] and a[4] == b[4] and a[5] <= a[4] and b[5] <= b[4] and a[6] and b[6]:     # same pixel stride: compare channel windows
             ca, cb = a[2] % a[4], b[2] % b[4]
             if ca + a[5] <= a[4] and cb + b[5] <= b[4]:
                 return ca < cb + b[5] and cb < ca + a[5]

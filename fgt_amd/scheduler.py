@@ -91,12 +91,16 @@ def ideal_speedup(sched, world):
 
 def needs_host_staging(is_cuda, backend):
     """RCCL ("nccl" IS RCCL on ROCm) gathers device buffers directly over xGMI; gloo cannot touch device memory."""
-    return bool(is_cuda) and backend != "nccl"
+    # (a group created without an explicit backend reports a composite string such as "cuda:nccl,cpu:gloo")
+    return bool(is_cuda) and "nccl" not in str(backend).lower()
 
 
 class _Done:
     def wait(self):
         return True
+
+
+_staging_logged = False
 
 
 def all_gather(out, buf, group=None, async_op=False):
@@ -105,6 +109,12 @@ def all_gather(out, buf, group=None, async_op=False):
     device tensors, so there the call is staged through host memory (synchronously)."""
     import torch.distributed as dist
     if needs_host_staging(buf.is_cuda, dist.get_backend(group)):
+        global _staging_logged
+        if not _staging_logged:
+            _staging_logged = True
+            import sys
+            print(f"[fgt_amd.scheduler] backend {dist.get_backend(group)!r} cannot gather device buffers: collectives are staged through "
+                  "host memory (synchronous; rehearsal / test path, not the RCCL path)", file=sys.stderr)
         host = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(host, buf.cpu(), group=group)
         out.copy_(host)
@@ -252,11 +262,15 @@ class ClipRunner:
         """Per-frame stages for frames [s0, s1) written into dst = (enc, tok, ftok) row slices."""
         net = self.model.net
         k = s1 - s0
-        if self.on_gpu:
+        if self.on_gpu and net.passmask and net.in_channels == 4:
+            fin = ops.ceil_to(net.cfg["flow_in"], 4)
             x_in = ops.pack_frames(self.frames01[0, s0:s1], self.masks[0, s0:s1])
-            f_in = torch.empty(k, self.H, self.W, 4, dtype=torch.float32, device=self.dev)
-            ops.nchw_to_nhwc(self.flows[0, s0:s1], f_in, coff=0, zero_to=4)
+            f_in = torch.empty(k, self.H, self.W, fin, dtype=torch.float32, device=self.dev)
+            ops.nchw_to_nhwc(self.flows[0, s0:s1], f_in, coff=0, zero_to=fin)
             net.encode_frames(packed_in=(x_in, f_in), out=tuple(d[:k] for d in dst))
+        elif self.on_gpu:   # models without the mask channel (PASSMASK = 0 / other in_channel): the nn.Module-style call, written in place
+            m = self.masks[:, s0:s1]
+            net.encode_frames((self.frames01[:, s0:s1] * 2 - 1) * (1 - m), self.flows[:, s0:s1], m, out=tuple(d[:k] for d in dst))
         else:       # CPU tests over tests/fake_ops.py: the nn.Module-style call, results copied into the buffers
             m = self.masks[:, s0:s1]
             enc, tok, ftok, _, _ = net.encode_frames((self.frames01[:, s0:s1] * 2 - 1) * (1 - m), self.flows[:, s0:s1], m)
@@ -326,7 +340,11 @@ class ClipRunner:
                 outs = {}
                 if self.on_gpu and self.n_streams > 1 and len(self.groups) > 1:
                     # independent window groups on separate HIP streams: the HBM-bound kernels of one group (LayerNorm, fold, pools)
-                    # and the tails of its GEMM launches overlap the matrix-core kernels of another
+                    # and the tails of its GEMM launches overlap the matrix-core kernels of another.
+                    # Every lazily filled cache the groups share (packed / split / fp16 weight images, zero rows) is filled HERE, on the
+                    # main stream, before the fork: a cache filled by the first group's stream would be read by the next group's
+                    # stream with no event between them.
+                    self.model.net.prepack(self.dev)
                     main = torch.cuda.current_stream()
                     if self._streams is None:
                         self._streams = [torch.cuda.Stream() for _ in range(self.n_streams)]

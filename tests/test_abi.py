@@ -76,6 +76,15 @@ def test_autotune_alias_guard():
     rows = torch.zeros(100, 64)
     assert not ops._aliases(rows[:50], None, rows[50:]) and ops._aliases(rows[:60], None, rows[50:])
     assert not ops._aliases(torch.zeros(3, 4), None, rows) and not ops._aliases(None, None, rows)
+    # views whose outer strides are NOT multiples of the pixel stride (padded rows): the channel-window shortcut does not apply,
+    # the guard must answer "overlaps"  — here element ranges interleave although the channel windows look disjoint
+    st = torch.zeros(4 * 1000)
+    a = st.as_strided((4, 3, 64), (1000, 200, 1), 0)           # frame stride 1000 = 5 * 200: regular
+    b = st.as_strided((4, 3, 64), (1000, 200, 1), 64)
+    assert not ops._aliases(a, None, b)
+    c = st.as_strided((3, 3, 64), (1100, 200, 1), 0)           # frame stride 1100: not a multiple of 200
+    d = st.as_strided((3, 3, 64), (1100, 200, 1), 64)
+    assert ops._aliases(c, None, d)
 
 
 def test_entry_build_runs_here():

@@ -88,3 +88,49 @@ def test_graph_cache_follows_weight_updates(dev):
     want = ClipRunner(m, fr, fl, ms, use_graphs=False).run()
     assert not torch.equal(a, b), "graph replayed the old weights"
     assert torch.equal(b, want)
+
+
+def test_two_streams_cold_without_autotune_bit_equal(dev, monkeypatch):
+    """with window groups on side streams the lazily built weight images / zero rows used to be filled by whichever stream
+    touched them first and read by the next stream with no event in between; the autotuner's host syncs masked it.  A COLD model
+    (fresh weights: nothing packed), no autotuning, two streams — must equal the single-stream composite bit for bit."""
+    from fgt_amd import ops
+    from fgt_amd.scheduler import ClipRunner
+    monkeypatch.setattr(ops, "AUTOTUNE", False)
+    for prec in ("bf16x3", "f16"):
+        monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", prec)
+        monkeypatch.setattr(ops, "DEFAULT_ATTN_PRECISION", prec)
+        fr, fl, ms = (x.to(dev) for x in synth_clip(26, 64, 96, seed=3))
+        m1, _, _ = _model(dev)
+        want = ClipRunner(m1, fr, fl, ms, window_batch=1, n_streams=1).run().cpu()
+        for _ in range(3):
+            m2, _, _ = _model(dev)                                   # cold: nothing packed, no split / fp16 images, no zero rows
+            two = ClipRunner(m2, fr, fl, ms, window_batch=1, n_streams=2)
+            assert len(two.groups) >= 3
+            assert torch.equal(two.run().cpu(), want), prec
+
+
+def test_transform_decode_accepts_int64_keep(dev):
+    """The public entry point documented `keep` as an int64 device tensor: same result as int32."""
+    m, _, _ = _model(dev)
+    fr, fl, ms = (x.to(dev) for x in synth_clip(4, 64, 96, seed=4))
+    net = m.net
+    enc, x, f, th, tw = net.encode_frames((fr * 2 - 1) * (1 - ms), fl, ms)
+    a = net.transform_decode(enc, x, f, 1, 4, th, tw, keep=torch.tensor([0, 2], dtype=torch.int32, device=dev))
+    b = net.transform_decode(enc, x, f, 1, 4, th, tw, keep=torch.tensor([0, 2], dtype=torch.int64, device=dev))
+    assert torch.equal(a, b)
+
+
+def test_cliprunner_model_without_mask_channel(dev):
+    """PASSMASK = 0 (3 input channels): the scheduler's packed-input fast path does not apply; it must fall back to the nn.Module-style
+    call instead of asserting, and equal the window-by-window path."""
+    from fgt_amd.fgt_model import DEFAULT_CONFIG, Model
+    from fgt_amd.scheduler import ClipRunner
+    cfg = dict(DEFAULT_CONFIG, PASSMASK=0, in_channel=3)
+    m = Model(cfg).eval()
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=0), strict=True)
+    m = m.to(dev)
+    fr, fl, ms = (x.to(dev) for x in synth_clip(12, 64, 96, seed=6))
+    a = ClipRunner(m, fr, fl, ms, cache_features=True).run()
+    b = ClipRunner(m, fr, fl, ms, cache_features=False).run()
+    assert torch.equal(a, b)

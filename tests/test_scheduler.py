@@ -61,6 +61,8 @@ def test_rccl_branch_gathers_device_buffers_directly(monkeypatch):
     import torch.distributed as dist
     from fgt_amd import scheduler
     assert needs_host_staging(True, "gloo") and not needs_host_staging(True, "nccl") and not needs_host_staging(False, "gloo")
+    # a group created without an explicit backend reports a composite string: still RCCL for device tensors
+    assert not needs_host_staging(True, "cuda:nccl,cpu:gloo") and needs_host_staging(True, "cpu:gloo")
     calls = []
 
     class FakeDev:                                   # stands in for a device tensor on this CPU-only box
