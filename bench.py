@@ -40,6 +40,12 @@ PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s mea
 KERNELS = {"conv": "conv_split_kernel (bf16x3) / conv_f16_kernel (f16) / conv_igemm_kernel (fp32 inputs): implicit-GEMM conv + every Linear; all fgt_conv2d MFMA launches",
            "attn_temporal": "attn_split_kernel<8|4, H> (bf16x3: split q/k/v; f16: H = true) / attn_kernel<4> (fp32): temporal zone attention, fgt_attention mode 0",
            "attn_spatial": "attn_split_kernel<2, H> (bf16x3 / f16) / attn_kernel<2> (fp32): spatial window + global-token attention, fgt_attention mode 1"}
+# HBM-bound kernels of the step (fgt_prof kinds 3..9): algorithmic bytes (every input / output byte once) over HIP-event time
+HBM_KERNELS = {"layernorm": "layernorm_kernel: row LayerNorm over [x0 | x1], up to two affine outputs (fp32 / split / fp16), FGT/models/model.py:126-128,147",
+               "fold": "fold_kernel: overlap-add of token patches as a gather (+ 1/count, residual, ReLU, split / fp16 output), ffn_base.py:56-75, model.py:102-110",
+               "conv_small": "conv3x3_tiled_kernel<3>: decoder.final 64 -> 3 (+ tanh) on the VALU, model.py:186",
+               "dw_pool": "dw_pool4_kernel: depthwise 4x4 / stride 4 global-token extraction, attention_flow.py:44-48",
+               "pointwise": "gather_rows / dw3x3_res / split / pad_tokens / pack_frames / nchw<->nhwc / axpby: one pass over the data"}
 
 
 DTYPES = {"fp32": "f32", "bf16x3": "f32 (conv/GEMM/attention products as 3 bf16 MFMAs on hi/lo splits, fp32 accumulate)",
@@ -60,7 +66,10 @@ def kernel_traffic(prec):
     p = os.path.join(ROOT, "profiles", "kernel_traffic.json")
     if not os.path.exists(p):
         return {}
-    return json.load(open(p)).get(prec, {})
+    out = dict(json.load(open(p)).get(prec, {}))
+    out["_source"] = {"file": "profiles/kernel_traffic.json", "git_head": out.get("git_head", ""), "command": out.get("command", ""),
+                      "note": "PMC counters cannot be read in-process: last profiled value of this configuration (tools/gpu_check.sh pmc stage)"}
+    return out
 
 
 def cpu_baseline(cfg, sd, frames, flows, masks, sched, model=None, runs=3):
@@ -125,6 +134,8 @@ def main():
                          "rounded once to fp16 by their producer, one fp16 MFMA per product, fp32 accumulation (~1e-4, bar 1e-3)")
     ap.add_argument("--no-fp32-exact", action="store_true", help="N = 1: do not also time the exact-fp32 mode (the `fp32_exact` object)")
     ap.add_argument("--no-f16", action="store_true", help="N = 1: do not also time the f16 mode (the `f16` object)")
+    ap.add_argument("--no-c4", action="store_true", help="N = 1: skip the `c4` object (BASELINE config C4 + tool stages: RAFT, diffusion fill, LAFC, "
+                                                         "gradient propagation, Poisson blend, pipeline frames/s)")
     ap.add_argument("--no-cache", action="store_true", help="recompute the per-frame encoders in every window like the reference")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N>1 headline: strong = one clip sharded by frames/windows over the ranks (default); weak = one clip per rank")
@@ -212,7 +223,7 @@ def main():
                 runner.use_graphs = True
                 scale = args.steps
             ops.prof_enable(False)
-            for k in KERNELS:
+            for k in list(KERNELS) + list(HBM_KERNELS):
                 ms, fl, n, by = ops.prof_collect(k)
                 kinds[k] = (ms * scale, fl * scale, n * scale, by * scale)
         return max_over_ranks(dt), host_dt, comp, kinds
@@ -243,6 +254,12 @@ def main():
         for k, (ms, fl, n, by) in kinds.items():
             if ms <= 0 or n == 0:
                 continue
+            if k in HBM_KERNELS:
+                gbs = by / (ms * 1e-3) / 1e9
+                out.append({"bound": "hbm", "kernel": HBM_KERNELS[k], "kind": k, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                            "frac": round(gbs / PEAK_HBM_GBPS, 4), "algorithmic_bytes_per_launch": round(by / n), "launches": n,
+                            "avg_launch_us": round(1e3 * ms / n, 2), "kernel_ms_per_step": round(ms / args.steps, 3), "share_of_step": round(ms / (1e3 * dt), 3)})
+                continue
             ach = passes * fl / (ms * 1e-3) / 1e12
             gbs = by / (ms * 1e-3) / 1e9
             # the same launches on the HBM roofline: unique bytes (every input / weight / output byte once) over the same time
@@ -250,13 +267,14 @@ def main():
             out.append({"bound": "mfma" if ach / peak >= gbs / PEAK_HBM_GBPS else "hbm (closer to the HBM roof than to the MFMA roof: see `hbm`)",
                         "kernel": KERNELS[k], "kind": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "hbm": hbm, "traffic": traffic.get(k, {}).get("hbm_bytes_per_launch"),
+                        "traffic_source": traffic.get("_source"),
                         "algorithmic_tflops": round(fl / (ms * 1e-3) / 1e12, 2), "mfma_passes_per_product": passes,
                         "launches": n, "avg_launch_us": round(1e3 * ms / n, 2), "kernel_ms_per_step": round(ms / args.steps, 3),
                         "share_of_step": round(ms / (1e3 * dt), 3)})
             if sus:
                 out[-1]["sustained"] = dict(sus, frac=round(ach / sus["peak"], 4)) if sus.get("peak") else sus
         out.sort(key=lambda r: -r["share_of_step"])
-        return out
+        return [r for r in out if r["kind"] in KERNELS] + [r for r in out if r["kind"] in HBM_KERNELS]
 
     def assemble(res, weak, strong_error=None):
         dt, runner = res["dt"], res["runner"]
@@ -374,6 +392,15 @@ def main():
                                  if (args.height, args.width) == (240, 432) else None,
                                  "composite_vs_headline": {"max_uint8_steps": float(d8.max()), "differing_values": float((d8 > 0).float().mean())}}
             ops.DEFAULT_CONV_PRECISION = ops.DEFAULT_ATTN_PRECISION = prec
+        if not args.no_c4:
+            # BASELINE config C4 + the tool stages around the FGT stage on the same clip geometry, each with its roofline and a CPU baseline
+            try:
+                import bench_stages
+                out["c4"] = bench_stages.run_stages(dev, prec, frames=args.frames, H=args.height, W=args.width, fgt_ms=out["ms_per_step"],
+                                                    with_cpu=not args.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001 - the side object must not take the headline down
+                import traceback
+                out["c4"] = {"error": f"{type(e).__name__}: {e}"[:400], "trace": traceback.format_exc()[-1200:]}
         if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
             ops.save_tuning(os.path.join(ROOT, "gpurun_out", "tuning.json"))
 

@@ -1,0 +1,278 @@
+"""BASELINE config C4 and the tool stages around the FGT stage, timed on the MI355X for bench.py's `c4` object.
+
+For one synthetic N-frame H x W clip (default 80 x 240 x 432, the clip of the headline) every covered stage of
+tool/video_inpainting.py is run on its full-clip workload through the same entry points the drop-in uses:
+
+    RAFT (calculate_flow :233-288)      fgt_amd.flow_pipeline.compute_flows     2(N-1) pairs, 20 iterations, at H x W and at 2H x 2W
+    diffusion fill (:42-51)             fgt_amd.flow_pipeline.diffusion         2 directions x (N-1) flows x 2 channels
+    LAFC (complete_flow :342-385)       fgt_amd.flow_pipeline.complete_flows    2 directions x (N-1) flows
+    gradient propagation (:623-633)     fgt_amd.propagation.propagate_gradients one clip
+    Poisson blend (:644-682)            fgt_amd.blending.poisson_blend_clip     N frames x 3 channels
+    FGT stage (:687-748)                the headline of bench.py (passed in)
+
+Each entry carries: ms per unit, the algorithmic work (SURVEY.md §8d counts: reference FLOPs for the networks, bytes for the
+solvers / propagation), the roofline it is held against (2.5 PF dense bf16 for the MFMA stages, 8 TB/s HBM for the others) and a CPU
+baseline on a BOUNDED sample (the oracle, on rank 0 only).  `rooflines` = per-kernel HIP-event figures over one extra pass of
+the flow stages (conv/GEMM TF as executed, and the HBM-bound kernels: corr lookup, warp, small-Cout convs, pointwise), and
+`pipeline_frames_per_s` = N / (sum of the stage times) for the whole covered chain.
+
+Not covered (out of scope): image I/O, cv2.resize / cv2.inpaint, scipy.ndimage mask dilation, edge maps.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+PEAK_BF16 = 2500.0
+PEAK_FP32 = 157.3
+PEAK_HBM = 8000.0
+GF_LAFC = 130.2                     # per LAFC call at 240x432
+GF_RAFT = {(240, 432): 245.7, (480, 864): 998.9}
+
+
+def _sync():
+    torch.cuda.synchronize()
+
+
+def _timed(fn, reps=2, warm=1):
+    for _ in range(warm):
+        fn()
+    _sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    _sync()
+    return (time.perf_counter() - t0) / reps, out
+
+
+def _smooth(x, k):
+    """separable box low-pass on the last two dims (torch only: no scipy needed on the product side)"""
+    sh = x.shape
+    y = x.reshape(-1, 1, sh[-2], sh[-1])
+    y = torch.nn.functional.avg_pool2d(y, (k, 1), 1, (k // 2, 0), count_include_pad=False)
+    y = torch.nn.functional.avg_pool2d(y, (1, k), 1, (0, k // 2), count_include_pad=False)
+    return y.reshape(sh)
+
+
+def stage_inputs(N, H, W, seed=4321):
+    """Seeded synthetic inputs of every stage for one clip (CPU tensors)."""
+    g = torch.Generator().manual_seed(seed)
+    # video 0..255 with structure at several scales (RAFT needs texture), moving 1.5 px / frame
+    base = _smooth(torch.rand(3, H + 64, W + 2 * N + 64, generator=g), 9)
+    base = (base - base.amin()) / (base.amax() - base.amin())
+    fine = torch.rand(3, H + 64, W + 2 * N + 64, generator=g) * 0.15
+    tex = (base + fine).clamp(0, 1)
+    video = torch.stack([tex[:, 32 + (i % 3):32 + (i % 3) + H, 16 + 2 * i:16 + 2 * i + W] for i in range(N)]) * 255.0
+    # object-like hole: an ellipse drifting 1.5 px / frame (about 17 k px at 240x432), and its dilation
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    hole = torch.stack([(((yy - H / 2 - 0.3 * i) / (H * 0.29)) ** 2 + ((xx - W * 0.35 - 1.5 * i) / (W * 0.185)) ** 2 <= 1.0) for i in range(N)])
+    # smooth flows of a few pixels; backward ~ -forward + noise
+    ff = _smooth(torch.randn(N - 1, 2, H, W, generator=g), 15) * 40.0
+    fb = -ff + _smooth(torch.randn(N - 1, 2, H, W, generator=g), 15) * 4.0
+    img = video / 255.0                                                      # [N,3,H,W]
+    gx = torch.zeros(N, H, W, 3)
+    gy = torch.zeros(N, H, W, 3)
+    im = img.permute(0, 2, 3, 1)
+    gx[:, :, :-1] = im[:, :, 1:] - im[:, :, :-1]
+    gy[:, :-1] = im[:, 1:] - im[:, :-1]
+    gx[hole] = 0
+    gy[hole] = 0
+    return dict(video=video, hole=hole, flow_f=ff, flow_b=fb, gx=gx, gy=gy, img=im.contiguous())
+
+
+def _models(dev):
+    import argparse
+    from fgt_amd import lafc_model, raft_model
+    from fgt_amd.synth import synth_state_dict
+    lafc = lafc_model.Model(dict(lafc_model.DEFAULT_CONFIG)).eval()
+    lsd = synth_state_dict(lafc.state_dict(), seed=0, mode="kaiming")
+    lafc.load_state_dict(lsd, strict=True)
+    raft = raft_model.RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).eval()
+    rsd = synth_state_dict(raft.state_dict(), seed=0, mode="kaiming")
+    raft.load_state_dict(rsd, strict=True)
+    return lafc.to(dev), lsd, raft.to(dev), rsd
+
+
+def _mfma(ms_unit, gflop_unit, prec):
+    passes = 3 if prec == "bf16x3" else 1
+    peak = PEAK_FP32 if prec == "fp32" else PEAK_BF16
+    alg = gflop_unit / ms_unit                                               # GFLOP / ms = TFLOP/s
+    return {"bound": "mfma", "algorithmic_tflops_reference_count": round(alg, 2), "achieved": round(alg * passes, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(alg * passes / peak, 4), "mfma_passes_per_product": passes}
+
+
+def _hbm(ms, nbytes):
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM, "unit": "GB/s", "frac": round(gbs / PEAK_HBM, 4), "algorithmic_bytes": int(nbytes)}
+
+
+def run_stages(dev, prec="bf16x3", frames=80, H=240, W=432, fgt_ms=None, with_cpu=True, reps=2, fill_iters=None, blend_iters=None):
+    from fgt_amd import blending, flow_pipeline, ops, propagation
+    torch.set_grad_enabled(False)
+    saved = (ops.DEFAULT_CONV_PRECISION, ops.DEFAULT_ATTN_PRECISION)
+    ops.DEFAULT_CONV_PRECISION = ops.DEFAULT_ATTN_PRECISION = prec
+    N = frames
+    inp = stage_inputs(N, H, W)
+    lafc, lsd, raft, rsd = _models(dev)
+    out = {"clip": f"{N} frames {W}x{H}", "precision": prec, "stages": {}}
+    st = out["stages"]
+    times_ms = {}
+
+    # ------------------------------------------------------------------ RAFT, 2(N-1) pairs, 20 iterations
+    video = inp["video"].to(dev)
+    for scale in (1, 2):
+        h, w = H * scale, W * scale
+        v = video if scale == 1 else torch.nn.functional.interpolate(video, size=(h, w), mode="bilinear", align_corners=False)
+        dt, _ = _timed(lambda: flow_pipeline.compute_flows(raft, v, iters=20), reps=reps)
+        pairs = 2 * (N - 1)
+        ms_pair = dt * 1e3 / pairs
+        gf = GF_RAFT.get((h, w))
+        rec = {"ms_per_pair": round(ms_pair, 3), "pairs": pairs, "ms_per_clip": round(dt * 1e3, 1), "iters": 20,
+               "pipeline": f"per-frame fnet/cnet cache + {flow_pipeline.RAFT_PAIR_BATCH} pairs per batch (bit-identical flows)"}
+        if gf:
+            rec["roofline"] = _mfma(ms_pair, gf, prec)
+        st[f"raft_{w}x{h}"] = rec
+        times_ms[f"raft_{w}x{h}"] = dt * 1e3
+    del v
+    # ------------------------------------------------------------------ diffusion fill: both directions in two calls like the tool
+    hole = inp["hole"].to(dev)
+    ffl = inp["flow_f"].to(dev).permute(1, 0, 2, 3)[None].contiguous()         # [1,2,N-1,H,W]
+    fbl = inp["flow_b"].to(dev).permute(1, 0, 2, 3)[None].contiguous()
+    mk_f = hole[:-1].float()[None, None]                                       # forward flows use mask i, backward mask i+1 (:350-353)
+    mk_b = hole[1:].float()[None, None]
+    kw = {} if fill_iters is None else {"iters": fill_iters}
+    dt, dif_f = _timed(lambda: flow_pipeline.diffusion(ffl, mk_f, **kw), reps=reps)
+    dt2, dif_b = _timed(lambda: flow_pipeline.diffusion(fbl, mk_b, **kw), reps=reps)
+    hole_px = float(hole.float().sum(dim=(1, 2)).mean())
+    fill_info = flow_pipeline.fill_info() if hasattr(flow_pipeline, "fill_info") else {"iters": 1000, "bytes_per_hole_px_iter": 17 * 4}
+    fill_bytes = 2 * (N - 1) * hole_px * fill_info["iters"] * fill_info["bytes_per_hole_px_iter"]
+    st["diffusion_fill"] = {"ms_per_clip": round((dt + dt2) * 1e3, 2), "ms_per_direction": round((dt + dt2) * 5e2, 2), "maps": 4 * (N - 1),
+                            "hole_px_per_map": int(hole_px), "solver": fill_info, "roofline": _hbm((dt + dt2) * 5e2, fill_bytes)}
+    times_ms["diffusion_fill"] = (dt + dt2) * 1e3
+    # ------------------------------------------------------------------ LAFC over both directions
+    dtl, comp_f = _timed(lambda: flow_pipeline.complete_flows(lafc, ffl, mk_f, dif_f), reps=reps)
+    dtl2, comp_b = _timed(lambda: flow_pipeline.complete_flows(lafc, fbl, mk_b, dif_b), reps=reps)
+    ms_flow = (dtl + dtl2) * 1e3 / (2 * (N - 1))
+    st["lafc"] = {"ms_per_flow": round(ms_flow, 3), "flows": 2 * (N - 1), "ms_per_clip": round((dtl + dtl2) * 1e3, 1),
+                  "pipeline": f"{flow_pipeline.LAFC_PIVOT_BATCH} pivots per call",
+                  "roofline": _mfma(ms_flow, GF_LAFC * (H * W) / (240 * 432), prec)}
+    times_ms["lafc"] = (dtl + dtl2) * 1e3
+    # ------------------------------------------------------------------ gradient propagation
+    gx, gy = inp["gx"].to(dev), inp["gy"].to(dev)
+    flf = comp_f.permute(0, 2, 3, 1).contiguous()                               # [N-1,H,W,2]
+    flb = comp_b.permute(0, 2, 3, 1).contiguous()
+    dtp, (pgx, pgy, tofill) = _timed(lambda: propagation.propagate_gradients(gx, gy, hole, flf, flb), reps=reps)
+    prop_bytes = N * H * W * (2 * 3 * 4 * 2 + 1 + 1) + 2 * (N - 1) * H * W * 2 * 4
+    st["gradient_propagation"] = {"ms_per_clip": round(dtp * 1e3, 3), "hole_px_total": int(hole.sum()),
+                                  "roofline": dict(_hbm(dtp * 1e3, prop_bytes), note="gradients in + out, masks, both flow fields once; the stage is a "
+                                                   "chain of per-frame launches (latency-bound), not a streaming pass")}
+    times_ms["gradient_propagation"] = dtp * 1e3
+    # ------------------------------------------------------------------ Poisson blend
+    img = inp["img"].to(dev)
+    trg = img * (~hole)[..., None]
+    kwb = {} if blend_iters is None else {"iters": blend_iters}
+    dtb, (blend, unf) = _timed(lambda: blending.poisson_blend_clip(trg, pgx, pgy, hole, tofill, **kwb), reps=reps)
+    blend_info = blending.blend_info() if hasattr(blending, "blend_info") else {"iters": 2000, "bytes_per_hole_px_iter": 20 * 4}
+    blend_bytes = N * 3 * hole_px * blend_info["iters"] * blend_info["bytes_per_hole_px_iter"]
+    st["poisson_blend"] = {"ms_per_clip": round(dtb * 1e3, 2), "problems": 3 * N, "hole_px_per_frame": int(hole_px), "solver": blend_info,
+                           "roofline": _hbm(dtb * 1e3, blend_bytes)}
+    times_ms["poisson_blend"] = dtb * 1e3
+    if fgt_ms is not None:
+        st["fgt"] = {"ms_per_clip": round(fgt_ms, 2), "note": "the headline of this line (one clip pass)"}
+        times_ms["fgt"] = fgt_ms
+    # ------------------------------------------------------------------ the covered chain
+    chain = ["raft_%dx%d" % (2 * W, 2 * H), "diffusion_fill", "lafc", "gradient_propagation", "poisson_blend"] + (["fgt"] if fgt_ms is not None else [])
+    total = sum(times_ms[k] for k in chain)
+    out["pipeline_frames_per_s"] = {"value": round(N / (total * 1e-3), 2), "unit": "frames/s", "ms_per_clip": round(total, 1),
+                                    "stages_ms": {k: round(times_ms[k], 2) for k in chain},
+                                    "note": f"covered chain for one {N}-frame {W}x{H} clip with RAFT on the 2x input ({2 * W}x{2 * H}: the tool-faithful "
+                                            "size, SURVEY.md §8a a11); stages run back to back on one GPU, inputs resident in HBM"}
+    # ------------------------------------------------------------------ per-kernel HIP-event figures over one pass of the flow stages
+    ops.prof_collect("all")
+    ops.prof_enable(True)
+    flow_pipeline.compute_flows(raft, video[:17], iters=20)
+    flow_pipeline.complete_flows(lafc, ffl[:, :, :16], mk_f[:, :, :16], dif_f[:, :, :16])
+    w_img = img[:16].contiguous()
+    ops.warp(w_img, flf[:16].contiguous())
+    _sync()
+    ops.prof_enable(False)
+    rl = []
+    passes = 3 if prec == "bf16x3" else 1
+    peak = PEAK_FP32 if prec == "fp32" else PEAK_BF16
+    for kind in ("conv", "corr_lookup", "conv_small", "warp", "pointwise"):
+        ms, fl, n, by = ops.prof_collect(kind)
+        if n == 0 or ms <= 0:
+            continue
+        if kind == "conv":
+            rl.append({"kind": "conv (RAFT 16 frames + LAFC 16 flows, as executed)", "bound": "mfma", "achieved": round(passes * fl / ms / 1e9, 2), "peak": peak,
+                       "unit": "TFLOP/s", "frac": round(passes * fl / ms / 1e9 / peak, 4), "algorithmic_tflops": round(fl / ms / 1e9, 2), "launches": n,
+                       "avg_launch_us": round(1e3 * ms / n, 2)})
+        else:
+            rl.append(dict(_hbm(ms, by), kind=kind, launches=n, avg_launch_us=round(1e3 * ms / n, 2)))
+    ops.prof_collect("all")
+    out["rooflines"] = rl
+    # ------------------------------------------------------------------ CPU baselines on bounded samples (oracle = port of the reference)
+    if with_cpu:
+        out["cpu_baseline"] = _cpu_legs(inp, lsd, rsd, N, H, W, comp_f, comp_b, st)
+    ops.DEFAULT_CONV_PRECISION, ops.DEFAULT_ATTN_PRECISION = saved
+    return out
+
+
+def _cpu_legs(inp, lsd, rsd, N, H, W, comp_f, comp_b, st):
+    """Oracle timings on the host cores; every sample is bounded to a few seconds and says what it was."""
+    from fgt_amd import lafc_model
+    from oracle import blend_oracle as BO
+    from oracle import fill_oracle as FO
+    from oracle import lafc_oracle as LO
+    from oracle import prop_oracle as PO
+    from oracle import raft_oracle as RO
+    ncpu = os.cpu_count() or 1
+    th = min(ncpu, 32)
+    torch.set_num_threads(th)
+    cpu = {"cores": th, "host_cores": ncpu, "kind": "port"}
+    hole = inp["hole"]
+    # LAFC: one call (3 flows)
+    fl = inp["flow_f"][:3].permute(1, 0, 2, 3)[None].contiguous()
+    mk = hole[:3].float()[None, None]
+    t0 = time.perf_counter()
+    LO.lafc_forward(lsd, lafc_model.DEFAULT_CONFIG, fl * (1 - mk), mk)
+    dt = time.perf_counter() - t0
+    cpu["lafc"] = {"ms_per_flow": round(dt * 1e3, 1), "sample": "one oracle lafc_forward call (3 flows -> 1 completed flow)",
+                   "gpu_speedup": round(dt * 1e3 / st["lafc"]["ms_per_flow"], 1)}
+    # RAFT: one pair at H x W, 20 iterations (the 2x input costs ~4x)
+    v = inp["video"]
+    t0 = time.perf_counter()
+    RO.raft_forward(rsd, v[0:1], v[1:2], iters=20)
+    dt = time.perf_counter() - t0
+    key = f"raft_{W}x{H}"
+    cpu[key] = {"ms_per_pair": round(dt * 1e3, 1), "sample": f"one oracle raft_forward pair at {W}x{H}, 20 iterations",
+                "gpu_speedup": round(dt * 1e3 / st[key]["ms_per_pair"], 1)}
+    # diffusion fill: 2 maps by scipy spsolve (what the reference runs)
+    t0 = time.perf_counter()
+    for c in range(2):
+        FO.regionfill(inp["flow_f"][0, c].numpy(), hole[0].numpy())
+    dt = (time.perf_counter() - t0) / 2
+    cpu["diffusion_fill"] = {"ms_per_map": round(dt * 1e3, 1), "sample": "oracle regionfill (scipy spsolve) on 2 maps",
+                             "ms_per_clip_extrapolated": round(dt * 1e3 * 4 * (N - 1), 0),
+                             "gpu_speedup": round(dt * 1e3 * 4 * (N - 1) / st["diffusion_fill"]["ms_per_clip"], 1)}
+    # propagation: the first 8 frames (vectorised numpy port; the reference's own per-pixel loop needs minutes)
+    n8 = min(8, N)
+    a = lambda t: np.ascontiguousarray(t.numpy())
+    t0 = time.perf_counter()
+    PO.get_flownn_gradient(a(inp["gx"][:n8]), a(inp["gy"][:n8]), a(hole[:n8]), a(comp_f[: n8 - 1].permute(0, 2, 3, 1).cpu()), a(comp_b[: n8 - 1].permute(0, 2, 3, 1).cpu()))
+    dt = time.perf_counter() - t0
+    cpu["gradient_propagation"] = {"ms_per_clip_extrapolated": round(dt * 1e3 * N / n8, 0), "sample": f"oracle get_flownn_gradient (vectorised numpy) on the first {n8} frames, scaled by frames",
+                                   "gpu_speedup": round(dt * 1e3 * N / n8 / st["gradient_propagation"]["ms_per_clip"], 1)}
+    # Poisson blend: one frame, one channel-set by scipy LSQR (the reference's solver)
+    im = a(inp["img"][0])
+    h0 = a(hole[0])
+    trg = im * (~h0)[..., None]
+    gx = a(inp["gx"][0])[:, : W - 1]
+    gy = a(inp["gy"][0])[: H - 1]
+    t0 = time.perf_counter()
+    BO.poisson_blend(trg, gx, gy, h0, np.zeros_like(h0), tight=False)
+    dt = time.perf_counter() - t0
+    cpu["poisson_blend"] = {"ms_per_frame": round(dt * 1e3, 1), "sample": "oracle poisson_blend (scipy LSQR at the reference's tolerances) on one frame (3 channels)",
+                            "ms_per_clip_extrapolated": round(dt * 1e3 * N, 0), "gpu_speedup": round(dt * 1e3 * N / st["poisson_blend"]["ms_per_clip"], 1)}
+    return cpu

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FGT_HIP_LIB: diagnostic builds of the same library (tools/conv_trace.py); there is still no fallback — a missing file raises.
 LIB_PATH = os.environ.get("FGT_HIP_LIB") or os.path.join(_HERE, "lib", "libfgt_hip.so")
 
-ABI_VERSION = 5        # include/fgt_hip.h: what fgt_abi_version() of a matching build returns
+ABI_VERSION = 6        # include/fgt_hip.h: what fgt_abi_version() of a matching build returns
 
 ACT = {"none": 0, None: 0, "lrelu": 1, "relu": 2, "sigmoid": 3, "tanh": 4}
 EPI = {"none": 0, None: 0, "mul": 1, "add": 2, "gru": 3}

@@ -13,13 +13,22 @@ import torch
 from . import ops
 
 
-def poisson_blend_clip(target, gradient_x, gradient_y, hole, gradient_mask, iters=2000, tol=1e-7):
+BLEND_ITERS = 2000           # CG iterations (fixed count, per-problem freeze at tol * |r0|)
+
+
+def blend_info():
+    """What one clip blend does per hole pixel (bench accounting): solver, iteration count, algorithmic bytes per iteration."""
+    return {"solver": "conjugate gradients on the normal equations of the reference's least-squares system (csrc/poisson_blend.hip)",
+            "iters": BLEND_ITERS, "bytes_per_hole_px_iter": 20 * 4}
+
+
+def poisson_blend_clip(target, gradient_x, gradient_y, hole, gradient_mask, iters=BLEND_ITERS, tol=1e-7):
     """target, gradient_x, gradient_y [N,H,W,3] fp32 device tensors (gradient_x[..., x, :] = I[x+1] - I[x]); hole, gradient_mask
     [N,H,W].  Returns (blend [N,H,W,3], UnfilledMask [N,H,W] bool)."""
     return ops.poisson_blend(target, gradient_x, gradient_y, hole, gradient_mask, iters, tol)
 
 
-def Poisson_blend_img(imgTrg, imgSrc_gx, imgSrc_gy, holeMask, gradientMask=None, edge=None, device="cuda", iters=2000, tol=1e-7):
+def Poisson_blend_img(imgTrg, imgSrc_gx, imgSrc_gy, holeMask, gradientMask=None, edge=None, device="cuda", iters=BLEND_ITERS, tol=1e-7):
     """Reference signature / layouts (tool/utils/Poisson_blend_img.py:19-75) for one frame."""
     if isinstance(edge, np.ndarray) and edge.any():
         raise NotImplementedError("edge constraints are not built (the tool always passes edge=None)")

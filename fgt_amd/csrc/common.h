@@ -16,6 +16,16 @@ bool fgt_prof_on();
 int fgt_prof_begin(int kind, double flops, double bytes, hipStream_t s);
 void fgt_prof_end(int idx, hipStream_t s);
 
+// brackets the launches of one C-ABI call with an event pair (no-op unless fgt_prof_enable(1)); `bytes` = algorithmic bytes of the call
+struct FgtProfScope {
+    int idx;
+    hipStream_t s;
+    FgtProfScope(int kind, double flops, double bytes, void* stream) : idx(fgt_prof_begin(kind, flops, bytes, (hipStream_t)stream)), s((hipStream_t)stream) {}
+    ~FgtProfScope() { fgt_prof_end(idx, s); }
+    FgtProfScope(const FgtProfScope&) = delete;
+    FgtProfScope& operator=(const FgtProfScope&) = delete;
+};
+
 #define FGT_REQUIRE(cond, ...)          \
     do {                                \
         if (!(cond)) {                  \

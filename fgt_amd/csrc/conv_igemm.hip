@@ -407,7 +407,8 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     const double conv_bytes = in_b * ((double)d.N * d.H * d.W * (d.C0 + d.C1) + (double)d.Cout * p.K) +
                               (double)M * d.Cout * ((d.out_split != 1 ? 4.0 : 0.0) + (d.out_split ? os_b : 0.0) +
                                                     4.0 * ((d.epi != FGT_EPI_NONE ? 1 : 0) + (d.epi == FGT_EPI_GRU ? 1 : 0)));
-    const int prof = direct ? -1 : fgt_prof_begin(FGT_PROF_CONV, 2.0 * (double)M * p.Cout_g * (d.k_alg > 0 ? d.k_alg : p.K) * d.groups, conv_bytes, s);
+    // (Cout <= 4 VALU kernels: an HBM-bound pass over the input map — their own kind, bytes only)
+    const int prof = direct ? fgt_prof_begin(FGT_PROF_CONV_SMALL, 0.0, conv_bytes, s) : fgt_prof_begin(FGT_PROF_CONV, 2.0 * (double)M * p.Cout_g * (d.k_alg > 0 ? d.k_alg : p.K) * d.groups, conv_bytes, s);
     int rc;
     if (direct) rc = fgt_conv_direct(p, s);   // Cout <= 4: VALU direct conv (fp32)
     else if (d.in_split == 3) rc = fgt_conv_f16_launch(tile, p, s);

@@ -220,6 +220,7 @@ __global__ void __launch_bounds__(256) in_apply_kernel(const float* x, int ld, i
 extern "C" int fgt_warp(const float* img, int ldi, const float* flow, int B, int H, int W, int C, int align_corners,
                         int absolute_coords, float* out, int ldo, void* stream) {
     FGT_REQUIRE(img && flow && out && B > 0 && H > 1 && W > 1 && C > 0, "fgt_warp: bad arguments");
+    FgtProfScope prof(FGT_PROF_WARP, 0.0, 4.0 * (double)B * H * W * (2.0 * C + 2.0), stream);
     hipLaunchKernelGGL(warp_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, img, ldi, flow, B, H, W, C,
                        align_corners, absolute_coords, out, ldo);
     return fgt_check_launch("warp");
@@ -246,6 +247,7 @@ extern "C" int fgt_corr_lookup(const float* const* pyr, int levels, int B, int H
     for (int l = 0; l < levels; ++l) { FGT_REQUIRE(pyr[l], "fgt_corr_lookup: null level"); pp.p[l] = pyr[l]; }
     FGT_REQUIRE((H1 >> (levels - 1)) >= 2 && (W1 >> (levels - 1)) >= 2, "fgt_corr_lookup: coarsest level smaller than 2x2");
     const long total = (long)B * H1 * W1 * levels * (2 * radius + 1) * (2 * radius + 1);
+    FgtProfScope prof(FGT_PROF_CORR_LOOKUP, 0.0, (double)B * H1 * W1 * (4.0 * levels * ((2 * radius + 2) * (2 * radius + 2) + (2 * radius + 1) * (2 * radius + 1)) + 8.0), stream);
     hipLaunchKernelGGL(corr_lookup_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, pp, levels, B, H1, W1, radius,
                        coords, out, ldo);
     return fgt_check_launch("corr_lookup");

@@ -430,6 +430,8 @@ extern "C" int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, 
                 "fgt_layernorm: strides must be multiples of 4 floats");
     FGT_REQUIRE((psA == -1 || (psA >= 0 && psA % 4 == 0)) && (psB == -1 || (psB >= 0 && psB % 4 == 0)),
                 "fgt_layernorm: plane strides must be non-negative multiples of 4 (or -1: fp16 plane)");
+    const auto ob = [](long long ps) { return ps < 0 ? 2.0 : 4.0; };
+    FgtProfScope prof(FGT_PROF_LAYERNORM, 0.0, (double)rows * ((C0 + C1) * 4.0 + (C0 + C1) * (ob(psA) + (outB ? ob(psB) : 0.0))), stream);
     hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, rows,
                        eps, gA, bA, outA, ldA, gB, bB, outB, ldB, (long)psA, (long)psB);
     return fgt_check_launch("layernorm");
@@ -442,6 +444,7 @@ extern "C" int fgt_dw_pool(const float* x0, int C0, int ld0, const float* x1, in
     FGT_REQUIRE(C0 % 4 == 0 && C1 % 4 == 0 && ld0 % 4 == 0 && (C1 == 0 || (x1 && ld1 % 4 == 0)) && ldo % 4 == 0, "fgt_dw_pool: alignment");
     FGT_REQUIRE(k > 0 && nh % k == 0 && nw % k == 0, "fgt_dw_pool: grid %dx%d not divisible by %d", nh, nw, k);
     const long total = (long)bt * (nh / k) * (nw / k) * ((C0 + C1) / 4);
+    FgtProfScope prof(FGT_PROF_DW_POOL, 0.0, 4.0 * (C0 + C1) * ((double)bt * vh * vw + (double)k * k + 1.0 + (double)bt * (nh / k) * (nw / k)), stream);
     if (k == 4 && (((uintptr_t)w | (uintptr_t)bias) & 15) == 0)
         hipLaunchKernelGGL(dw_pool4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, bt, nh,
                            nw, vh, vw, w, bias, out, ldo);
@@ -456,6 +459,7 @@ extern "C" int fgt_dw3x3_residual(const float* x, int bt, int h, int w, int C, c
     FGT_REQUIRE(x && wgt && bias && out && C % 4 == 0, "fgt_dw3x3_residual: bad arguments");
     FGT_REQUIRE(((uintptr_t)wgt & 15) == 0, "fgt_dw3x3_residual: weights must be 16-byte aligned");
     const long total = (long)bt * h * w * (C / 4);
+    FgtProfScope prof(FGT_PROF_POINTWISE, 0.0, 8.0 * (double)bt * h * w * C, stream);
     hipLaunchKernelGGL(dw3x3_res_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, bt, h, w, C, wgt, bias, out);
     return fgt_check_launch("dw3x3_residual");
 }
@@ -467,6 +471,8 @@ extern "C" int fgt_fold(const float* Y, int ldy, int frames, int th, int tw, int
     const long total = (long)frames * Hf * Wf * (C / 4);
     FGT_REQUIRE(ps_out == -1 || (ps_out >= 0 && ps_out % 4 == 0), "fgt_fold: plane stride must be a non-negative multiple of 4 (or -1: fp16 plane)");
     FGT_REQUIRE(y_f16 == 0 || y_f16 == 1, "fgt_fold: y_f16 must be 0 or 1");
+    FgtProfScope prof(FGT_PROF_FOLD, 0.0, (double)frames * th * tw * k * k * C * (y_f16 ? 2.0 : 4.0) +
+                                              (double)frames * Hf * Wf * C * ((ps_out < 0 ? 2.0 : 4.0) + (res ? 4.0 : 0.0)), stream);
     if (y_f16)
         hipLaunchKernelGGL(fold_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, Y, ldy, frames, th, tw, C, k, s, p,
                            Hf, Wf, normalize, res, ldres, out, ldo, relu, (long)ps_out);
@@ -479,6 +485,7 @@ extern "C" int fgt_fold(const float* Y, int ldy, int frames, int th, int tw, int
 extern "C" int fgt_nchw_to_nhwc(const float* src, int N, int C, int H, int W, float* dst, int ldd, int coff, int zero_to,
                                 float scale, float shift, void* stream) {
     FGT_REQUIRE(src && dst && C > 0, "fgt_nchw_to_nhwc: bad arguments");
+    FgtProfScope prof(FGT_PROF_POINTWISE, 0.0, 4.0 * (double)N * H * W * (C + (zero_to > C ? zero_to : C)), stream);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, src, N, C, H, W,
                        dst, ldd, coff, zero_to, scale, shift);
     return fgt_check_launch("nchw_to_nhwc");
@@ -486,6 +493,7 @@ extern "C" int fgt_nchw_to_nhwc(const float* src, int N, int C, int H, int W, fl
 
 extern "C" int fgt_nhwc_to_nchw(const float* src, int lds, int coff, int N, int C, int H, int W, float* dst, void* stream) {
     FGT_REQUIRE(src && dst && C > 0, "fgt_nhwc_to_nchw: bad arguments");
+    FgtProfScope prof(FGT_PROF_POINTWISE, 0.0, 8.0 * (double)N * H * W * C, stream);
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, src, lds, coff, N,
                        C, H, W, dst);
     return fgt_check_launch("nhwc_to_nchw");
@@ -495,6 +503,7 @@ extern "C" int fgt_pad_tokens(const float* src, int lds, int bt, int h, int w, i
                               void* stream) {
     FGT_REQUIRE(src && dst && C % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0, "fgt_pad_tokens: bad arguments");
     const long total = (long)bt * nh * nw * (C / 4);
+    FgtProfScope prof(FGT_PROF_POINTWISE, 0.0, 4.0 * C * ((double)bt * (h < nh ? h : nh) * (w < nw ? w : nw) + (double)bt * nh * nw), stream);
     hipLaunchKernelGGL(pad_tokens_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, lds, bt, h, w, C, nh, nw,
                        dst, ldd);
     return fgt_check_launch("pad_tokens");
@@ -503,6 +512,7 @@ extern "C" int fgt_pad_tokens(const float* src, int lds, int bt, int h, int w, i
 extern "C" int fgt_axpby(const float* a, int lda, float sa, const float* b, int ldb, float sb, long rows, int C, int act,
                          float slope, float* out, int ldo, void* stream) {
     FGT_REQUIRE(a && out && rows > 0 && C > 0, "fgt_axpby: bad arguments");
+    FgtProfScope prof(FGT_PROF_POINTWISE, 0.0, 4.0 * (double)rows * C * (b ? 3.0 : 2.0), stream);
     hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, a, lda, sa, b, ldb, sb, rows, C,
                        act, slope, out, ldo);
     return fgt_check_launch("axpby");
@@ -536,6 +546,7 @@ extern "C" int fgt_pack_frames(const float* frames01, const float* masks, const 
                                void* stream) {
     FGT_REQUIRE(frames01 && masks && dst && n > 0 && H > 0 && W > 0, "fgt_pack_frames: bad arguments");
     FGT_REQUIRE(ldd >= 4 && ldd % 4 == 0 && ((uintptr_t)dst & 15) == 0, "fgt_pack_frames: dst must be float4 aligned with ldd %% 4 == 0");
+    FgtProfScope prof(FGT_PROF_POINTWISE, 0.0, 4.0 * (double)n * H * W * 8.0, stream);
     hipLaunchKernelGGL(pack_frames_kernel, dim3(grid_for((long)n * H * W)), dim3(256), 0, (hipStream_t)stream, frames01, masks, ids, n,
                        (long)H * W, dst, ldd);
     return fgt_check_launch("pack_frames");
@@ -551,6 +562,7 @@ extern "C" int fgt_gather_rows(const float* src, long ld_src, const int* ids, in
     FGT_REQUIRE(src && ids && dst && n > 0 && row_len > 0, "fgt_gather_rows: bad arguments");
     FGT_REQUIRE(row_len % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0,
                 "fgt_gather_rows: rows must be float4 aligned");
+    FgtProfScope prof(FGT_PROF_POINTWISE, 0.0, 8.0 * (double)n * row_len, stream);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)n * (row_len / 4))), dim3(256), 0, (hipStream_t)stream, src, ld_src, ids, n,
                        row_len / 4, dst, ld_dst);
     return fgt_check_launch("gather_rows");
@@ -560,6 +572,7 @@ extern "C" int fgt_split(const float* x, long rows, int C, int ldx, void* out_s,
     FGT_REQUIRE(x && out_s && rows > 0 && C > 0, "fgt_split: bad arguments");
     FGT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ld_s % 4 == 0 && (ps == -1 || (ps > 0 && ps % 4 == 0)) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out_s & 7) == 0,
                 "fgt_split: C, strides must be multiples of 4 and pointers aligned");
+    FgtProfScope prof(FGT_PROF_POINTWISE, 0.0, (double)rows * C * (4.0 + (ps < 0 ? 2.0 : 4.0)), stream);
     hipLaunchKernelGGL(split_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, rows, C / 4, ldx,
                        static_cast<__bf16*>(out_s), ld_s, (long)ps, relu);
     return fgt_check_launch("split");

@@ -13,7 +13,18 @@ import torch
 from . import ops
 
 
-def compute_flows(raft, frames, iters=20, batch=8, enc_batch=16):
+RAFT_PAIR_BATCH = 8          # pairs per RAFT refinement batch (forward and backward pairs mixed)
+LAFC_PIVOT_BATCH = 8         # pivots per LAFC call
+FILL_ITERS = 1000            # CG iterations of the diffusion fill (fixed count, per-map freeze at tol * |r0|)
+
+
+def fill_info():
+    """What one diffusion-fill call does per hole pixel (bench accounting): solver, iteration count, algorithmic bytes per iteration."""
+    return {"solver": "conjugate gradients on the masked 5-point Laplacian (csrc/laplace_fill.hip)", "iters": FILL_ITERS,
+            "bytes_per_hole_px_iter": 17 * 4}
+
+
+def compute_flows(raft, frames, iters=20, batch=RAFT_PAIR_BATCH, enc_batch=16):
     """frames [N,3,H,W] in 0..255 (H, W multiples of 8) -> (forward [N-1,2,H,W], backward [N-1,2,H,W]).
     forward[i] = RAFT(frame i, frame i+1), backward[i] = RAFT(frame i+1, frame i)  (tool/video_inpainting.py:246-263)."""
     N = frames.shape[0]
@@ -49,7 +60,7 @@ def indices_gen(pivot, interval, frames, t):
     return out
 
 
-def diffusion(flows, masks, iters=1000, tol=1e-6):
+def diffusion(flows, masks, iters=FILL_ITERS, tol=1e-6):
     """`diffusion()` of tool/video_inpainting.py:42-51 (rf.regionfill per flow and channel, tool/utils/region_fill.py:7-63) for the
     whole clip in one call: flows [1,2,t,H,W], masks [1,1,t,H,W] (non-zero = hole) -> diffused flows [1,2,t,H,W].
     All 2t maps are solved together on the GPU (ops.laplace_fill); map (c, i) uses mask i."""
@@ -58,7 +69,7 @@ def diffusion(flows, masks, iters=1000, tol=1e-6):
     return out.view(1, c, t, H, W)
 
 
-def complete_flows(lafc, flows, masks, diffused=None, num_flows=3, interval=3, batch=8):
+def complete_flows(lafc, flows, masks, diffused=None, num_flows=3, interval=3, batch=LAFC_PIVOT_BATCH):
     """`complete_flow` of tool/video_inpainting.py:341-386: diffusion fill (when `diffused` is not given) + the LAFC loop of
     :367-384 with `batch` pivots per LAFC call.
     flows, diffused [1,2,t,H,W]; masks [1,1,t,H,W] (already sliced for the direction, :350-353).  Returns [t,2,H,W]:

@@ -821,7 +821,8 @@ def prof_is_enabled():
     return _prof_on
 
 
-PROF_KINDS = {"conv": 0, "attn_temporal": 1, "attn_spatial": 2, "all": -1}
+PROF_KINDS = {"conv": 0, "attn_temporal": 1, "attn_spatial": 2, "layernorm": 3, "fold": 4, "conv_small": 5, "dw_pool": 6, "warp": 7,
+              "corr_lookup": 8, "pointwise": 9, "all": -1}
 
 
 def prof_collect(kind="conv"):

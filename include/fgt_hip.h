@@ -376,6 +376,23 @@ int fgt_poisson_blend(const float* target, const float* gx, const float* gy, con
 #define FGT_PROF_CONV 0
 #define FGT_PROF_ATTN_TEMPORAL 1
 #define FGT_PROF_ATTN_SPATIAL 2
+/* HBM-bound kernels (ABI 6): records carry 0 flops and the launch's ALGORITHMIC bytes — every input / output byte once, the
+ * SURVEY.md §8(d) formulas — so that bytes / event time is the figure to hold against the 8 TB/s HBM roof:
+ *   LAYERNORM    rows * (C_in * 4 + sum over outputs of C * {4: fp32 or hi + lo, 2: fp16})
+ *   FOLD         token matrix once (frames*th*tw*k*k*C * {4 | 2}) + output map (+ residual map)
+ *   CONV_SMALL   Cout <= 4 VALU convs (decoder.final 64 -> 3, LAFC 24 -> 2, RAFT flow head): input map + weights + output
+ *   DW_POOL      real input tokens * C * 4 + weights + output tokens * C * 4
+ *   WARP         (2C + 2) * B*H*W * 4   (image_warp: image in, flow in, image out)
+ *   CORR_LOOKUP  per query pixel: levels * (2r+2)^2 * 4 gathered + 8 (coords) + levels * (2r+1)^2 * 4 written
+ *   POINTWISE    everything else that is one pass over its data (row gathers, fp32 -> split, pad / crop, 3x3 position embedding,
+ *                axpby, layout packing): bytes in + bytes out */
+#define FGT_PROF_LAYERNORM 3
+#define FGT_PROF_FOLD 4
+#define FGT_PROF_CONV_SMALL 5
+#define FGT_PROF_DW_POOL 6
+#define FGT_PROF_WARP 7
+#define FGT_PROF_CORR_LOOKUP 8
+#define FGT_PROF_POINTWISE 9
 void fgt_prof_enable(int on);
 int fgt_prof_collect_kind(int kind, double* total_ms, double* total_flops, double* total_bytes, long* launches);
 int fgt_prof_collect(double* total_ms, double* total_flops, long* launches); /* = kind FGT_PROF_CONV */

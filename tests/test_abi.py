@@ -25,7 +25,7 @@ def test_library_exports_every_symbol():
     h = ctypes.CDLL(_lib.LIB_PATH)
     for s in declared_symbols():
         assert hasattr(h, s), f"{s} not exported"
-    assert _lib.lib().fgt_abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.lib().fgt_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_struct_sizes_match_header():

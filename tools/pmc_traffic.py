@@ -19,7 +19,7 @@ from collections import defaultdict
 
 
 def kind_of(name):
-    if "conv_split_kernel" in name or "conv_igemm_kernel" in name or "conv_f16" in name:
+    if "conv_split_kernel" in name or "conv_igemm_kernel" in name or "conv_f16" in name or "conv_wide" in name:
         return "conv"
     if "attn_" in name:
         # spatial windows run the 2-wavefront instances (64 queries), temporal zones the 4- / 8-wavefront ones
@@ -63,6 +63,9 @@ def main():
         head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     except Exception:
         head = ""
+    if not head:        # the GPU box gets a snapshot without .git: tools/gpu.sh writes the head of the snapshot into .git_head
+        hf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".git_head")
+        head = open(hf).read().strip() if os.path.exists(hf) else ""
     entry = {"command": note, "git_head": head, "templates": templates,
              "note": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KiB -> bytes, per launch"}
     for k, v in kinds.items():
