@@ -634,7 +634,7 @@ int fgt_attention_split(const fgt_attn_desc* dd, const void* Q, const void* K, c
     static const int nw_long = [] { const char* e = getenv("FGT_ATTN_SPLIT_NW"); return e ? atoi(e) : 8; }();
     const bool big = n_q >= 2048 && nw_long == 8;
     if (h16) {
-        static const int prefetch = [] { const char* e = getenv("FGT_ATTN_PREFETCH"); return e ? atoi(e) : 0; }();
+        static const int prefetch = [] { const char* e = getenv("FGT_ATTN_PREFETCH"); return e ? atoi(e) : 1; }();
         if (n_q <= 64) return launch<2, true>(p, problems, s);
         if (big && prefetch && d.mode == 0 && n_k >= 4 * KT) return launch_prefetch(p, problems, s);
         if (big) return launch<8, true>(p, problems, s);

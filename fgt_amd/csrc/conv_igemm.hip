@@ -412,6 +412,10 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     int rc;
     if (direct) rc = fgt_conv_direct(p, s);   // Cout <= 4: VALU direct conv (fp32)
     else if (d.in_split == 3) rc = fgt_conv_f16_launch(tile, p, s);
+    else if (d.in_split == 2 && tile >= FGT_TILE_WIDE) {
+        if (d.w_il != 1 || d.Kpad != p.K) { fgt_set_error("fgt_conv2d: the wide bf16x3 tiles need interleaved weights (w_il = 1) and K %% 32 == 0"); rc = FGT_EINVAL; }
+        else rc = fgt_conv_wide_launch(tile - FGT_TILE_WIDE, p, s);
+    }
     else if (d.in_split) rc = fgt_conv_split_launch(tile, p, s);
     else if (tile >= FGT_TILE_256x128x8_S3) { fgt_set_error("fgt_conv2d: tile %d needs split inputs", tile); rc = FGT_EINVAL; }
     else rc = d.precision == 0 ? launch_tile<0>(tile, p, s) : launch_tile<1>(tile, p, s);

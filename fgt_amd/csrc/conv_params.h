@@ -20,6 +20,9 @@ const float* fgt_zero_page();
 // conv_split.hip: bf16x3 with pre-split inputs moved global -> LDS by LDS-DMA
 int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s);
 
+// conv_wide.hip: bf16x3 on interleaved pre-split inputs (in_split = 2, w_il = 1) with full-line LDS-DMA pieces; `tile` = tile code - 100
+int fgt_conv_wide_launch(int tile, const ConvP& p, hipStream_t s);
+
 // conv_f16.hip: FGT_PREC_F16 — fp16 inputs (one plane) through LDS-DMA, one MFMA per product
 int fgt_conv_f16_launch(int tile, const ConvP& p, hipStream_t s);
 

@@ -1,6 +1,7 @@
 // Pieces shared by the implicit-GEMM kernels (conv_igemm.hip: register-staged fp32 inputs; conv_split.hip: pre-split bf16
 // inputs through LDS-DMA): LDS tile geometry, the hi/lo split, the XCD-aware tile order and the fused epilogue.
 #pragma once
+#include <utility>
 #include "common.h"
 #include "conv_params.h"
 
@@ -37,6 +38,18 @@ __device__ __forceinline__ bool conv_tile_index(const ConvP& p, int& m_idx, int&
     m_idx = blockIdx.x % p.mtiles;
     n_idx = blockIdx.x / p.mtiles;
     return true;
+}
+
+// A loop over 0..N-1 whose index is a compile-time constant in the body.  `#pragma unroll` is a request hipcc may decline ("unrolled
+// size is too large" for the row-block loop of the epilogue with 8 accumulator tiles per wavefront): the accumulator array was then
+// indexed at run time and lived in scratch memory around the epilogue.
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
 // ---- epilogue.  The accumulators go through LDS (the tile buffers are free now) so that the global side is a compact,
@@ -81,8 +94,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 sc = (p.cscale && col_ok) ? *reinterpret_cast<const float4*>(p.cscale + co) : one;
         const float4 bi = (p.cbias && col_ok) ? *reinterpret_cast<const float4*>(p.cbias + co) : zero;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        static_for<TM>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -142,7 +155,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 }
             }
             __builtin_amdgcn_wave_barrier();                           // the patch is rewritten by the next row block
-        }
+        });
         return;
     }
 

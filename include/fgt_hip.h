@@ -154,6 +154,10 @@ typedef struct fgt_conv_desc {
 #define FGT_TILE_128x128_LW 33    /* B tile: address arithmetic + LDS-DMA issue only) next to the 8 / 4 consumer wavefronts (fragment reads + MFMAs): */
 #define FGT_TILE_128x64_LW 34     /* the DMA issue no longer sits in front of the MFMAs of the same wavefront.  Bit-identical results; measured slower. */
 #define FGT_TILE_256x128_EA 38   /* FGT_PREC_F16 only: 256x128 on 8 wavefronts of 64x64 with early stage release */
+#define FGT_TILE_WIDE 100        /* tile code + 100 = the same tile on the "wide" LDS image: a stage row is one full 128-byte line per pixel and
+                                  * K-step, an LDS-DMA instruction copies 8 full cache lines instead of 16 half lines.  FGT_PREC_F16 (below) and, since
+                                  * ABI 6, FGT_PREC_BF16X3 with INTERLEAVED inputs (in_split = 2, w_il = 1: csrc/conv_wide.hip; codes 1-8, 26-31, 38 and the
+                                  * 8-phase tiles 17 / 18).  Bit-identical results. */
 #define FGT_TILE_F16_WIDE 100    /* FGT_PREC_F16 only: tile code + 100 = the same tile on the "wide" LDS image (a stage row is the pixel's whole
                                   * 128-byte line of the 64-channel K-step; an LDS-DMA instruction copies 8 full cache lines instead of 16 half
                                   * lines).  Codes 1-8, 26-31 and 38.  Bit-identical results. */

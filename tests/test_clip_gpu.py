@@ -134,3 +134,37 @@ def test_cliprunner_model_without_mask_channel(dev):
     a = ClipRunner(m, fr, fl, ms, cache_features=True).run()
     b = ClipRunner(m, fr, fl, ms, cache_features=False).run()
     assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ the bench clip itself
+@pytest.fixture(scope="module")
+def clip80(dev):
+    """The 432x240x80 clip bench.py times (synth_clip seed 1234, trained 20x36 token grid, 16 windows of t = 13 / 17 / 18) through the CPU
+    oracle of the tool's loop: ~45 TFLOP on the host cores, once per test session."""
+    import os
+    m, sd, cfg = _model(dev)
+    fr, fl, ms = synth_clip(80, 240, 432, seed=1234)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    ref = O.fgt_clip(sd, cfg, fr, fl, ms)
+    return m, (fr.to(dev), fl.to(dev), ms.to(dev)), ref
+
+
+@pytest.mark.parametrize("prec,max_rate", [("fp32", 3e-4), ("bf16x3", 2e-2)])
+def test_bench_clip_432x240x80_full_geometry_matches_oracle_clip(prec, max_rate, clip80, monkeypatch):
+    """`ClipRunner(cache, batch 8, pruned last pair)` — exactly the runner and clip of the bench headline — against `oracle.fgt_clip`:
+    batch-8 groups of t = 17 / 18 windows on the trained grid, the composite of all 16 windows.  Every difference <= 1 uint8 step
+    (a value on an integer boundary of (x+1)/2*255 flips with a 1e-7 change), the rate of differing values bounded by the arithmetic."""
+    from fgt_amd import ops
+    from fgt_amd.scheduler import ClipRunner
+    monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", prec)
+    monkeypatch.setattr(ops, "DEFAULT_ATTN_PRECISION", prec)
+    m, (fr, fl, ms), ref = clip80
+    r = ClipRunner(m, fr, fl, ms, cache_features=True, window_batch=8)
+    assert sorted(len(g) for g in r.groups) == [1, 7, 8] and all(tq is not None for tq in r._group_tq)
+    got = r.run().cpu()
+    d = (got - ref).abs()
+    rate = (d > 0).float().mean().item()
+    print(f"[parity] bench clip 432x240x80 ClipRunner(cache, batch 8, pruned, {prec}) vs oracle.fgt_clip: max diff {d.max().item()} uint8 steps, "
+          f"differing values {rate:.3e} of {d.numel()}, PSNR {O.psnr(got.to(torch.uint8).float(), ref.to(torch.uint8).float()):.1f} dB")
+    assert d.max().item() <= 1.0
+    assert rate < max_rate

@@ -210,6 +210,58 @@ def test_conv_interleaved_two_source_and_out_il(dev):
                    ops.PackedConv(_rand(16, 40, 3, 3, seed=2).to(dev), None), pad=1, precision="bf16x3", tile="64x64")
 
 
+# ---- wide LDS image (csrc/conv_wide.hip): interleaved inputs + interleaved weights, 8-row x 128-byte LDS-DMA pieces, 8-phase tiles
+WIDE_TILES = ["128x128w", "128x64w", "64x64w", "128x32w", "256x128w", "128x128x8w", "256x128x16w", "256x64x8w", "128x128eaw", "128x64eaw", "64x64eaw",
+              "128x128x8eaw", "256x128x16eaw", "256x64x8eaw", "256x128eaw", "256x256p8w", "256x128p8w"]
+WIDE_CASES = IL_CASES + [
+    ("3x3_cin256_cout384", 1, 20, 36, 256, 384, 3, 1, 1, 1, 1),      # several K-steps per tap, N tile past Npad for the 256-wide tiles
+    ("1x1_k768_rows_not_tile_multiple", 1, 1, 1111, 768, 512, 1, 1, 0, 1, 1),
+    ("7x7_s3_cin128", 1, 30, 45, 128, 256, 7, 3, 3, 1, 1),
+    ("3x3_g2_cin64", 2, 13, 21, 128, 64, 3, 1, 1, 1, 2),
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=[c[0] for c in WIDE_CASES])
+@pytest.mark.parametrize("tile", WIDE_TILES)
+def test_conv_wide_tiles_bit_equal(case, tile, dev):
+    from fgt_amd import ops
+    name, N, H, W, Cin, Cout, k, s, p, d, g = case
+    kh, kw = (k, k) if isinstance(k, int) else k
+    x = _rand(N, H, W, Cin, seed=1).to(dev)
+    w = _rand(Cout, Cin // g, kh, kw, seed=2, scale=1.0 / math.sqrt(Cin // g * kh * kw))
+    pc = ops.PackedConv(w.to(dev), _rand(Cout, seed=3).to(dev), groups=g)
+    ref = ops.conv2d(x, pc, stride=s, pad=p, dil=d, act="lrelu", tile="128x128", precision="bf16x3")
+    got = ops.conv2d(ops.split(x, interleave=True), pc, stride=s, pad=p, dil=d, act="lrelu", tile=tile, precision="bf16x3")
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref), f"{name} tile={tile}: max diff {(got - ref).abs().max().item():.3e}"
+
+
+def test_conv_wide_two_source_upsample_replicate_out_il(dev):
+    """The wave-uniform (tap, source, channel) walk of the wide kernel: group-interleaved two-source concat, nearest-x2 upsample,
+    replicate padding, dilation; interleaved split output feeding another wide conv; planes inputs and planes weights are rejected."""
+    from fgt_amd import ops
+    N, H, W = 2, 15, 27
+    x0, o = _rand(N, H, W, 256, seed=1).to(dev), _rand(N, H, W, 384, seed=2).to(dev)
+    for g, cout in ((2, 512), (4, 384)):
+        w, b = _rand(cout, 640 // g, 3, 3, seed=3, scale=0.05), _rand(cout, seed=4)
+        pc = ops.PackedConv(w.to(dev), b.to(dev), groups=g)
+        ref = ops.conv2d(x0, pc, x1=o, stride=1, pad=1, act="lrelu", precision="bf16x3")
+        for tile in ("128x128x8eaw", "64x64w", "256x256p8w", "256x128p8w", "128x128w"):
+            r32, rs = ops.conv2d(ops.split(x0, interleave=True), pc, x1=ops.split(o, interleave=True), stride=1, pad=1, act="lrelu",
+                                 precision="bf16x3", tile=tile, out_split="both", out_il=True)
+            assert torch.equal(r32, ref), (g, tile)
+            assert torch.equal(rs.data, ops.split(ref, interleave=True).data), (g, tile)
+    x = _rand(1, 12, 20, 64, seed=5).to(dev)
+    w2, b2 = _rand(48, 64, 3, 3, seed=6, scale=0.1), _rand(48, seed=7)
+    pc2 = ops.PackedConv(w2.to(dev), b2.to(dev))
+    for kw in (dict(upsample=True, pad=1), dict(pad=2, pad_mode="replicate", dil=2), dict(stride=2, pad=1)):
+        ref = ops.conv2d(x, pc2, precision="bf16x3", **kw)
+        for tile in ("64x64eaw", "128x64w", "256x128p8w"):
+            assert torch.equal(ops.conv2d(ops.split(x, interleave=True), pc2, precision="bf16x3", tile=tile, **kw), ref), (kw, tile)
+    with pytest.raises(RuntimeError, match="not built|unknown tile|wide"):
+        ops.conv2d(ops.split(x), pc2, pad=1, precision="bf16x3", tile="128x128w")         # planes input on a wide tile
+
+
 # ---- fused producers of split tensors: LayerNorm, attention, fold (the GEMM operands of the transformer blocks)
 def _same_split(sp, ref32):
     from fgt_amd import ops

@@ -85,14 +85,19 @@ def main():
         cells = []
         for t in TILES:
             o1, o2 = torch.empty_like(out), torch.empty_like(out)
-            if t.endswith(("s3", "s4", "pp", "il", "p8", "p8n", "p8l", "ea", "lw", "xy")) or t.startswith("x2") or a.split_only:        # split inputs only
+            if t.endswith(("s3", "s4", "pp", "il", "p8", "p8n", "p8l", "ea", "lw", "xy", "w")) or t.startswith("x2") or a.split_only:        # split inputs only
                 ops.conv2d(x, pc, x1=x1, stride=s, pad=p, act="lrelu", tile="128x128", precision="bf16x3", out=o1)
                 ms_a = float("inf")
             else:
                 ms_a = bench(lambda: ops.conv2d(x, pc, x1=x1, stride=s, pad=p, act="lrelu", tile=t, precision="bf16x3", out=o1), a.reps)
-            ms_b = bench(lambda: ops.conv2d(xs, pc, x1=x1s, stride=s, pad=p, act="lrelu", tile=t, precision="bf16x3", out=o2), a.reps)
+            wide = t.endswith("w")                 # wide LDS image (csrc/conv_wide.hip): interleaved inputs only
+            if wide:
+                ms_b = float("inf")
+                o2.copy_(o1)
+            else:
+                ms_b = bench(lambda: ops.conv2d(xs, pc, x1=x1s, stride=s, pad=p, act="lrelu", tile=t, precision="bf16x3", out=o2), a.reps)
             ms_c = float("inf")
-            if can_il and not a.split_only:
+            if can_il and (wide or not a.split_only):
                 o3 = torch.empty_like(out)
                 ms_c = bench(lambda: ops.conv2d(xi, pc, x1=x1i, stride=s, pad=p, act="lrelu", tile=t, precision="bf16x3", out=o3), a.reps)
                 o2 = o2 if torch.equal(o2, o3) else o2 + 1
