@@ -145,8 +145,21 @@ def run_stages(dev, prec="bf16x3", frames=80, H=240, W=432, fgt_ms=None, with_cp
     dt, dif_f = _timed(lambda: flow_pipeline.diffusion(ffl, mk_f, **kw), reps=reps)
     dt2, dif_b = _timed(lambda: flow_pipeline.diffusion(fbl, mk_b, **kw), reps=reps)
     hole_px = float(hole.float().sum(dim=(1, 2)).mean())
-    fill_info = flow_pipeline.fill_info() if hasattr(flow_pipeline, "fill_info") else {"iters": 1000, "bytes_per_hole_px_iter": 17 * 4}
-    fill_bytes = 2 * (N - 1) * hole_px * fill_info["iters"] * fill_info["bytes_per_hole_px_iter"]
+
+    def solver_info(name, per_iter_bytes):
+        """what the last call of the stage ran: on-chip (one workgroup per problem) or multi-launch CG, iterations used"""
+        st = ops.last_solver.get(name, {})
+        if st.get("solver") == "onchip":
+            it = (st["status"].cpu().long() >> 1).float()
+            return {"solver": "on-chip CG: one workgroup per problem, all iterations in one launch (csrc/solve_onchip.hip)", "iterations_mean": round(float(it.mean()), 1),
+                    "iterations_max": int(it.max()), "bbox_rows_cols": list(st.get("bbox", ())), "bytes_per_hole_px_iter": 8}
+        return {"solver": "multi-launch CG (two launches per iteration over the frame)", "bytes_per_hole_px_iter": per_iter_bytes}
+
+    fill_info = solver_info("laplace_fill", 17 * 4)
+    fill_info.setdefault("iterations_mean", flow_pipeline.FILL_ITERS)
+    # algorithmic bytes: per iteration and hole pixel what the solver moves through the memory system (multi-launch: ~17 floats; on-chip: the
+    # in-place x update only — p, r, A p never leave the CU), plus every map in and out once
+    fill_bytes = 2 * (N - 1) * (hole_px * fill_info["iterations_mean"] * fill_info["bytes_per_hole_px_iter"] + H * W * 8)
     st["diffusion_fill"] = {"ms_per_clip": round((dt + dt2) * 1e3, 2), "ms_per_direction": round((dt + dt2) * 5e2, 2), "maps": 4 * (N - 1),
                             "hole_px_per_map": int(hole_px), "solver": fill_info, "roofline": _hbm((dt + dt2) * 5e2, fill_bytes)}
     times_ms["diffusion_fill"] = (dt + dt2) * 1e3
@@ -173,8 +186,9 @@ def run_stages(dev, prec="bf16x3", frames=80, H=240, W=432, fgt_ms=None, with_cp
     trg = img * (~hole)[..., None]
     kwb = {} if blend_iters is None else {"iters": blend_iters}
     dtb, (blend, unf) = _timed(lambda: blending.poisson_blend_clip(trg, pgx, pgy, hole, tofill, **kwb), reps=reps)
-    blend_info = blending.blend_info() if hasattr(blending, "blend_info") else {"iters": 2000, "bytes_per_hole_px_iter": 20 * 4}
-    blend_bytes = N * 3 * hole_px * blend_info["iters"] * blend_info["bytes_per_hole_px_iter"]
+    blend_info = solver_info("poisson_blend", 20 * 4)
+    blend_info.setdefault("iterations_mean", blending.BLEND_ITERS)
+    blend_bytes = N * 3 * (hole_px * blend_info["iterations_mean"] * blend_info["bytes_per_hole_px_iter"] + H * W * 16)
     st["poisson_blend"] = {"ms_per_clip": round(dtb * 1e3, 2), "problems": 3 * N, "hole_px_per_frame": int(hole_px), "solver": blend_info,
                            "roofline": _hbm(dtb * 1e3, blend_bytes)}
     times_ms["poisson_blend"] = dtb * 1e3

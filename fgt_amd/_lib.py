@@ -84,13 +84,17 @@ SIGNATURES = {
     "fgt_flow_propagate": [_P, _P, _P, _P, _P, _I, _I, _I, C.c_double, C.c_double, _I, _P, _P, _P, _P, _P],
     "fgt_poisson_blend_workspace": [_I, _I, _I],
     "fgt_poisson_blend": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],
+    "fgt_mask_bbox": [_P, _I, _I, _I, _P, _P],
+    "fgt_laplace_fill_onchip": [_P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _P, _P],
+    "fgt_poisson_blend_onchip": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],
     "fgt_mfma_probe_workspace": [],
     "fgt_mfma_probe": [_I, _I, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), _P],
     "fgt_prof_enable": [_I],
+    "fgt_prof_enable_kinds": [C.c_uint],
     "fgt_prof_collect": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)],
     "fgt_prof_collect_kind": [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)],
 }
-_RESTYPES = {"fgt_last_error": C.c_char_p, "fgt_prof_enable": None, "fgt_laplace_fill_workspace": C.c_long, "fgt_flow_propagate_workspace": C.c_long, "fgt_poisson_blend_workspace": C.c_long, "fgt_mfma_probe_workspace": C.c_long}
+_RESTYPES = {"fgt_last_error": C.c_char_p, "fgt_prof_enable": None, "fgt_prof_enable_kinds": None, "fgt_laplace_fill_workspace": C.c_long, "fgt_flow_propagate_workspace": C.c_long, "fgt_poisson_blend_workspace": C.c_long, "fgt_mfma_probe_workspace": C.c_long}
 
 _lib = None
 

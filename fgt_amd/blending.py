@@ -13,13 +13,7 @@ import torch
 from . import ops
 
 
-BLEND_ITERS = 2000           # CG iterations (fixed count, per-problem freeze at tol * |r0|)
-
-
-def blend_info():
-    """What one clip blend does per hole pixel (bench accounting): solver, iteration count, algorithmic bytes per iteration."""
-    return {"solver": "conjugate gradients on the normal equations of the reference's least-squares system (csrc/poisson_blend.hip)",
-            "iters": BLEND_ITERS, "bytes_per_hole_px_iter": 20 * 4}
+BLEND_ITERS = 2000           # iteration cap of the conjugate gradients (a problem stops at tol * |r0|)
 
 
 def poisson_blend_clip(target, gradient_x, gradient_y, hole, gradient_mask, iters=BLEND_ITERS, tol=1e-7):

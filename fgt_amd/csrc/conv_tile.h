@@ -138,17 +138,32 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                         v[u] = x;
                     }
                     if (ok[u0]) {
-                        if (want_f32) *reinterpret_cast<float4*>(p.out + (long)m * d.ldo + d.ooff + co) = make_float4(v[0], v[1], v[2], v[3]);
+                        typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                        typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
+                        const bool nt = p.nt_store != 0;
+                        if (want_f32) {
+                            float* o = p.out + (long)m * d.ldo + d.ooff + co;
+                            if (nt) __builtin_nontemporal_store(nt_f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<nt_f4*>(o));
+                            else *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                        }
                         if (want_split) {
                             const int cs = d.ooff_s + co;       // pso == 32: interleaved layout, channel c -> (c/32)*64 + c%32, lo 32 further
                             if (p.pso < 0) {                    // pso == -1: one fp16 plane (in_split = 3 of the consumer)
-                                *reinterpret_cast<uint2*>(p.out_s + (long)m * d.ldo_s + cs) = fgt_half4(make_float4(v[0], v[1], v[2], v[3]));
+                                const uint2 h = fgt_half4(make_float4(v[0], v[1], v[2], v[3]));
+                                __bf16* o = p.out_s + (long)m * d.ldo_s + cs;
+                                if (nt) __builtin_nontemporal_store(nt_u2{h.x, h.y}, reinterpret_cast<nt_u2*>(o));
+                                else *reinterpret_cast<uint2*>(o) = h;
                             } else {
                                 uint2 hi, lo;
                                 split4(make_float4(v[0], v[1], v[2], v[3]), hi, lo);
                                 __bf16* o = p.out_s + (long)m * d.ldo_s + (p.pso == 32 ? ((cs >> 5) << 6) + (cs & 31) : cs);
-                                *reinterpret_cast<uint2*>(o) = hi;
-                                *reinterpret_cast<uint2*>(o + p.pso) = lo;
+                                if (nt) {
+                                    __builtin_nontemporal_store(nt_u2{hi.x, hi.y}, reinterpret_cast<nt_u2*>(o));
+                                    __builtin_nontemporal_store(nt_u2{lo.x, lo.y}, reinterpret_cast<nt_u2*>(o + p.pso));
+                                } else {
+                                    *reinterpret_cast<uint2*>(o) = hi;
+                                    *reinterpret_cast<uint2*>(o + p.pso) = lo;
+                                }
                             }
                         }
                     }

@@ -252,14 +252,19 @@ inline long al256(long b) { return (b + 255) / 256 * 256; }
 
 }  // namespace
 
+// solve_onchip.hip: the CG iterations of all N * 3 problems inside ONE launch (one workgroup per problem)
+int fgt_blend_onchip(const float* trg, const float* gx, const float* gy, const unsigned char* hole, const unsigned char* ecode, const int* bbox,
+                     float* x, int* status, int N, int H, int W, int max_rows, int max_cols, int iters, float tol, hipStream_t s);
+
 extern "C" long fgt_poisson_blend_workspace(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
     const long n = (long)N * H * W, nblk = ((long)H * W + PPB - 1) / PPB;
     return al256(4l * N * 3 * nblk * 8) + 5 * al256(3 * n * 4) + 2 * al256(n);
 }
 
-extern "C" int fgt_poisson_blend(const float* target, const float* gx, const float* gy, const unsigned char* hole, const unsigned char* gmask,
-                                 int N, int H, int W, int iters, float tol, float* blend, unsigned char* unfilled, void* workspace, void* stream) {
+static int poisson_blend_impl(const float* target, const float* gx, const float* gy, const unsigned char* hole, const unsigned char* gmask,
+                              int N, int H, int W, int iters, float tol, float* blend, unsigned char* unfilled, void* workspace, void* stream,
+                              const int* bbox, int max_rows, int max_cols, int* status) {
     FGT_REQUIRE(target && gx && gy && hole && gmask && blend && unfilled && workspace, "fgt_poisson_blend: null pointer");
     FGT_REQUIRE(N > 0 && H > 1 && W > 1 && iters >= 0 && tol >= 0.f, "fgt_poisson_blend: bad sizes");
     FGT_REQUIRE((long)H * W < (1l << 30) && (long)N * 3 <= 65535, "fgt_poisson_blend: clip too large for one call (N * 3 problems on grid.y)");
@@ -282,11 +287,28 @@ extern "C" int fgt_poisson_blend(const float* target, const float* gx, const flo
     hipLaunchKernelGGL(blend_codes, dim3(gpx), dim3(256), 0, s, P);
     dim3 grid(P.nblk, N * 3), block(256);
     hipLaunchKernelGGL(blend_init, grid, block, 0, s, P);
-    for (int k = 0; k < iters; ++k) {
-        hipLaunchKernelGGL(blend_apply, grid, block, 0, s, P, k);
-        hipLaunchKernelGGL(blend_update, grid, block, 0, s, P, k);
+    if (bbox) {
+        // every problem on chip, all iterations in one launch (the known pixels of P.x carry the target: blend_init wrote them)
+        if (int rc = fgt_blend_onchip(target, gx, gy, hole, P.ecode, bbox, P.x, status, N, H, W, max_rows, max_cols, iters, tol, s)) return rc;
+    } else {
+        for (int k = 0; k < iters; ++k) {
+            hipLaunchKernelGGL(blend_apply, grid, block, 0, s, P, k);
+            hipLaunchKernelGGL(blend_update, grid, block, 0, s, P, k);
+        }
     }
     hipLaunchKernelGGL(blend_finish, dim3(gpx), dim3(256), 0, s, P, blend);
     hipLaunchKernelGGL(unfilled_kernel, dim3(N), dim3(SCAN_T), 0, s, hole, gmask, H, W, scan_work, unfilled);
     return fgt_check_launch("poisson_blend");
+}
+
+extern "C" int fgt_poisson_blend(const float* target, const float* gx, const float* gy, const unsigned char* hole, const unsigned char* gmask,
+                                 int N, int H, int W, int iters, float tol, float* blend, unsigned char* unfilled, void* workspace, void* stream) {
+    return poisson_blend_impl(target, gx, gy, hole, gmask, N, H, W, iters, tol, blend, unfilled, workspace, stream, nullptr, 0, 0, nullptr);
+}
+
+extern "C" int fgt_poisson_blend_onchip(const float* target, const float* gx, const float* gy, const unsigned char* hole, const unsigned char* gmask,
+                                        const int* bbox, int N, int H, int W, int max_rows, int max_cols, int iters, float tol, float* blend,
+                                        unsigned char* unfilled, int* status, void* workspace, void* stream) {
+    FGT_REQUIRE(bbox && status && max_rows >= 0 && max_cols >= 0, "fgt_poisson_blend_onchip: bbox / status / bounds");
+    return poisson_blend_impl(target, gx, gy, hole, gmask, N, H, W, iters, tol, blend, unfilled, workspace, stream, bbox, max_rows, max_cols, status);
 }

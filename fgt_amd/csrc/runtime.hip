@@ -66,7 +66,7 @@ extern "C" int fgt_init(int device) {
 // flop count and its unique-byte floor (every input / output byte once).  fgt_prof_collect_kind synchronises the events of one kind and returns its totals.  Single host thread (the bench).
 namespace {
 struct ProfRec { hipEvent_t a, b; double flops, bytes; int kind; };
-bool g_prof_on = false;
+unsigned g_prof_mask = 0;      // bit k: launches of kind k record events
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_event_pool;
 
@@ -78,10 +78,10 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-bool fgt_prof_on() { return g_prof_on; }
+bool fgt_prof_on() { return g_prof_mask != 0; }
 
 int fgt_prof_begin(int kind, double flops, double bytes, hipStream_t s) {
-    if (!g_prof_on) return -1;
+    if (kind < 0 || kind > 31 || !((g_prof_mask >> kind) & 1u)) return -1;
     ProfRec r{get_event(), get_event(), flops, bytes, kind};
     hipEventRecord(r.a, s);
     g_prof.push_back(r);
@@ -92,7 +92,8 @@ void fgt_prof_end(int idx, hipStream_t s) {
     if (idx >= 0 && idx < (int)g_prof.size()) hipEventRecord(g_prof[idx].b, s);
 }
 
-extern "C" void fgt_prof_enable(int on) { g_prof_on = on != 0; }
+extern "C" void fgt_prof_enable(int on) { g_prof_mask = on ? ~0u : 0u; }
+extern "C" void fgt_prof_enable_kinds(unsigned mask) { g_prof_mask = mask; }
 
 extern "C" int fgt_prof_collect_kind(int kind, double* total_ms, double* total_flops, double* total_bytes, long* launches) {
     double ms = 0, fl = 0, by = 0;

@@ -15,13 +15,7 @@ from . import ops
 
 RAFT_PAIR_BATCH = 8          # pairs per RAFT refinement batch (forward and backward pairs mixed)
 LAFC_PIVOT_BATCH = 8         # pivots per LAFC call
-FILL_ITERS = 1000            # CG iterations of the diffusion fill (fixed count, per-map freeze at tol * |r0|)
-
-
-def fill_info():
-    """What one diffusion-fill call does per hole pixel (bench accounting): solver, iteration count, algorithmic bytes per iteration."""
-    return {"solver": "conjugate gradients on the masked 5-point Laplacian (csrc/laplace_fill.hip)", "iters": FILL_ITERS,
-            "bytes_per_hole_px_iter": 17 * 4}
+FILL_ITERS = 1000            # iteration cap of the diffusion fill's conjugate gradients (a map stops at tol * |r0|)
 
 
 def compute_flows(raft, frames, iters=20, batch=RAFT_PAIR_BATCH, enc_batch=16):

@@ -759,15 +759,57 @@ def compose_blend_u8(filled_u8, ids, first, frames01, masks, comp):
 _prof_on = False
 
 
-def laplace_fill(maps, masks, iters=1000, tol=1e-6):
-    """fgt_laplace_fill: maps [B, H, W] fp32, masks [n_masks, H, W] (non-zero = hole; map b uses mask b % n_masks) -> filled [B, H, W].
-    tool/utils/region_fill.py:7-63 for every map at once (conjugate gradients, fixed `iters`, per-map freeze at tol * |r0|)."""
+# which implementation the two sparse solves take: 'auto' = one workgroup per problem on chip when every hole's bounding box fits
+# (csrc/solve_onchip.hip), else the multi-launch kernels; 'onchip' / 'multilaunch' force one (tests, A/B measurements)
+SOLVER = os.environ.get("FGT_SOLVER", "auto")
+last_solver = {}          # what the last laplace_fill / poisson_blend call used (bench accounting, tests)
+
+
+def mask_bbox(m8):
+    """fgt_mask_bbox: uint8 masks [n, H, W] -> device int32 [n, 4] = (y0, x0, y1, x1) inclusive per mask (empty: y1 < y0)."""
+    assert m8.dtype == torch.uint8 and m8.is_cuda and m8.is_contiguous() and m8.dim() == 3
+    bb = torch.empty(m8.shape[0], 4, dtype=torch.int32, device=m8.device)
+    check(_lib.lib().fgt_mask_bbox(C.c_void_p(m8.data_ptr()), m8.shape[0], m8.shape[1], m8.shape[2], C.c_void_p(bb.data_ptr()), _stream()), "fgt_mask_bbox")
+    return bb
+
+
+def _onchip_bounds(bb):
+    """(max rows, max cols) of the boxes — the ONE host read-back of the on-chip solvers (they size their workgroup and LDS by it) — or None
+    when such a box cannot fit one workgroup: <= 6144 strips of 4 cells (~24 k cells), (rows + 2) * (strip columns + 8) floats + scratch <= 160 KB."""
+    b = bb.cpu()
+    ok = b[:, 2] >= b[:, 0]
+    if not bool(ok.any()):
+        return 0, 0
+    rows = int((b[ok, 2] - b[ok, 0] + 1).max())
+    cols = int((b[ok, 3] - b[ok, 1] + 1).max())
+    wq = (cols + 6) // 4                   # strips start at a multiple of 4 columns: up to 3 extra cells per row
+    if rows * wq > 512 * 12 or ((rows + 2) * (wq * 4 + 8)) * 4 + 256 > 160 * 1024:
+        return None
+    return rows, cols
+
+
+def laplace_fill(maps, masks, iters=1000, tol=1e-6, solver=None):
+    """fgt_laplace_fill[_onchip]: maps [B, H, W] fp32, masks [n_masks, H, W] (non-zero = hole; map b uses mask b % n_masks) -> filled [B, H, W].
+    tool/utils/region_fill.py:7-63 for every map at once by conjugate gradients (`iters` = iteration cap, a map stops at tol * |r0|)."""
     _require_dev(maps)
     assert maps.dim() == 3 and masks.dim() == 3 and masks.shape[1:] == maps.shape[1:] and masks.is_cuda
     maps = maps.contiguous()
     m8 = (masks != 0).to(torch.uint8).contiguous()
     B, H, W = maps.shape
     out = torch.empty_like(maps)
+    solver = solver or SOLVER
+    if solver != "multilaunch" and W % 4 == 0:
+        bb = mask_bbox(m8)
+        bounds = _onchip_bounds(bb)
+        if bounds is not None:
+            status = torch.empty(B, dtype=torch.int32, device=maps.device)
+            check(_lib.lib().fgt_laplace_fill_onchip(_ptr(maps), C.c_void_p(m8.data_ptr()), C.c_void_p(bb.data_ptr()), B, m8.shape[0], H, W, _ptr(out),
+                                                     bounds[0], bounds[1], int(iters), float(tol), C.c_void_p(status.data_ptr()), _stream()), "fgt_laplace_fill_onchip")
+            last_solver["laplace_fill"] = {"solver": "onchip", "status": status, "bbox": bounds}
+            return out
+        if solver == "onchip":
+            raise RuntimeError("laplace_fill(solver='onchip'): a hole's bounding box does not fit one workgroup")
+    last_solver["laplace_fill"] = {"solver": "multilaunch"}
     ws = torch.empty(_lib.lib().fgt_laplace_fill_workspace(B, H, W), dtype=torch.uint8, device=maps.device)
     check(_lib.lib().fgt_laplace_fill(_ptr(maps), _ptr(m8), B, m8.shape[0], H, W, _ptr(out), _ptr(ws), int(iters), float(tol), _stream()),
           "fgt_laplace_fill")
@@ -794,8 +836,8 @@ def flow_propagate(gx, gy, mask, flow_f, flow_b, consistency_thres=5.0, alpha=0.
     return ox, oy, fill.bool()
 
 
-def poisson_blend(target, gx, gy, hole, gmask, iters=2000, tol=1e-7):
-    """fgt_poisson_blend: target, gx, gy [N,H,W,3] fp32; hole, gmask [N,H,W] (non-zero = hole / gradient unknown) ->
+def poisson_blend(target, gx, gy, hole, gmask, iters=2000, tol=1e-7, solver=None):
+    """fgt_poisson_blend[_onchip]: target, gx, gy [N,H,W,3] fp32; hole, gmask [N,H,W] (non-zero = hole / gradient unknown) ->
     (blend [N,H,W,3], unfilled [N,H,W] bool).  tool/utils/Poisson_blend_img.py:19-244 for the whole clip."""
     _require_dev(target, gx, gy)
     N, H, W, _ = target.shape
@@ -805,16 +847,37 @@ def poisson_blend(target, gx, gy, hole, gmask, iters=2000, tol=1e-7):
     out = torch.empty_like(target)
     unf = torch.empty(N, H, W, dtype=torch.uint8, device=target.device)
     ws = torch.empty(_lib.lib().fgt_poisson_blend_workspace(N, H, W), dtype=torch.uint8, device=target.device)
+    solver = solver or SOLVER
+    if solver != "multilaunch" and W % 4 == 0:
+        bb = mask_bbox(h8)
+        bounds = _onchip_bounds(bb)
+        if bounds is not None:
+            status = torch.empty(3 * N, dtype=torch.int32, device=target.device)
+            check(_lib.lib().fgt_poisson_blend_onchip(_ptr(target), _ptr(gx), _ptr(gy), C.c_void_p(h8.data_ptr()), C.c_void_p(g8.data_ptr()), C.c_void_p(bb.data_ptr()),
+                                                      N, H, W, bounds[0], bounds[1], int(iters), float(tol), _ptr(out), C.c_void_p(unf.data_ptr()),
+                                                      C.c_void_p(status.data_ptr()), C.c_void_p(ws.data_ptr()), _stream()), "fgt_poisson_blend_onchip")
+            last_solver["poisson_blend"] = {"solver": "onchip", "status": status, "bbox": bounds}
+            return out, unf.bool()
+        if solver == "onchip":
+            raise RuntimeError("poisson_blend(solver='onchip'): a hole's bounding box does not fit one workgroup")
+    last_solver["poisson_blend"] = {"solver": "multilaunch"}
     check(_lib.lib().fgt_poisson_blend(_ptr(target), _ptr(gx), _ptr(gy), C.c_void_p(h8.data_ptr()), C.c_void_p(g8.data_ptr()), N, H, W,
                                        int(iters), float(tol), _ptr(out), C.c_void_p(unf.data_ptr()), C.c_void_p(ws.data_ptr()), _stream()),
           "fgt_poisson_blend")
     return out, unf.bool()
 
 
-def prof_enable(on):
+def prof_enable(on, kinds=None):
+    """Per-launch HIP-event timing on / off; kinds: iterable of PROF_KINDS names to restrict it to (None = every kind)."""
     global _prof_on
     _prof_on = bool(on)
-    _lib.lib().fgt_prof_enable(int(on))
+    if on and kinds is not None:
+        mask = 0
+        for k in kinds:
+            mask |= 1 << PROF_KINDS[k]
+        _lib.lib().fgt_prof_enable_kinds(mask)
+    else:
+        _lib.lib().fgt_prof_enable(int(on))
 
 
 def prof_is_enabled():

@@ -370,6 +370,22 @@ long fgt_poisson_blend_workspace(int N, int H, int W);
 int fgt_poisson_blend(const float* target, const float* gx, const float* gy, const unsigned char* hole, const unsigned char* gmask,
                       int N, int H, int W, int iters, float tol, float* blend, unsigned char* unfilled, void* workspace, void* stream);
 
+/* ---- the two solves above with ONE WORKGROUP PER PROBLEM, all iterations inside one launch (csrc/solve_onchip.hip, ABI 6) ----
+ * The problems are small (a hole's bounding box: 17-33 k cells) and many (158-240 per clip: one per CU): the search direction lives in LDS
+ * as a dense image of the bounding box, x / r / A p in registers, the dot products are fixed-order block reductions (bit-reproducible), a
+ * problem leaves its loop when |r| <= tol |r0| (`iters` is the cap).  Same iteration as fgt_laplace_fill / fgt_poisson_blend.
+ * fgt_mask_bbox: bbox[m] = (y0, x0, y1, x1) inclusive of the non-zero pixels of mask m (device int32 [n][4]; empty mask: y1 < y0).
+ * max_rows / max_cols: host-known upper bounds of the boxes' sizes (the Python wrapper reads `bbox` back once); FGT_EINVAL when such a box
+ * does not fit one workgroup (<= 6 144 four-cell strips ~ 24 k cells, (rows + 2) * (strip columns + 8) floats of LDS within 160 KB) or
+ * W % 4 != 0 — use the multi-launch entry points then.  status[problem]: 2 * iterations used; 1 = the DEVICE found the box larger than the bounds promised (its hole is
+ * filled with NaN, nothing is written out of bounds). */
+int fgt_mask_bbox(const unsigned char* mask, int n, int H, int W, int* bbox, void* stream);
+int fgt_laplace_fill_onchip(const float* I, const unsigned char* mask, const int* bbox, int B, int n_masks, int H, int W, float* out,
+                            int max_rows, int max_cols, int iters, float tol, int* status, void* stream);
+int fgt_poisson_blend_onchip(const float* target, const float* gx, const float* gy, const unsigned char* hole, const unsigned char* gmask,
+                             const int* bbox /* of `hole`, [N][4] */, int N, int H, int W, int max_rows, int max_cols, int iters, float tol,
+                             float* blend, unsigned char* unfilled, int* status /* [3N] */, void* workspace /* fgt_poisson_blend_workspace */, void* stream);
+
 /* ---- per-kernel timing with HIP events on the launch stream (bench.py's roofline blocks) ----
  * fgt_prof_enable(1) makes every fgt_conv2d (MFMA kernels) and fgt_attention launch record an event pair and its ALGORITHMIC
  * flops: conv/GEMM 2*M*Cout_g*K*groups (K before channel padding, fgt_conv_desc.k_alg); attention 4*n_q*n_k*128 per
@@ -397,7 +413,9 @@ int fgt_poisson_blend(const float* target, const float* gx, const float* gy, con
 #define FGT_PROF_WARP 7
 #define FGT_PROF_CORR_LOOKUP 8
 #define FGT_PROF_POINTWISE 9
-void fgt_prof_enable(int on);
+void fgt_prof_enable(int on);                 /* every kind */
+void fgt_prof_enable_kinds(unsigned mask);    /* bit k = kind k: an event pair serialises neighbouring launches a little, so bench.py times its
+                                               * steps with the three MFMA kinds only and measures the HBM kinds on one extra step */
 int fgt_prof_collect_kind(int kind, double* total_ms, double* total_flops, double* total_bytes, long* launches);
 int fgt_prof_collect(double* total_ms, double* total_flops, long* launches); /* = kind FGT_PROF_CONV */
 

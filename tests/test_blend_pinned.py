@@ -116,3 +116,55 @@ def test_hip_blend_edge_cases(dev):
     want, wunf = BO.poisson_blend(trg[2], gx[2][:, : W - 1], gy[2][: H - 1], hole[2], gm[2])
     assert np.array_equal(unf[2], wunf) and 0 < wunf.sum() < hole[2].sum()
     assert np.abs(blend[2] - want)[~wunf].max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_hip_blend_onchip_matches_multilaunch_and_oracle(dev):
+    """csrc/solve_onchip.hip (one workgroup per (frame, channel), all CG iterations in one launch) vs the multi-launch kernels vs the exact
+    least-squares solution: two 240x432 frames whose holes fit one workgroup (an ellipse of ~17 k px with a band of unknown gradients; a
+    hole touching the image corner at an unaligned column), bit-reproducible, status = iterations used."""
+    from fgt_amd import ops
+    H, W = 240, 432
+    yy, xx = np.mgrid[:H, :W]
+    holes = [((yy - 120) / 70.0) ** 2 + ((xx - 201) / 80.0) ** 2 <= 1.0, np.zeros((H, W), bool)]
+    holes[1][:90, :131] = True
+    holes[1][60:140, 100:181] = True
+    cases = []
+    for s, hole in enumerate(holes):
+        trg, gx, gy, _, _ = blend_inputs(H, W, 20 + s)
+        src = trg.copy()                                # blend_inputs zeroed its own hole: rebuild gradients for ours from a smooth image
+        rng = np.random.default_rng(30 + s)
+        from scipy.ndimage import gaussian_filter
+        img = gaussian_filter(rng.normal(size=(H, W, 3)), (3, 3, 0))
+        img = ((img - img.min()) / (img.max() - img.min())).astype(np.float32)
+        gmask = np.zeros((H, W), bool)
+        gmask[100:112, 150:230] = True
+        gmask &= hole
+        gx = np.diff(img, axis=1).astype(np.float32)
+        gy = np.diff(img, axis=0).astype(np.float32)
+        gx[gmask[:, :-1]] = 0
+        gy[gmask[:-1, :]] = 0
+        trg = img.copy()
+        trg[hole] = 0
+        cases.append((trg, gx, gy, hole, gmask))
+    st = lambda k: torch.from_numpy(np.stack([np.ascontiguousarray(c[k]) for c in cases])).to(dev)
+    fx = torch.from_numpy(np.stack([_full(c[1], c[2], H, W)[0] for c in cases])).to(dev)
+    fy = torch.from_numpy(np.stack([_full(c[1], c[2], H, W)[1] for c in cases])).to(dev)
+    a, ua = ops.poisson_blend(st(0), fx, fy, st(3), st(4), iters=4000, tol=1e-7, solver="onchip")
+    info = ops.last_solver["poisson_blend"]
+    assert info["solver"] == "onchip"
+    status = info["status"].cpu().numpy()
+    assert not (status & 1).any()
+    a2, _ = ops.poisson_blend(st(0), fx, fy, st(3), st(4), iters=4000, tol=1e-7, solver="onchip")
+    assert torch.equal(a, a2)
+    b, ub = ops.poisson_blend(st(0), fx, fy, st(3), st(4), iters=4000, tol=1e-7, solver="multilaunch")
+    assert torch.equal(ua, ub)
+    a, b, ua = a.cpu().numpy(), b.cpu().numpy(), ua.cpu().numpy()
+    for i, (trg, gx, gy, hole, gmask) in enumerate(cases):
+        want, wunf = BO.poisson_blend(trg, gx, gy, hole, gmask)
+        assert np.array_equal(ua[i], wunf)
+        da, db = np.abs(a[i] - want)[~wunf].max(), np.abs(b[i] - want)[~wunf].max()
+        print(f"[parity] poisson blend on-chip 432x240 frame {i}: hole px {hole.sum()}, iterations {[int(x) >> 1 for x in status[3 * i:3 * i + 3]]}, "
+              f"max |on-chip - lsq| {da:.2e}, |multi-launch - lsq| {db:.2e}")
+        assert da < 1e-4 and db < 1e-4
+        assert np.array_equal(a[i][~hole], trg[~hole])
