@@ -379,7 +379,7 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     p.pipe = pipe_env;
     static const int xcd_env = [] { const char* e = getenv("FGT_CONV_XCD"); return e ? atoi(e) : 1; }();
     p.xcd_swizzle = xcd_env;
-    static const int nt_env = [] { const char* e = getenv("FGT_CONV_NT"); return e ? atoi(e) : 0; }();
+    static const int nt_env = [] { const char* e = getenv("FGT_CONV_NT"); return e ? atoi(e) : 1; }();
     p.nt_store = nt_env;
     p.zero_page = fgt_zero_page();
     FGT_REQUIRE(p.zero_page != nullptr, "fgt_conv2d: could not allocate the zero page");

@@ -123,6 +123,21 @@ def all_gather(out, buf, group=None, async_op=False):
     return work if async_op else _Done()
 
 
+def all_to_all_rows(out, inp, out_rows, in_rows, group=None, async_op=False):
+    """all_to_all_single over leading-dimension rows: `inp` holds in_rows[q] consecutive rows for every rank q (in rank order), `out`
+    receives out_rows[r] rows from every rank r.  RCCL moves the device buffers rank to rank over xGMI (point-to-point links: an
+    all-to-all of exactly the rows each rank needs is the natural collective on this fabric); gloo (CPU tests, single-GPU rehearsal)
+    stages device tensors through the host like `all_gather`."""
+    import torch.distributed as dist
+    if needs_host_staging(inp.is_cuda, dist.get_backend(group)):
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(host, inp.cpu(), output_split_sizes=list(out_rows), input_split_sizes=list(in_rows), group=group)
+        out.copy_(host)
+        return _Done()
+    work = dist.all_to_all_single(out, inp, output_split_sizes=list(out_rows), input_split_sizes=list(in_rows), group=group, async_op=async_op)
+    return work if async_op else _Done()
+
+
 def compose_torch(out, nb, frames01, masks, comp, visited):
     """Reference compose/blend restated with torch ops (CPU path used only by the CPU tests).  `out`: model output (fp32) or
     its uint8 truncation."""
@@ -186,22 +201,45 @@ class ClipRunner:
         for t, ws in sorted(by_t.items()):
             nb = min(self.window_batch, self._max_batch(t))
             self.groups += [ws[i:i + nb] for i in range(0, len(ws), nb)]
-        # ---- frame sharding of the per-frame stages: rank r encodes frames [r*per, (r+1)*per) in `n_chunks` chunks of `ck`;
-        # feature row of frame f in the gathered buffers = _row_of[f] (identity for world == 1).  Ranks whose block is (partly)
-        # past the clip encode nothing there and contribute zero rows, so the collectives stay matched on every rank.
+        # ---- frame sharding of the per-frame stages: rank r encodes frames [r*per, (r+1)*per) in `n_chunks` chunks of `ck` frames
+        # (`encode_chunk` frames per call at most, at least two chunks so that the exchange of chunk j travels while chunk j+1 is
+        # encoded).  A rank only needs the frames its own windows reference (its neighbours + the stride-10 reference frames: ~30 of 80
+        # at 8 ranks): after every chunk an ALL-TO-ALL delivers exactly those rows — rank r sends to rank q the frames of the chunk that
+        # q's windows use — instead of an all-gather of every feature to everyone (442 MB per 80-frame clip, 3.5 GB at 864x480x160).
+        # Feature row of frame f in this rank's buffers = _row_of[f] (identity for world == 1; -1: not held here).
+        # Ranks whose block is (partly) past the clip encode nothing there and send / receive zero rows: every rank still enters every
+        # collective, so they stay matched for any (frames, ranks).
         self.per = -(-self.n // world)
         if world > 1:
-            self.n_chunks = 2 if self.per >= 2 else 1             # two chunks: all-gather of chunk 0 overlaps the encode of chunk 1
+            self.n_chunks = max(2 if self.per >= 2 else 1, -(-self.per // self.encode_chunk))
             self.ck = -(-self.per // self.n_chunks)
         else:
             self.n_chunks, self.ck = -(-self.n // self.encode_chunk), self.encode_chunk
         self._row_of = list(range(self.n))
+        self.rows = self.n
         if world > 1:
-            for f in range(self.n):
-                r, o = divmod(f, self.per)
-                j, i = divmod(o, self.ck)
-                self._row_of[f] = j * world * self.ck + r * self.ck + i
-        self.rows = world * self.ck * self.n_chunks if world > 1 else self.n
+            need = [sorted({f for wi in self.assign[q] for f in self.sched[wi][0] + self.sched[wi][1]}) for q in range(world)]
+            self.need = need
+            chunk_of = lambda r, j: range(min(self.n, r * self.per + j * self.ck), min(self.n, r * self.per + (j + 1) * self.ck, (r + 1) * self.per))
+            self._row_of = [-1] * self.n
+            self._plan = []                        # per chunk: (send ids [local rows of this rank's block], in_rows per dest, out_rows per source, first recv row)
+            row = 0
+            for j in range(self.n_chunks):
+                mine_j = chunk_of(rank, j)
+                send, in_rows = [], []
+                for q in range(world):
+                    fs = [f for f in mine_j if f in set(need[q])]
+                    send += [f - rank * self.per for f in fs]
+                    in_rows.append(len(fs))
+                out_rows, r0 = [], row
+                for r in range(world):
+                    fs = [f for f in chunk_of(r, j) if f in set(need[rank])]
+                    for f in fs:
+                        self._row_of[f] = row
+                        row += 1
+                    out_rows.append(len(fs))
+                self._plan.append((torch.tensor(send, dtype=torch.int32, device=self.dev), in_rows, out_rows, r0))
+            self.rows = max(row, 1)
         self._group_ids, self._group_keep, self._group_tq, self._group_keep_q = [], [], [], []
         for ws in self.groups:
             t = len(self.sched[ws[0]][0]) + len(self.sched[ws[0]][1])
@@ -254,8 +292,13 @@ class ClipRunner:
             C, c, cf = net.cfg["cnum"] * 2, net.cfg["c"], net.cfg["cf"]
             new = lambda rows, *s: torch.zeros(rows, *s, dtype=torch.float32, device=self.dev)
             full = (new(self.rows, Hf, Wf, C), new(self.rows, th * tw, c), new(self.rows, th * tw, cf))
-            local = [tuple(new(self.ck, *b.shape[1:]) for b in full) for _ in range(self.n_chunks)] if self.world > 1 else None
-            self._feat = (full, local, th, tw)
+            local = send = None
+            if self.world > 1:
+                # this rank's block as encoded, and one send buffer per chunk (rows ordered by destination rank; a frame that several
+                # ranks need appears once per destination)
+                local = tuple(new(max(self.per, 1), *b.shape[1:]) for b in full)
+                send = [tuple(new(max(ids.numel(), 1), *b.shape[1:]) for b in full) for ids, _, _, _ in self._plan]
+            self._feat = (full, local, th, tw, send)
         return self._feat
 
     def _encode_chunk(self, s0, s1, dst):
@@ -280,7 +323,7 @@ class ClipRunner:
     def encode_clip(self):
         """Per-frame stages for the whole clip into the persistent feature buffers:
         (enc [rows,Hf,Wf,C], tokens [rows,n,c], flow tokens [rows,n,cf], th, tw); frame f lives in row _row_of[f]."""
-        full, local, th, tw = self._feature_buffers()
+        full, local, th, tw, send = self._feature_buffers()
         if self.world == 1:
             for s0 in range(0, self.n, self.ck):
                 s1 = min(self.n, s0 + self.ck)
@@ -288,16 +331,23 @@ class ClipRunner:
             return full + (th, tw)
         lo = self.rank * self.per
         works = []
-        for j in range(self.n_chunks):
+        for j, (ids, in_rows, out_rows, r0) in enumerate(self._plan):
             s0 = min(self.n, lo + j * self.ck)
             s1 = min(self.n, lo + (j + 1) * self.ck, lo + self.per)
             if s1 > s0:
-                self._encode_chunk(s0, s1, local[j])
-            g0 = j * self.world * self.ck
-            for b, l in zip(full, local[j]):                    # "boundary feature" all-gathers (RCCL / gloo), asynchronous:
-                works.append(all_gather(b[g0:g0 + self.world * self.ck], l, self.group, async_op=True))    # chunk j travels while chunk j+1 is encoded
+                self._encode_chunk(s0, s1, tuple(l[s0 - lo:s1 - lo] for l in local))
+            n_in, n_out = sum(in_rows), sum(out_rows)
+            for b, l, sb in zip(full, local, send[j]):          # "boundary feature" exchange (RCCL / gloo), asynchronous:
+                if n_in:                                         # chunk j travels while chunk j+1 is encoded
+                    if self.on_gpu:
+                        ops.gather_rows(l, ids, out=sb[:n_in])
+                    else:
+                        sb[:n_in] = l[ids.long()]
+                works.append(all_to_all_rows(b[r0:r0 + n_out], sb[:n_in], out_rows, in_rows, self.group, async_op=True))
+        self._t("encode")
         for w in works:
             w.wait()
+        self._t("gather_wait")
         return full + (th, tw)
 
     def run_group_cached(self, gi, feats):
@@ -331,12 +381,44 @@ class ClipRunner:
             o += nb
         return outs
 
+    # ---- per-phase timing (bench.py --gpus N: the first real multi-GPU curve must be diagnosable): with `timing = True` every phase
+    # boundary of run() records an event on the main stream (GPU) / a wall-clock stamp (CPU); phase_ms() turns the last pass into
+    # {phase: ms}.  "gather_wait" is what the feature exchange costs beyond the encode it overlaps.
+    timing = False
+
+    def _t(self, name):
+        if not self.timing:
+            return
+        if self.on_gpu:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+        else:
+            import time
+            e = time.perf_counter()
+        self._stamps.append((name, e))
+
+    def phase_ms(self):
+        out, prev = {}, None
+        for name, e in getattr(self, "_stamps", []):
+            if prev is not None:
+                if self.on_gpu:
+                    e.synchronize()
+                    out[name] = out.get(name, 0.0) + prev.elapsed_time(e)
+                else:
+                    out[name] = out.get(name, 0.0) + (e - prev) * 1e3
+            prev = e
+        return {k: round(v, 3) for k, v in out.items()}
+
     def run(self):
         """One pass over the clip.  Returns comp [N,H,W,3] fp32 (0..255 scale, before the final astype(uint8))."""
+        self._stamps = []
+        self._t("start")
         comp = torch.empty(self.n, self.H, self.W, 3, dtype=torch.float32, device=self.dev)
         if self.cache_features:
             with torch.no_grad():
                 feats = self.encode_clip()
+                if self.world == 1:
+                    self._t("encode")
                 outs = {}
                 if self.on_gpu and self.n_streams > 1 and len(self.groups) > 1:
                     # independent window groups on separate HIP streams: the HBM-bound kernels of one group (LayerNorm, fold, pools)
@@ -363,8 +445,10 @@ class ClipRunner:
                         outs.update(self.run_group_cached(gi, feats))
         else:
             outs = {wi: self.run_window(wi) for wi in self.mine}
+        self._t("windows")
         if self.world > 1:
             outs = self._exchange(outs)
+            self._t("exchange")
         if self.on_gpu:
             f01 = self.frames01[0].contiguous()
             mk = self.masks[0].contiguous()
@@ -375,6 +459,7 @@ class ClipRunner:
             visited = [False] * self.n
             for wi in range(len(self.sched)):
                 compose_torch(outs[wi], self.sched[wi][0], self.frames01, self.masks, comp, visited)
+        self._t("blend")
         return comp
 
     def _exchange(self, outs):

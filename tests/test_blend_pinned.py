@@ -127,8 +127,8 @@ def test_hip_blend_onchip_matches_multilaunch_and_oracle(dev):
     H, W = 240, 432
     yy, xx = np.mgrid[:H, :W]
     holes = [((yy - 120) / 70.0) ** 2 + ((xx - 201) / 80.0) ** 2 <= 1.0, np.zeros((H, W), bool)]
-    holes[1][:90, :131] = True
-    holes[1][60:140, 100:181] = True
+    holes[1][:80, :119] = True
+    holes[1][50:120, 90:161] = True                     # bounding box 120 x 161 from the image corner: 4 920 strips, fits one workgroup
     cases = []
     for s, hole in enumerate(holes):
         trg, gx, gy, _, _ = blend_inputs(H, W, 20 + s)
