@@ -11,7 +11,7 @@ N = 1: the headline runs in the bf16x3 arithmetic (fp32 operands split into hi/l
 accumulate; inside the north star's 1e-3 bar, parity block in the line); the SAME invocation then times the exact-fp32 mode and
 reports it as `fp32_exact` (value, ms_per_step, its own roofline against the 157.3 TF fp32-MFMA peak).
 N > 1 (`--scaling strong`, default): ONE clip sharded over the ranks — frames block-sharded for the per-frame stages with
-chunked RCCL all-gathers of the features, windows cost-balanced over the ranks with equal lengths co-located, window outputs
+chunked RCCL all-to-alls of the feature rows each rank needs, windows cost-balanced over the ranks with equal lengths co-located, window outputs
 exchanged as uint8 in one all-gather, identical composite on every rank.  The weak variant (one independent clip
 per rank, no data-path collective) is timed first and reported beside it as `weak_scaling_clip_per_rank`; if the sharded
 section fails or times out the weak number becomes the headline and the line says so (`scaling`, `strong_error`).
@@ -237,6 +237,18 @@ def main():
             for k in HBM_KERNELS:
                 ms, fl, n, by = ops.prof_collect(k)
                 kinds[k] = (ms * args.steps, fl * args.steps, n * args.steps, by * args.steps)
+        # per-phase times of ONE extra pass on every rank (encode / gather wait / windows / exchange / blend: events on the main stream),
+        # so that a multi-GPU curve can be read phase by phase
+        runner.timing = True
+        runner.run()
+        torch.cuda.synchronize()
+        runner.timing = False
+        ph = runner.phase_ms()
+        if world > 1:
+            allph = [None] * world
+            dist.all_gather_object(allph, ph)
+            ph = allph
+        runner.last_phases = ph
         return max_over_ranks(dt), host_dt, comp, kinds
 
     sustained_cache = {}
@@ -304,8 +316,8 @@ def main():
                                    f"reference window schedule (neighbor_stride 5, step 10; sum t = {sum(len(a) + len(b) for a, b in sched)})",
                        "windows": len(sched),
                        "sharding": ("single GPU" if world == 1 else f"one clip per rank x {world} ranks, no data-path collective" if weak else
-                                    f"one clip: frames block-sharded for the per-frame stages (chunked all-gather of features), windows cost-balanced over "
-                                    f"{world} ranks with equal lengths co-located, uint8 all-gather of window outputs"),
+                                    f"one clip: frames block-sharded for the per-frame stages (chunked all-to-all of the feature rows each rank's windows "
+                                    f"reference), windows cost-balanced over {world} ranks with equal lengths co-located, uint8 all-gather of window outputs"),
                        "conv_precision": prec, "per_frame_feature_cache": bool(runner.cache_features), "hip_graphs": bool(args.graphs),
                        "window_batch": runner.window_batch},
             "host_enqueue_ms_per_step": round(1e3 * res["host_dt"] / args.steps, 3),
@@ -316,6 +328,12 @@ def main():
         if rl:
             line["roofline"] = dict(rl[0], note="kernel with the largest share of the step (rank 0's launches of the timed region)")
             line["rooflines"] = rl
+        ph = getattr(runner, "last_phases", None)
+        if ph:
+            line["phases_ms"] = ph if isinstance(ph, dict) else {f"rank{i}": p_ for i, p_ in enumerate(ph)}
+            if not isinstance(ph, dict):
+                line["feature_rows_per_rank"] = {"rows_held": getattr(runner, "rows", None), "frames": args.frames,
+                                                 "note": "a rank receives only the frames its windows reference (needed-rows all-to-all)"}
         if strong_error:
             line["strong_error"] = strong_error
         c = res["comp"].float()

@@ -145,3 +145,79 @@ def test_window_groups_partition_the_rank_windows():
     small = ClipRunner.__new__(ClipRunner)
     small.model, small.H, small.W = m, 240, 432
     assert small._max_batch(17) == 64
+
+
+# ------------------------------------------------------------------------------------------------ 8 ranks (the node the driver scales to)
+class _StubNet:
+    """The smallest model the feature-cache path of ClipRunner can drive: per-frame features that identify their frame, a window
+    forward that depends on EVERY frame of the window (so a wrong or missing feature row changes the composite)."""
+    passmask, in_channels = 1, 4
+    cfg = dict(cnum=2, c=4, cf=2, p=(3, 3), k=(7, 7), s=(3, 3), ws=8, heads=4, flow_in=2)
+
+    def token_grid(self, H, W):
+        return tuple((n // 4 + 6 - 7) // 3 + 1 for n in (H, W))
+
+    def encode_frames(self, masked, flows, masks, packed_in=None, out=None):
+        b, t, _, H, W = masked.shape
+        th, tw = self.token_grid(H, W)
+        pool = torch.nn.functional.avg_pool2d
+        enc = torch.cat([pool(masked[0], 4), pool(masks[0], 4)], 1).permute(0, 2, 3, 1).contiguous()             # [t, H/4, W/4, 4]
+        tok = pool(masked[0], (H // th, W // tw))[:, :, :th, :tw].permute(0, 2, 3, 1)
+        tok = torch.cat([tok, tok[..., :1] * 0.5], -1).reshape(t * th * tw, 4)
+        ftok = pool(flows[0], (H // th, W // tw))[:, :, :th, :tw].permute(0, 2, 3, 1).reshape(t * th * tw, 2)
+        return enc, tok, ftok, th, tw
+
+    def transform_decode(self, enc, x, f, b, t, th, tw, keep=None, tq=None, keep_q=None):
+        n = th * tw
+        ctx = (x.view(b, t, n, 4).mean((1, 2)) + f.view(b, t, n, 2).mean((1, 2)).sum(-1, keepdim=True) * 0.3)         # [b, 4]: all t frames of a window
+        k = keep.long()
+        e = enc[k]                                                                                                   # [nk, Hf, Wf, 4]
+        y = e[..., :3] * 0.8 + ctx[k // t][:, None, None, :3] * 0.5 + e[..., 3:] * 0.1
+        return torch.tanh(torch.nn.functional.interpolate(y.permute(0, 3, 1, 2), scale_factor=4, mode="nearest"))
+
+
+class _StubModel:
+    net = _StubNet()
+
+
+def _worker8(rank, world, port, n, H, W, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    fr, fl, ms = clip(n, H, W)
+    r = ClipRunner(_StubModel(), fr, fl, ms, rank=rank, world=world, cache_features=True, encode_chunk=4)
+    r.timing = True
+    got = r.run()
+    q.put((rank, got.numpy(), r.rows, r.n_chunks, sorted(r.phase_ms())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,what", [(80, "BASELINE C3 schedule: 16 windows"), (160, "BASELINE C5 schedule: 32 windows")])
+def test_eight_ranks_needed_rows_exchange_matches_single_rank(n, what):
+    """The sharded clip on 8 gloo ranks (frames block-sharded, features delivered by the needed-rows all-to-all, windows cost-balanced,
+    uint8 exchange, ordered blend) == the single-rank composite on every rank, for the two schedules the driver benchmarks; a rank
+    holds only the frames its windows use; the assignment stays within the bound the bench line reports."""
+    world, port, H, W = 8, 33500 + (os.getpid() % 2000), 32, 48
+    fr, fl, ms = clip(n, H, W)
+    single = ClipRunner(_StubModel(), fr, fl, ms, cache_features=True)
+    assert single.cache_features
+    want = single.run()
+    sched = single.sched
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, n, H, W, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = {r: (torch.from_numpy(a), rows, nch, ph) for r, a, rows, nch, ph in (q.get(timeout=300) for _ in range(world))}
+    [p.join(timeout=60) for p in procs]
+    parts = assign_windows(sched, world)
+    cost = lambda ws: sum(window_cost(len(sched[w][0]) + len(sched[w][1]), len(sched[w][0])) for w in ws)
+    assert max(map(cost, parts)) <= cost(range(len(sched))) / ideal_speedup(sched, world) * (1 + 1e-9)
+    assert ideal_speedup(sched, world) > (7.4 if n == 80 else 7.5)
+    for r in range(world):
+        got, rows, nch, phases = res[r]
+        assert torch.equal(got, want), f"{what}: rank {r} differs from the single-rank composite"
+        need = {f for w in parts[r] for f in sched[w][0] + sched[w][1]}
+        assert rows == len(need) and rows <= 0.45 * n, f"rank {r} holds {rows} feature rows of {n} frames"
+        assert nch == max(2, -(-(-(-n // world)) // 4))               # chunk count follows encode_chunk (= 4 here), at least two
+        assert phases == ["blend", "encode", "exchange", "gather_wait", "windows"]
