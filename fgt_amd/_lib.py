@@ -7,7 +7,8 @@ import torch  # noqa: F401  -- MUST precede loading libfgt_hip.so: torch ships i
 #                              bring up a second HIP runtime with no device context ("no ROCm-capable device is detected").
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# FGT_HIP_LIB: diagnostic builds of the same library (tools/conv_trace.py); there is still no fallback — a missing file raises.
+# FGT_HIP_LIB: diagnostic builds of the same library (fgt_amd.build.build(variant=...): tools/split_sweep.py --diag, tools/conv_trace.py); there is still
+# no fallback — a missing file raises.
 LIB_PATH = os.environ.get("FGT_HIP_LIB") or os.path.join(_HERE, "lib", "libfgt_hip.so")
 
 ABI_VERSION = 6        # include/fgt_hip.h: what fgt_abi_version() of a matching build returns

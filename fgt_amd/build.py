@@ -9,6 +9,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfgt_hip.so")
 SOURCES = ["runtime.hip", "conv_igemm.hip", "conv_split.hip", "conv_wide.hip", "conv_f16.hip", "conv_direct.hip", "attention.hip", "attention_split.hip", "pointwise.hip", "flow_ops.hip", "laplace_fill.hip", "propagate.hip", "poisson_blend.hip", "solve_onchip.hip"]
+# diagnostic builds only (build(variant=...)): measured-and-not-adopted schedule variants, trace instrumentation.  The product library never contains them.
+DIAG_SOURCES = ["diag/conv_split_variants.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
@@ -26,8 +28,12 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, variant=None, extra_flags=()):
-    """variant / extra_flags: diagnostic builds (lib/libfgt_hip_<variant>.so, e.g. tools/conv_trace.py); the product library has neither."""
+def build(force=False, verbose=True, variant=None, extra_flags=(), swap=None):
+    """variant / extra_flags: diagnostic builds (lib/libfgt_hip_<variant>.so: the product sources + DIAG_SOURCES compiled with -DFGT_DIAG, e.g.
+    `build(variant="diag")` for tools/split_sweep.py --diag, `build(variant="trace", extra_flags=["-DFGT_CONV_TRACE"])` for tools/conv_trace.py;
+    selected at run time with FGT_HIP_LIB); the product library has neither.
+    swap: {product source: diagnostic source} — a diagnostic build may replace a translation unit by its instrumented twin, e.g.
+    {"attention_split.hip": "diag/attention_split_trace.hip"} (tools/attn_trace.py, tools/attn_ablate.py)."""
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj" + (f"_{variant}" if variant else ""))
     lib = os.path.join(LIBDIR, f"libfgt_hip_{variant}.so") if variant else LIB
@@ -36,9 +42,13 @@ def build(force=False, verbose=True, variant=None, extra_flags=()):
     hipcc = _hipcc()
     jobs = []
     objs = []
-    for s in SOURCES:
+    if variant:
+        extra_flags = list(extra_flags) + ["-DFGT_DIAG"]
+    assert not swap or variant, "swap= is for diagnostic builds"
+    for s in SOURCES + (DIAG_SOURCES if variant else []):
+        s = (swap or {}).get(s, s)
         src = os.path.join(CSRC, s)
-        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        obj = os.path.join(objdir, s.replace("/", "_").replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
             jobs.append([hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj])

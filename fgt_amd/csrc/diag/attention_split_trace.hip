@@ -1,3 +1,5 @@
+// DIAGNOSTIC BUILDS ONLY: csrc/attention_split.hip as of round 2 with its s_memtime trace (-DFGT_ATTN_TRACE, tools/attn_trace.py) and timing-only
+// ablation (-DFGT_ATTN_ABLATE, tools/attn_ablate.py) instrumentation; swapped in for the product file by fgt_amd.build.build(variant=..., swap=...).
 // bf16x3 flash attention on PRE-SPLIT operands: Q, K, V arrive as hi/lo bf16 planes (written once by the projection GEMM's epilogue,
 // fgt_conv_desc.out_split), K and V tiles are streamed global -> LDS by LDS-DMA, and V is consumed in its natural [key][d] layout
 // through gfx950's transposing LDS read.  Same arithmetic family as attn_bf16x3_kernel (attention.hip): every product is three
@@ -24,7 +26,7 @@
 // transposing V reads and softmax; a stage is [K | V] (half the LDS-DMA pieces and LDS reads, a third of the MFMAs).
 #include <stdlib.h>
 #include <type_traits>
-#include "common.h"
+#include "../common.h"
 
 namespace {
 
@@ -47,8 +49,33 @@ struct AttnS {
     long psq, psk, psv, psgk, psgv;
     int n_q, n_k, zh, zw, gh, gw, n_loc;
     float scale_log2e;
+#ifdef FGT_ATTN_ABLATE
+    int dbg;   // diagnostic build only (tools/attn_ablate.py): timing-only ablations of the tile loop, results are WRONG
+#endif
 };
+#ifdef FGT_ATTN_ABLATE
+#define ABL(bit) (p.dbg & (bit))
+#else
+#define ABL(bit) 0
+#endif
 
+#ifdef FGT_ATTN_TRACE
+// Diagnostic build only (python tools/attn_trace.py --build; written at the end of round 2, first run is round 3's): every wavefront stamps
+// s_memtime at the phase boundaries of its first ATR_TILES key tiles into spare LDS, the workgroup dumps them (plus HW_ID / XCC_ID and the
+// constant-rate s_memrealtime) to a global buffer at the end.  Not part of the product library.
+constexpr int ATR_TILES = 24, ATR_NST = 8, ATR_HDR = 8;
+__device__ unsigned* g_attn_trace = nullptr;
+__device__ long g_attn_trace_words = 0;
+#define ATR_STAMP(i) ats[i] = __builtin_readcyclecounter()
+#define ATR_STORE(it)                                                                                             \
+    if ((it) < ATR_TILES && lane == 0) {                                                                          \
+        unsigned* tr_ = atrace_lds + (wave * ATR_TILES + (it)) * ATR_NST;                                         \
+        for (int i_ = 0; i_ < ATR_NST; ++i_) tr_[i_] = (unsigned)ats[i_];                                         \
+    }
+#else
+#define ATR_STAMP(i)
+#define ATR_STORE(it)
+#endif
 
 struct Prob { int frame0, zi, zj, hd; };
 
@@ -260,6 +287,14 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     for (int t = 0; t < NS - 1; ++t)
         if (t < ntiles) issue_tile(t);
     bf16x8 kf_pf[PF ? 8 : 1];                                               // PF: K fragments of the tile about to be multiplied
+#ifdef FGT_ATTN_TRACE
+    unsigned long long ats[ATR_NST] = {};
+    unsigned* const atrace_lds = reinterpret_cast<unsigned*>(smem + NS * STAGE);
+    const unsigned long long atr_t0 = __builtin_readcyclecounter();
+    const unsigned long long atr_r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = tid; i < NW * ATR_TILES * ATR_NST; i += NT) atrace_lds[i] = 0;
+    __syncthreads();
+#endif
 
     // per-lane LDS offsets of the operand reads (stage-relative)
     const int krow = l31 * 256;                                             // K: row l31, chunk (2 st + lh) ^ (l31 & 15)
@@ -279,6 +314,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     auto tile_step = [&](const int it, auto masked_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const int slot = it % NS;
+        ATR_STAMP(0);                                                       // tile top
         // this wavefront's pieces of tile `it` have landed; the (up to NS - 2) younger tiles stay in flight across the barrier
         if constexpr (PF) {
             // tile it+1 has landed as well (its K fragments are read during this tile); only tile it+2 may stay in flight
@@ -290,9 +326,12 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
             else if (NS >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();                         // ... everyone's have, and tile it-1 is fully consumed
+        ATR_STAMP(1);                                                       // own DMA pieces landed
+        if (!ABL(16)) __builtin_amdgcn_s_barrier();                         // ... everyone's have, and tile it-1 is fully consumed
+        ATR_STAMP(2);                                                       // behind the barrier
         if constexpr (!PF)
-            if (it + NS - 1 < ntiles) issue_tile((it + NS - 1) % NS);   // its stage held tile it-1; streams under the MFMAs of NS - 1 tiles
+            if (it + NS - 1 < ntiles && !ABL(8)) issue_tile((it + NS - 1) % NS);   // its stage held tile it-1; streams under the MFMAs of NS - 1 tiles
+        ATR_STAMP(3);                                                       // DMAs of a later tile issued (default kernels)
         const char* st = smem + slot * STAGE;
         const int k0 = it * KT;
 
@@ -316,7 +355,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
                     vf_pf[ks * 4 + t] = tr_pair(st + VOFF + a0, st + VOFF + a1);
                 }
         }
-        if constexpr (H && !PF) {
+        if constexpr (H && !PF) if (!ABL(1)) {
             // all eight K fragments in flight before the first MFMA (one LDS round trip instead of eight: the per-tile chain of a
             // wavefront is latency-bound, not issue-bound — halving its VALU instructions did not move the kernel)
             bf16x8 kf[8];
@@ -330,7 +369,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int sx = 0; sx < (H ? 0 : 8); ++sx) {
+        for (int sx = 0; sx < ((H || ABL(1)) ? 0 : 8); ++sx) {
             const int off = krow + (((2 * sx + lh) ^ (l31 & 15)) << 4);
             const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(st + off);
             if constexpr (H) {
@@ -348,7 +387,8 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
         // the barrier and the issue runs while the matrix pipe works: 1 196 -> 1 095 us on the b = 8, t = 17 call (profiles/r02_run12_attn_prefetch_check.txt,
         // second table), bit-identical.  The default kernels keep the issue in front (the same move measured 0...+5 % there).
         if constexpr (PF)
-            if (it + NS - 1 < ntiles) issue_tile((it + NS - 1) % NS);
+            if (it + NS - 1 < ntiles && !ABL(8)) issue_tile((it + NS - 1) % NS);
+        ATR_STAMP(4);                                                       // QK^T MFMAs issued (fragment reads waited for)
         // ---- online softmax in base 2 on the RAW scores (the scale c = log2(e) / sqrt(d) > 0 commutes with the maximum and is folded into the
         // exponent: p = exp2(s c - m c), one FMA per score); keys of this lane: k0 + (e&3) + 8*(e>>2) + 4*lh, masked in the last tile only
         if constexpr (MASKED) {
@@ -370,13 +410,17 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
         for (int e = 0; e < 16; e += 2) {
             const f32x2 sv = {s[e], s[e + 1]};
             const f32x2 x = __builtin_elementwise_fma(sv, c2, -mc2);
-            const f32x2 pe = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+            const f32x2 pe = ABL(2) ? x : f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
             s[e] = pe[0];
             s[e + 1] = pe[1];
             ps2 += pe;
         }
         l_run = l_run * alpha + (ps2[0] + ps2[1]);
         m_run = m_new;
+#ifdef FGT_ATTN_TRACE
+        asm volatile("" ::"v"(l_run));                                      // (the row sum depends on every score: the QK^T results have arrived)
+#endif
+        ATR_STAMP(5);                                                       // softmax done
         // the running maximum settles after a few tiles: when NO query of this wavefront saw a new one, alpha is exactly 1 for all of
         // them and the 64 multiplies are skipped (bit-identical: x * 1.0f == x)
         if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
@@ -405,7 +449,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
             }
         }
 #pragma unroll
-        for (int ks = 0; ks < (PF ? 0 : 2); ++ks) {
+        for (int ks = 0; ks < ((PF || ABL(4)) ? 0 : 2); ++ks) {
             unsigned h0, h1, h2, h3, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
             if constexpr (H) {     // P in [0, 1]: f16_rne
                 h0 = half2(s[8 * ks + 0], s[8 * ks + 1]); h1 = half2(s[8 * ks + 2], s[8 * ks + 3]);
@@ -449,10 +493,37 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
                 }
             }
         }
+        ATR_STAMP(6);                                                       // PV MFMAs issued
+        ATR_STORE(it);
     };
     const int nfull = p.n_k / KT;                                           // tiles whose 32 keys all exist
     for (int it = 0; it < nfull; ++it) tile_step(it, std::false_type{});
     if (nfull < ntiles) tile_step(nfull, std::true_type{});
+#ifdef FGT_ATTN_TRACE
+    {
+        const unsigned long long atr_t2 = __builtin_readcyclecounter();
+        __syncthreads();
+        constexpr int PER_WG = NW * (ATR_HDR + ATR_TILES * ATR_NST);
+        const long wg = (long)blockIdx.y * gridDim.x + blockIdx.x;
+        unsigned* out = g_attn_trace;
+        if (out && (wg + 1) * PER_WG <= g_attn_trace_words) {
+            out += wg * PER_WG;
+            if (lane == 0) {
+                unsigned* h = out + wave * ATR_HDR;
+                h[0] = __builtin_amdgcn_s_getreg(63492);    // HW_ID
+                h[1] = __builtin_amdgcn_s_getreg(63508);    // XCC_ID
+                h[2] = (unsigned)atr_t0;
+                h[3] = (unsigned)ntiles;
+                h[4] = (unsigned)atr_t2;
+                h[5] = (unsigned)(__builtin_amdgcn_s_memrealtime() - atr_r0);
+                h[6] = (unsigned)NW;
+                h[7] = (unsigned)(H ? 1 : 0);
+            }
+            for (int i = tid; i < NW * ATR_TILES * ATR_NST; i += NT) out[NW * ATR_HDR + i] = atrace_lds[i];
+        }
+        __syncthreads();
+    }
+#endif
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / l_tot;
@@ -494,7 +565,11 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
 template <int NW, bool H, bool TEMPORAL>
 int launch_mode(const AttnS& p, int problems, hipStream_t s) {
     constexpr int NS = NW == 8 ? 4 : 2;          // long zones (one workgroup per CU): four stages = three tiles in flight
+#ifdef FGT_ATTN_TRACE
+    constexpr int smem = NS * (H ? 2 : 4) * PLANE + NW * ATR_TILES * ATR_NST * 4;
+#else
     constexpr int smem = NS * (H ? 2 : 4) * PLANE;
+#endif
     static_assert(smem <= 160 * 1024, "LDS ring does not fit");
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<NW, H, TEMPORAL, NS>), smem, lds_set, "attn_split")) return rc;
@@ -505,7 +580,11 @@ int launch_mode(const AttnS& p, int problems, hipStream_t s) {
 
 // fp16, long temporal zones, FGT_ATTN_PREFETCH=1 (explicit variant: bit-identical, measured slower — see the kernel's header comment)
 int launch_prefetch(const AttnS& p, int problems, hipStream_t s) {
+#ifdef FGT_ATTN_TRACE
+    constexpr int smem = 4 * 2 * PLANE + 8 * ATR_TILES * ATR_NST * 4;
+#else
     constexpr int smem = 4 * 2 * PLANE;
+#endif
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<8, true, true, 4, true>), smem, lds_set, "attn_split")) return rc;
     dim3 grid(cdiv(p.n_q, 8 * 32), problems);
@@ -520,6 +599,14 @@ int launch(const AttnS& p, int problems, hipStream_t s) {
 
 }  // namespace
 
+#ifdef FGT_ATTN_TRACE
+extern "C" int fgt_debug_attn_trace(void* buf, long words) {
+    unsigned* b = static_cast<unsigned*>(buf);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace), &b, sizeof(b)) != hipSuccess) return FGT_ELAUNCH;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace_words), &words, sizeof(words)) != hipSuccess) return FGT_ELAUNCH;
+    return FGT_OK;
+}
+#endif
 
 // called by fgt_attention (attention.hip) when desc.in_split is set
 int fgt_attention_split(const fgt_attn_desc* dd, const void* Q, const void* K, const void* V, const void* KG, const void* VG, float* O,
@@ -541,6 +628,9 @@ int fgt_attention_split(const fgt_attn_desc* dd, const void* Q, const void* K, c
     p.psq = d.psq; p.psk = d.psk; p.psv = d.psv; p.psgk = d.psg_k; p.psgv = d.psg_v;
     p.n_q = n_q; p.n_k = n_k; p.n_loc = n_loc; p.zh = zh; p.zw = zw; p.gh = gh; p.gw = gw;
     p.scale_log2e = scale_log2e;
+#ifdef FGT_ATTN_ABLATE
+    { const char* e = getenv("FGT_ATTN_ABLATE"); p.dbg = e ? atoi(e) : 0; }
+#endif
     // long zones: 8 wavefronts share each K / V tile (FGT_ATTN_SPLIT_NW=4: A/B switch — the 4-wavefront instance runs three workgroups per CU
     // where the register count of the 8-wavefront one allows a single workgroup)
     static const int nw_long = [] { const char* e = getenv("FGT_ATTN_SPLIT_NW"); return e ? atoi(e) : 8; }();

@@ -132,6 +132,9 @@ typedef struct fgt_conv_desc {
 #define FGT_TILE_256x128x16 7  /* 256x128 tile on 16 wavefronts */
 #define FGT_TILE_256x64x8 8    /* 256x64 tile on 8 wavefronts (Cout = 64 layers) */
 /* 9: retired (256x256 one-workgroup tiles: 8 wavefronts of 128x64 or 16 of 64x64 spill at their VGPR caps and measured slower) */
+/* Codes 10-20, 32-35 (planes layout): schedule variants that were measured and NOT adopted.  They are rejected by the product library and exist
+ * in diagnostic builds only (csrc/diag/conv_split_variants.hip, `fgt_amd.build.build(variant="diag")`); 17 / 18 + 100 are product tiles of the
+ * wide kernel (csrc/conv_wide.hip). */
 #define FGT_TILE_256x128x8_S3 10  /* split inputs only: 256x128 on 8 wavefronts, 3-stage LDS-DMA ring, one workgroup per CU */
 #define FGT_TILE_256x128x16_S3 11 /* split inputs only: 256x128 on 16 wavefronts, 3-stage ring */
 #define FGT_TILE_128x128x8_S4 12  /* split inputs only: 128x128 on 8 wavefronts, 4-stage ring */

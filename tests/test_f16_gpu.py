@@ -198,7 +198,7 @@ def test_f16_rejections(dev):
     with pytest.raises(AssertionError):
         ops.linear(ops.split(x, h=True), pc, x1=ops.split(x, h=False))
     with pytest.raises(RuntimeError):
-        ops.conv2d(ops.split(x, h=True).view(1, 1, 64, 64), pc, tile="256x256p8")          # not an fp16 tile
+        ops.conv2d(ops.split(x, h=True).view(1, 1, 64, 64), pc, tile="256x256p8w")         # not an fp16 tile
     # fp16 output from bf16-pair inputs: rejected by the library (csrc/attention.hip)
     import ctypes as C
     from fgt_amd import _lib

@@ -14,7 +14,9 @@ from util import report
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-TILES = ["128x128", "128x64", "64x64", "128x32", "256x128", "128x128x8", "256x128x16", "256x64x8", "256x128x8s3", "256x128x16s3", "128x128x8s4", "256x128x8pp", "128x128x8pp", "256x128x8il", "256x256p8", "256x128p8", "128x128ea", "128x64ea", "64x64ea", "128x128x8ea", "256x128x16ea", "256x64x8ea", "128x128x8lw", "128x128lw", "128x64lw", "128x128x8xy"]
+TILES = ["128x128", "128x64", "64x64", "128x32", "256x128", "128x128x8", "256x128x16", "256x64x8", "128x128ea", "128x64ea", "64x64ea", "128x128x8ea", "256x128x16ea", "256x64x8ea"]
+# (the ring / ping-pong / interleaved-schedule / 8-phase / loader-wavefront variants of round 1-2 measured within +-5 % or slower and now exist in
+#  diagnostic builds only: csrc/diag/conv_split_variants.hip, `fgt_amd.build.build(variant="diag")`)
 
 
 def _rand(*shape, seed=0, scale=1.0):
@@ -167,7 +169,7 @@ def test_split_interleaved_format(dev):
 
 
 @pytest.mark.parametrize("case", IL_CASES, ids=[c[0] for c in IL_CASES])
-@pytest.mark.parametrize("tile", ["128x128", "64x64", "128x128x8", "256x128x16", "256x128x8s3", "128x128x8s4", "256x128x8pp", "128x128x8pp", "256x128x8il", "256x256p8", "256x128p8", "128x128ea", "128x64ea", "64x64ea", "128x128x8ea", "256x128x16ea", "256x64x8ea", "128x128x8lw", "128x128lw", "128x64lw", "128x128x8xy"])
+@pytest.mark.parametrize("tile", ["128x128", "64x64", "128x128x8", "256x128x16", "128x128ea", "128x64ea", "64x64ea", "128x128x8ea", "256x128x16ea", "256x64x8ea"])
 @pytest.mark.parametrize("w_il", [False, True], ids=["w-planes", "w-interleaved"])
 def test_conv_interleaved_inputs_bit_equal(case, tile, w_il, dev, monkeypatch):
     from fgt_amd import ops
@@ -179,7 +181,7 @@ def test_conv_interleaved_inputs_bit_equal(case, tile, w_il, dev, monkeypatch):
     monkeypatch.setattr(ops, "WEIGHTS_INTERLEAVED", False)
     ref = ops.conv2d(x, pc, stride=s, pad=p, dil=d, act="lrelu", tile="128x128", precision="bf16x3")
     monkeypatch.setattr(ops, "WEIGHTS_INTERLEAVED", w_il)
-    a = ops.conv2d(x, pc, stride=s, pad=p, dil=d, act="lrelu", tile=tile if not tile.endswith(("s3", "s4", "pp", "il", "p8", "p8n", "p8l", "ea", "lw", "xy")) else "128x128", precision="bf16x3")
+    a = ops.conv2d(x, pc, stride=s, pad=p, dil=d, act="lrelu", tile=tile if not tile.endswith("ea") else "128x128", precision="bf16x3")
     b = ops.conv2d(ops.split(x, interleave=True), pc, stride=s, pad=p, dil=d, act="lrelu", tile=tile, precision="bf16x3")
     c = ops.conv2d(ops.split(x), pc, stride=s, pad=p, dil=d, act="lrelu", tile=tile, precision="bf16x3")
     assert torch.equal(a, ref) and torch.equal(b, ref) and torch.equal(c, ref)

@@ -49,7 +49,7 @@ def main():
     a = ap.parse_args()
     if a.build:
         from fgt_amd import build as B
-        print(B.build(variant="ablate", extra_flags=["-DFGT_ATTN_ABLATE"], verbose=False))
+        print(B.build(variant="ablate", extra_flags=["-DFGT_ATTN_ABLATE"], swap={"attention_split.hip": "diag/attention_split_trace.hip"}, verbose=False))
         return
     run()
 

@@ -30,7 +30,7 @@ def main():
     a = ap.parse_args()
     if a.build:
         from fgt_amd import build
-        print(build.build(variant="atrace", extra_flags=["-DFGT_ATTN_TRACE"], verbose=False))
+        print(build.build(variant="atrace", extra_flags=["-DFGT_ATTN_TRACE"], swap={"attention_split.hip": "diag/attention_split_trace.hip"}, verbose=False))
         return
     os.environ["FGT_HIP_LIB"] = TRACE_LIB
     import numpy as np

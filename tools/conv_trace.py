@@ -40,6 +40,7 @@ def main():
         print(build.build(variant="trace", extra_flags=["-DFGT_CONV_TRACE"]))
         return
     os.environ["FGT_HIP_LIB"] = TRACE_LIB
+    os.environ["FGT_DIAG_TILES_ALL"] = "1"          # the instrumented kernels live in csrc/diag/conv_split_variants.hip
     import numpy as np
     import torch
     from fgt_amd import _lib, ops

@@ -10,6 +10,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--diag" in sys.argv:           # before fgt_amd loads the library
+    os.environ["FGT_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fgt_amd", "lib", "libfgt_hip_diag.so")
 from fgt_amd import ops  # noqa: E402
 
 LAYERS = {  # name: (N, H, W, C0, C1, Cout, groups, k, stride, pad)
@@ -42,7 +44,7 @@ LAYERS = {  # name: (N, H, W, C0, C1, Cout, groups, k, stride, pad)
     "e20 enc6 128->256": (20, 60, 108, 128, 0, 256, 1, 3, 1, 1),
     "v2p 512->6272 (66 frames)": (1, 1, 47520, 512, 0, 6272, 1, 1, 1, 0),
 }
-TILES = ["128x128", "256x128", "128x128x8", "256x128x16", "256x64x8", "256x128x8s3", "256x128x8pp", "256x128x8il"]
+TILES = ["128x128", "256x128", "128x128x8", "256x128x16", "256x64x8", "128x128x8ea", "128x128x8eaw"]
 
 
 def bench(fn, reps):
@@ -63,6 +65,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--layers", default="")
     ap.add_argument("--tiles", default="")
+    ap.add_argument("--diag", action="store_true", help="load lib/libfgt_hip_diag.so (fgt_amd.build.build(variant='diag')): the ring / ping-pong / 8-phase / loader-wavefront tiles")
     ap.add_argument("--split-only", action="store_true", help="time only the pre-split (planes) inputs; still checks bit equality with the 128x128 result")
     a = ap.parse_args()
     global TILES
