@@ -419,6 +419,22 @@ __global__ void split_kernel(const float* __restrict__ x, long rows, int C4, int
     }
 }
 
+// C % 4 != 0 but even (RAFT's 2-channel flow into the GRU input buffer): one channel pair per thread, planes layout only
+__global__ void split2_kernel(const float* __restrict__ x, long rows, int C2, int ldx, __bf16* __restrict__ out, int ld_s, long ps, int relu) {
+    const long total = rows * C2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C2;
+        const int c = (int)(i - r * C2) * 2;
+        float2 v = *reinterpret_cast<const float2*>(x + r * ldx + c);
+        if (relu) v = make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f));
+        uint2 hi, lo;
+        fgt_split4(make_float4(v.x, v.y, 0.f, 0.f), hi, lo);          // THE definition of the format; the upper pair is unused
+        __bf16* o = out + r * ld_s + c;
+        *reinterpret_cast<unsigned*>(o) = hi.x;
+        *reinterpret_cast<unsigned*>(o + ps) = lo.x;
+    }
+}
+
 }  // namespace
 
 extern "C" int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, long rows, float eps,
@@ -570,6 +586,14 @@ extern "C" int fgt_gather_rows(const float* src, long ld_src, const int* ids, in
 
 extern "C" int fgt_split(const float* x, long rows, int C, int ldx, void* out_s, int ld_s, long long ps, int relu, void* stream) {
     FGT_REQUIRE(x && out_s && rows > 0 && C > 0, "fgt_split: bad arguments");
+    if (C % 4 != 0) {       // channel pairs (planes layout): e.g. a 2-channel slice at the end of a wider split buffer
+        FGT_REQUIRE(C % 2 == 0 && ldx % 2 == 0 && ld_s % 2 == 0 && ps > 0 && ps % 2 == 0 && ps != 32 && ((uintptr_t)x & 7) == 0 && ((uintptr_t)out_s & 3) == 0,
+                    "fgt_split: C %% 4 != 0 needs even C, strides and plane stride (planes layout) and 8- / 4-byte aligned pointers");
+        FgtProfScope prof2(FGT_PROF_POINTWISE, 0.0, (double)rows * C * 8.0, stream);
+        hipLaunchKernelGGL(split2_kernel, dim3(grid_for(rows * (C / 2))), dim3(256), 0, (hipStream_t)stream, x, rows, C / 2, ldx,
+                           static_cast<__bf16*>(out_s), ld_s, (long)ps, relu);
+        return fgt_check_launch("split2");
+    }
     FGT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ld_s % 4 == 0 && (ps == -1 || (ps > 0 && ps % 4 == 0)) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out_s & 7) == 0,
                 "fgt_split: C, strides must be multiples of 4 and pointers aligned");
     FgtProfScope prof(FGT_PROF_POINTWISE, 0.0, (double)rows * C * (4.0 + (ps < 0 ? 2.0 : 4.0)), stream);

@@ -131,19 +131,46 @@ class P3DNet(nn.Module):
         ops.axpby(y.reshape(-1, C), 1.0, aux1.reshape(-1, C), 1.0, act=act2, slope=slope, out=tgt.reshape(-1, C))
         return tgt
 
-    def _p3d(self, x, b, T, blk):
-        """x [b*T, H, W, C] -> P3DBlock output (lafc.py:117-125)."""
+    # ---- split chains (vanilla convs, bf16x3 arithmetic): a conv whose output only feeds other convs writes it PRE-SPLIT (ops.Split, bf16 hi /
+    # lo pair) and the consumer's im2col tiles become plain LDS-DMA copies (csrc/conv_split.hip) — bit-identical to handing fp32 tensors to
+    # the bf16x3 kernel.  `want`: "s" = split only, "both" = (fp32, split) for outputs that are ALSO an epilogue operand (residuals) or
+    # feed a Cout <= 4 VALU conv, "f32" = fp32 only.  Without split chains (exact-fp32 mode, gated convs) every form is the fp32 tensor.
+    def _sc(self):
+        return (not self.gated) and ops.DEFAULT_CONV_PRECISION != "fp32"
+
+    def _cv(self, x, packed, want="s", **kw):
+        """One conv block; returns (tensor for conv consumers, fp32 tensor or None)."""
+        if not self._sc():
+            y = self._block(x, packed, **kw)
+            return y, y
+        if want == "f32":
+            y = self._block(x, packed, **kw)
+            return y, y
+        r = ops.conv2d(x, packed[0], act=kw.pop("act", "lrelu"), slope=kw.pop("slope", 0.2), out_split="only" if want == "s" else "both", out_h=False, **kw)
+        return (r, None) if want == "s" else (r[1], r[0])
+
+    @staticmethod
+    def _v(t, *shape):
+        return t.view(*shape)
+
+    def _p3d(self, x, b, T, blk, want="s", x_f32=None):
+        """x [b*T, H, W, C] (fp32 tensor or Split) -> P3DBlock output (lafc.py:117-125) in the forms `want` asks for;
+        x_f32: the fp32 form of x (the residual operand) when x is a Split."""
         c1, c2, (k, stride, pad, residual) = blk
-        y = self._block(x, c1, stride=stride, pad=pad if k != 5 else 2, pad_mode="zeros" if k != 5 else "replicate")
+        y, _ = self._cv(x, c1, "s", stride=stride, pad=pad if k != 5 else 2, pad_mode="zeros" if k != 5 else "replicate")
         bT, H, W, C = y.shape
         yt = y.view(b, T, H * W, C)
         if residual:
-            return self._block(yt, c2, pad=(1, 0), epi="add", aux1=x.view(b, T, H * W, C)).view(bT, H, W, C)
-        return self._block(yt, c2, pad=(1, 0)).view(bT, H, W, C)
+            res = (x_f32 if x_f32 is not None else x).view(b, T, H * W, C)
+            o, o32 = self._cv(yt, c2, want, pad=(1, 0), epi="add", aux1=res)
+        else:
+            o, o32 = self._cv(yt, c2, want, pad=(1, 0))
+        return o.view(bT, H, W, C), (None if o32 is None else o32.view(bT, H, W, C))
 
-    def _condense(self, x, b, T, pk):
+    def _condense(self, x, b, T, pk, want="s"):
         bT, H, W, C = x.shape
-        return self._block(x.view(b, T, H * W, C), pk, pad=0).view(b, H, W, -1)
+        o, o32 = self._cv(x.view(b, T, H * W, C), pk, want, pad=0)
+        return o.view(b, H, W, -1)
 
     def forward(self, flows, masks, edges=None):
         with torch.no_grad():
@@ -172,29 +199,29 @@ class P3DNet(nn.Module):
             ops.nchw_to_nhwc(p.permute(0, 2, 1, 3, 4).reshape(b * T, c, H, W).float(), x, coff=off)
             off += c
         assert off == self.in_channels, f"input channels {off} != in_channel {self.in_channels}"
-        e2 = self._p3d(x, b, T, P["encoder2"][0])
-        e2 = self._p3d(e2, b, T, P["encoder2"][1])
+        e2, _ = self._p3d(x, b, T, P["encoder2"][0])
+        e2, e2_32 = self._p3d(e2, b, T, P["encoder2"][1], want="both" if P["encoder4"][0][2][3] else "s")     # also the residual of encoder4.0
         c_e2pre = self._condense(e2, b, T, P["condense2"])
-        e4 = self._p3d(e2, b, T, P["encoder4"][0])
-        e4 = self._p3d(e4, b, T, P["encoder4"][1])
+        e4, _ = self._p3d(e2, b, T, P["encoder4"][0], x_f32=e2_32)
+        e4, e4_32 = self._p3d(e4, b, T, P["encoder4"][1], want="both" if P["res"] else "s")
         c_e4pre = self._condense(e4, b, T, P["condense4_pre"])
-        for blk in P["res"]:
-            e4 = self._p3d(e4, b, T, blk)
+        for i, blk in enumerate(P["res"]):
+            e4, e4_32 = self._p3d(e4, b, T, blk, want="both" if i + 1 < len(P["res"]) else "s", x_f32=e4_32)
         y = self._condense(e4, b, T, P["condense4_post"])
         for pk, d in zip(P["middle"], (8, 4, 2, 1)):
-            y = self._block(y, pk, pad=d, dil=d)
-        y = self._block(y, P["decoder2"][0], x1=c_e4pre, pad=1, upsample=True)        # cat(filled, pre) + nearest x2
-        y = self._block(y, P["decoder2"][1], pad=1)
-        y = self._block(y, P["decoder2"][2], pad=1)
-        y = self._block(y, P["decoder"][0], x1=c_e2pre, pad=1, upsample=True)
-        y = self._block(y, P["decoder"][1], pad=1)
+            y, _ = self._cv(y, pk, "s", pad=d, dil=d)
+        y, _ = self._cv(y, P["decoder2"][0], "s", x1=c_e4pre, pad=1, upsample=True)        # cat(filled, pre) + nearest x2
+        y, _ = self._cv(y, P["decoder2"][1], "s", pad=1)
+        y, _ = self._cv(y, P["decoder2"][2], "s", pad=1)
+        y, _ = self._cv(y, P["decoder"][0], "s", x1=c_e2pre, pad=1, upsample=True)
+        y, _ = self._cv(y, P["decoder"][1], "f32", pad=1)                                  # feeds the Cout = 2 VALU conv: fp32
         fbuf = torch.zeros(b, H, W, 4, dtype=torch.float32, device=dev)               # flow in channels 0..1, zero pad for the edge head
         self._block(y, P["decoder"][2], act=None, pad=1, out=fbuf[..., :2])
         flow = ops.nhwc_to_nchw(fbuf[..., :2])
         E = P["edge"]
-        pr = self._block(fbuf, E[0], pad=1)
-        ed = self._block(pr, E[1], pad=1)
-        ed = self._block(ed, E[2], act=None, pad=1, slope=0.01, epi="add", aux1=pr, act2="lrelu")   # LeakyReLU() default 0.01
+        pr, pr32 = self._cv(fbuf, E[0], "both", pad=1)
+        ed, _ = self._cv(pr, E[1], "s", pad=1)
+        ed, _ = self._cv(ed, E[2], "f32", act=None, pad=1, slope=0.01, epi="add", aux1=pr32, act2="lrelu")   # LeakyReLU() default 0.01
         if E[3][1] is None:
             edge = ops.conv2d(ed, E[3][0], pad=0, act="sigmoid", out_nchw=True)
         else:

@@ -136,6 +136,16 @@ class Split:
             return Split(self.data[idx], h=True)
         return Split(self.data[idx], True) if self.il else Split(self.data[:, idx])
 
+    def channels(self, c0, c1):
+        """Channel slice [c0, c1) of the last dimension as a Split view of the same storage (writers fill slices of a wider buffer in
+        place: RAFT's GRU input [inp | motion | flow]); interleaved: multiples of 32."""
+        if self.h:
+            return Split(self.data[..., c0:c1], h=True)
+        if self.il:
+            assert c0 % 32 == 0 and c1 % 32 == 0
+            return Split(self.data[..., 2 * c0:2 * c1], True)
+        return Split(self.data[..., c0:c1])
+
     def planes(self):
         """(hi, lo) as bf16 tensors of the logical shape (tests / debugging)."""
         assert not self.h, "an fp16 Split has one plane"
@@ -266,7 +276,7 @@ def prepack_weights(pc, mode=None):
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
            epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None,
-           out_split=None, out_s=None, out_il=False):
+           out_split=None, out_s=None, out_il=False, out_h=None):
     """fgt_conv2d.  x (and optional x1) are channels-last maps (fp32 tensors, or `Split`s for the LDS-DMA bf16x3 path);
     returns/outputs a channels-last map (or NCHW).  out_split: None -> fp32 result; "only" -> a Split; "both" -> (fp32, Split)."""
     in_split = isinstance(x, Split)
@@ -330,7 +340,9 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     d.out_split = osp
     if osp:
         if out_s is None:
-            out_s = Split.empty((N, Ho, Wo, pc.Cout), x.device, interleaved=bool(out_il))
+            # out_h: None = the split output follows the arithmetic mode (fp16 plane in 'f16'), False = always the bf16 pair (RAFT / LAFC
+            # stay in bf16x3 under the 'f16' switch)
+            out_s = Split.empty((N, Ho, Wo, pc.Cout), x.device, interleaved=bool(out_il), h=False if out_il else out_h)
         s4, sN, sH, sW, sC, ldo_s = _as_map(out_s.hi)
         assert (sN * sH * sW, sC) == (N * Ho * Wo, pc.Cout * (2 if out_s.il else 1)), f"conv2d: out_s shape {tuple(out_s.shape)}"
         d.ldo_s, d.ooff_s, d.pso = ldo_s, 0, out_s.ps

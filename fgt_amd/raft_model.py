@@ -146,6 +146,11 @@ class RAFT(nn.Module):
             u = self.update_block
             P = {"fnet": self._pack_encoder(self.fnet), "cnet": self._pack_encoder(self.cnet)}
             P["enc"] = {n: self._pk(getattr(u.encoder, n)) for n in ("convc1", "convc2", "convf1", "convf2", "conv")}
+            # the same conv with 2 zero output channels appended (126 -> 128): in the split chain its epilogue writes the GRU input buffer's
+            # channels 128..255 as one aligned 128-channel slice (relu(0) = 0 lands in the two flow channels, which are written right after)
+            cw, cb = u.encoder.conv.weight.detach(), u.encoder.conv.bias.detach()
+            P["enc"]["conv128"] = PackedConv(torch.cat([cw, torch.zeros(2, *cw.shape[1:], device=cw.device, dtype=cw.dtype)], 0),
+                                             torch.cat([cb, torch.zeros(2, device=cb.device, dtype=cb.dtype)], 0))
             P["gru"] = {n: self._pk(getattr(u.gru, n)) for n in ("convz1", "convr1", "convq1", "convz2", "convr2", "convq2")}
             P["fh"] = (self._pk(u.flow_head.conv1), self._pk(u.flow_head.conv2))
             P["mask"] = (self._pk(u.mask[0]), self._pk(u.mask[2]))
@@ -238,30 +243,61 @@ class RAFT(nn.Module):
         corr = torch.empty(B * n, 324, dtype=torch.float32, device=dev)
         E, G = P["enc"], P["gru"]
         m4 = lambda t2: t2.view(B, h8, w8, t2.shape[1]) if t2.is_contiguous() else t2.unflatten(0, (B, h8, w8))
+        # bf16x3 arithmetic: the conv -> conv chains of the update block hand their activations over PRE-SPLIT (ops.Split, bf16 hi / lo pairs:
+        # the consumer's im2col tiles are plain LDS-DMA copies, csrc/conv_split.hip) — the same arithmetic as feeding fp32 tensors to the
+        # bf16x3 kernel, bit for bit.  Under the 'f16' mode RAFT stays in bf16x3 (h = False: bf16 pairs, never fp16 planes).
+        sc = ops.DEFAULT_CONV_PRECISION != "fp32"
+        rows = B * n
+        S = lambda ch: ops.Split.empty((rows, ch), dev, h=False)
+        s4 = lambda sp: sp.view(B, h8, w8, sp.shape[-1])
+        if sc:
+            cor1_s, cor2_s, flo1_s, flo2_s, rh_s, net_s, xbuf_s = S(256), S(192), S(128), S(64), S(128), S(128), S(256)
+            ops.split(cmap.view(rows, 256)[:, 128:], relu=True, out=xbuf_s.channels(0, 128))       # inp = relu(cnet[:, 128:])
+            ops.split(net, out=net_s)
+            motion_s, flow_s = xbuf_s.channels(128, 256), xbuf_s.channels(254, 256)
         ups = []
         for it in range(iters):
             ops.corr_lookup(pyr, B, h8, w8, self.corr_radius, coords1, m4(corr))
             ops.axpby(coords1, 1.0, coords0, -1.0, out=flow4[:, :2])               # flow = coords1 - coords0
-            # BasicMotionEncoder (update.py:62-76)
-            cor = ops.conv2d(m4(corr), E["convc1"], act="relu")
-            cor = ops.conv2d(cor, E["convc2"], pad=1, act="relu")
-            flo = ops.conv2d(m4(flow4), E["convf1"], pad=3, act="relu")
-            flo = ops.conv2d(flo, E["convf2"], pad=1, act="relu")
-            ops.conv2d(cor, E["conv"], x1=flo, pad=1, act="relu", out=m4(xbuf)[..., 128:254])
-            ops.axpby(flow4[:, :2], out=xbuf[:, 254:256])
-            # SepConvGRU (update.py:36-60): horizontal then vertical pass
-            for s, pad in (("1", (0, 2)), ("2", (2, 0))):
-                z = ops.conv2d(m4(net), G["convz" + s], x1=m4(xbuf), pad=pad, act="sigmoid")
-                rh = ops.conv2d(m4(net), G["convr" + s], x1=m4(xbuf), pad=pad, act="sigmoid", epi="mul", aux1=net)
-                net = ops.conv2d(rh, G["convq" + s], x1=m4(xbuf), pad=pad, act="tanh", epi="gru", aux1=z, aux2=net).view(B * n, 128)
+            if sc:
+                # BasicMotionEncoder (update.py:62-76)
+                ops.conv2d(m4(corr), E["convc1"], act="relu", out_split="only", out_s=cor1_s)
+                ops.conv2d(s4(cor1_s), E["convc2"], pad=1, act="relu", out_split="only", out_s=cor2_s)
+                ops.conv2d(m4(flow4), E["convf1"], pad=3, act="relu", out_split="only", out_s=flo1_s)
+                ops.conv2d(s4(flo1_s), E["convf2"], pad=1, act="relu", out_split="only", out_s=flo2_s)
+                ops.conv2d(s4(cor2_s), E["conv128"], x1=s4(flo2_s), pad=1, act="relu", out_split="only", out_s=motion_s)
+                ops.split(flow4[:, :2], out=flow_s)
+                # SepConvGRU (update.py:36-60): horizontal then vertical pass; z stays fp32 (an epilogue operand), r * h goes on split, the new
+                # hidden state is written in both forms (fp32: the next pass's epilogue operands and the heads; split: the next convs' input)
+                for s_, pad in (("1", (0, 2)), ("2", (2, 0))):
+                    z = ops.conv2d(s4(net_s), G["convz" + s_], x1=s4(xbuf_s), pad=pad, act="sigmoid")
+                    ops.conv2d(s4(net_s), G["convr" + s_], x1=s4(xbuf_s), pad=pad, act="sigmoid", epi="mul", aux1=net, out_split="only", out_s=rh_s)
+                    net, _ = ops.conv2d(s4(rh_s), G["convq" + s_], x1=s4(xbuf_s), pad=pad, act="tanh", epi="gru", aux1=z, aux2=net, out_split="both", out_s=net_s)
+                    net = net.view(rows, 128)
+                d = ops.conv2d(s4(net_s), P["fh"][0], pad=1, act="relu")
+            else:
+                cor = ops.conv2d(m4(corr), E["convc1"], act="relu")
+                cor = ops.conv2d(cor, E["convc2"], pad=1, act="relu")
+                flo = ops.conv2d(m4(flow4), E["convf1"], pad=3, act="relu")
+                flo = ops.conv2d(flo, E["convf2"], pad=1, act="relu")
+                ops.conv2d(cor, E["conv"], x1=flo, pad=1, act="relu", out=m4(xbuf)[..., 128:254])
+                ops.axpby(flow4[:, :2], out=xbuf[:, 254:256])
+                for s_, pad in (("1", (0, 2)), ("2", (2, 0))):
+                    z = ops.conv2d(m4(net), G["convz" + s_], x1=m4(xbuf), pad=pad, act="sigmoid")
+                    rh = ops.conv2d(m4(net), G["convr" + s_], x1=m4(xbuf), pad=pad, act="sigmoid", epi="mul", aux1=net)
+                    net = ops.conv2d(rh, G["convq" + s_], x1=m4(xbuf), pad=pad, act="tanh", epi="gru", aux1=z, aux2=net).view(B * n, 128)
+                d = ops.conv2d(m4(net), P["fh"][0], pad=1, act="relu")
             # FlowHead + coords update (update.py:6-15, raft.py:131-132)
-            d = ops.conv2d(m4(net), P["fh"][0], pad=1, act="relu")
             new_coords = torch.empty_like(coords1)
             ops.conv2d(d, P["fh"][1], pad=1, epi="add", aux1=coords1, out=m4(new_coords))
             coords1 = new_coords
             if (not test_mode) or it == iters - 1:                                  # only the last mask is consumed in test_mode
-                mk = ops.conv2d(m4(net), P["mask"][0], pad=1, act="relu")
-                mk = ops.conv2d(mk, P["mask"][1], out_scale=0.25)
+                if sc:
+                    mk = ops.conv2d(s4(net_s), P["mask"][0], pad=1, act="relu", out_split="only", out_s=S(256))
+                    mk = ops.conv2d(s4(mk), P["mask"][1], out_scale=0.25)
+                else:
+                    mk = ops.conv2d(m4(net), P["mask"][0], pad=1, act="relu")
+                    mk = ops.conv2d(mk, P["mask"][1], out_scale=0.25)
                 ops.axpby(coords1, 1.0, coords0, -1.0, out=flow4[:, :2])
                 ups.append(ops.convex_upsample(m4(flow4), mk))
         if test_mode:

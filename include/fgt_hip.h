@@ -174,7 +174,9 @@ int fgt_conv2d(const fgt_conv_desc* d, const void* x0, const void* x1, const flo
 
 /* fp32 [rows, C] (row stride ldx floats) -> split tensor (hi plane at out_s, lo plane `ps` bf16 elements further, row stride
  * ld_s); relu = 1 applies max(x, 0) first.  For activations whose producer is not one of the fused ones.  C % 4 == 0.
- * ps == -1: out_s is ONE fp16 plane = f16_rne(x) (fgt_conv_desc.in_split = 3). */
+ * ps == -1: out_s is ONE fp16 plane = f16_rne(x) (fgt_conv_desc.in_split = 3).
+ * C % 4 == 2 (planes layout only; strides and ps even): channel pairs, e.g. RAFT's 2-channel flow written into the last two channels of the
+ * split GRU input buffer (RAFT/update.py:126 `cat([inp, motion_features])`). */
 int fgt_split(const float* x, long rows, int C, int ldx, void* out_s, int ld_s, long long ps, int relu, void* stream);
 
 /* Row LayerNorm over the concatenation [x0 | x1] (C1 = 0: single source), eps inside rsqrt.

@@ -59,10 +59,19 @@ class Split:
         s.h, s.x = self.h, self.x.view(*shape)
         return s
 
+    def channels(self, c0, c1):
+        s = Split.__new__(Split)
+        s.h, s.x = self.h, self.x[..., c0:c1]
+        return s
 
-def split(x, relu=False, out=None):
+
+def split(x, relu=False, out=None, interleave=False, h=None):
     assert not isinstance(x, Split), "double split"
-    return Split(F.relu(x) if relu else x)
+    v = F.relu(x) if relu else x
+    if out is not None:
+        out.put(v.reshape(out.x.shape))
+        return out
+    return Split(v, h)
 
 
 def _dense_weight(pc):
@@ -73,11 +82,16 @@ def _dense_weight(pc):
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
            epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None,
-           out_split=None, out_s=None):
+           out_split=None, out_s=None, out_il=False, out_h=None):
     if out_split:
-        assert not out_nchw and out_s is None
+        assert not out_nchw
         y = conv2d(x, pc, x1, stride, pad, dil, upsample, pad_mode, in_relu, act, slope, epi, aux1, aux2, act2, out_scale, out)
-        return Split(y) if out_split == "only" else (y, Split(y))
+        if out_s is not None:                      # a preallocated Split (possibly a channel slice of a wider buffer)
+            out_s.put(y.reshape(out_s.x.shape))
+            sp = out_s
+        else:
+            sp = Split(y, out_h)
+        return sp if out_split == "only" else (y, sp)
     h16 = False
     if isinstance(x, Split):
         assert DEFAULT_CONV_PRECISION in ("bf16x3", "f16") or precision == "bf16x3", "Split inputs need the bf16x3 / f16 mode"

@@ -50,8 +50,12 @@ def fake(monkeypatch):
         monkeypatch.setattr(m, "PackedConv", fake_ops.PackedConv)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("ct", ["vanilla", "gated"])
-def test_lafc_host_logic_and_keys(fake, ct):
+def test_lafc_host_logic_and_keys(fake, ct, mode, monkeypatch):
+    """mode 'bf16x3' walks the split-chain plumbing (conv -> conv hand-overs as ops.Split, fp32 forms for residual operands and the
+    Cout <= 4 convs) over the CPU spec, whose Splits carry exact values: the result must not change."""
+    monkeypatch.setattr(fake_ops, "DEFAULT_CONV_PRECISION", mode)
     keys = json.load(open(os.path.join(GOLDEN, f"lafc_{ct}_state_keys.json")))
     m = lafc_model.Model(dict(lafc_model.DEFAULT_CONFIG, conv_type=ct)).eval()
     assert {k: list(v.shape) for k, v in m.state_dict().items()} == keys
@@ -61,7 +65,9 @@ def test_lafc_host_logic_and_keys(fake, ct):
     assert rel_err(flow, g["flow"]) < 2e-5 and max_err(edge, g["edge"]) < 2e-5
 
 
-def test_raft_host_logic_and_keys(fake):
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_raft_host_logic_and_keys(fake, mode, monkeypatch):
+    monkeypatch.setattr(fake_ops, "DEFAULT_CONV_PRECISION", mode)
     keys = json.load(open(os.path.join(GOLDEN, "raft_state_keys.json")))
     m = raft_model.RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).eval()
     assert {k: list(v.shape) for k, v in m.state_dict().items()} == keys
