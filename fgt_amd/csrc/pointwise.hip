@@ -13,13 +13,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // fp32 store, or (ps > 0) the split format: `out` then points at the hi plane of a bf16 tensor, offsets / ps in bf16 elements;
 // ps == -1: `out` is one fp16 plane (offsets in fp16 elements)
-__device__ __forceinline__ void store_f32_or_split(float* out, long off, long ps, const float4 v) {
+// ps == 32: the INTERLEAVED split layout (fgt_conv_desc.in_split = 2): channel c of a row lives at element (c / 32) * 64 + c % 32 (hi) and 32
+// further (lo) — `off` is then row * ld + c with ld the row stride in elements (>= 2 * C) and c the LOGICAL channel, passed separately
+__device__ __forceinline__ void store_f32_or_split(float* out, long off, long ps, const float4 v, int c = 0) {
     if (ps < 0) {
         *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(out) + off) = fgt_half4(v);
     } else if (ps > 0) {
         uint2 hi, lo;
         fgt_split4(v, hi, lo);
-        __bf16* o = reinterpret_cast<__bf16*>(out) + off;
+        __bf16* o = reinterpret_cast<__bf16*>(out) + (ps == 32 ? off - c + ((c >> 5) << 6) + (c & 31) : off);
         *reinterpret_cast<uint2*>(o) = hi;
         *reinterpret_cast<uint2*>(o + ps) = lo;
     } else {
@@ -67,10 +69,10 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* x0, int C0,
             const float4 n = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd,
                                          (v[i].w - mean) * rstd);
             const float4 g = *reinterpret_cast<const float4*>(gA + c), b = *reinterpret_cast<const float4*>(bA + c);
-            store_f32_or_split(outA, row * ldA + c, psA, make_float4(n.x * g.x + b.x, n.y * g.y + b.y, n.z * g.z + b.z, n.w * g.w + b.w));
+            store_f32_or_split(outA, row * ldA + c, psA, make_float4(n.x * g.x + b.x, n.y * g.y + b.y, n.z * g.z + b.z, n.w * g.w + b.w), c);
             if (outB) {
                 const float4 g2 = *reinterpret_cast<const float4*>(gB + c), b2 = *reinterpret_cast<const float4*>(bB + c);
-                store_f32_or_split(outB, row * ldB + c, psB, make_float4(n.x * g2.x + b2.x, n.y * g2.y + b2.y, n.z * g2.z + b2.z, n.w * g2.w + b2.w));
+                store_f32_or_split(outB, row * ldB + c, psB, make_float4(n.x * g2.x + b2.x, n.y * g2.y + b2.y, n.z * g2.z + b2.z, n.w * g2.w + b2.w), c);
             }
         }
     }
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(256) fold_kernel(const float* Y, int ldy, int 
             acc[0] = rv.x + acc[0]; acc[1] = rv.y + acc[1]; acc[2] = rv.z + acc[2]; acc[3] = rv.w + acc[3];
         }
         if (relu) { acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f); }
-        store_f32_or_split(out, pix * ldo + c, ps_out, make_float4(acc[0], acc[1], acc[2], acc[3]));
+        store_f32_or_split(out, pix * ldo + c, ps_out, make_float4(acc[0], acc[1], acc[2], acc[3]), c);
     }
 }
 
@@ -446,6 +448,8 @@ extern "C" int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, 
                 "fgt_layernorm: strides must be multiples of 4 floats");
     FGT_REQUIRE((psA == -1 || (psA >= 0 && psA % 4 == 0)) && (psB == -1 || (psB >= 0 && psB % 4 == 0)),
                 "fgt_layernorm: plane strides must be non-negative multiples of 4 (or -1: fp16 plane)");
+    FGT_REQUIRE((psA != 32 || ((C0 + C1) % 32 == 0 && ldA >= 2 * (C0 + C1))) && (psB != 32 || ((C0 + C1) % 32 == 0 && ldB >= 2 * (C0 + C1))),
+                "fgt_layernorm: an interleaved output (ps = 32) needs C %% 32 == 0 and a row stride of at least 2 * C elements");
     const auto ob = [](long long ps) { return ps < 0 ? 2.0 : 4.0; };
     FgtProfScope prof(FGT_PROF_LAYERNORM, 0.0, (double)rows * ((C0 + C1) * 4.0 + (C0 + C1) * (ob(psA) + (outB ? ob(psB) : 0.0))), stream);
     hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, rows,
@@ -487,6 +491,7 @@ extern "C" int fgt_fold(const float* Y, int ldy, int frames, int th, int tw, int
     const long total = (long)frames * Hf * Wf * (C / 4);
     FGT_REQUIRE(ps_out == -1 || (ps_out >= 0 && ps_out % 4 == 0), "fgt_fold: plane stride must be a non-negative multiple of 4 (or -1: fp16 plane)");
     FGT_REQUIRE(y_f16 == 0 || y_f16 == 1, "fgt_fold: y_f16 must be 0 or 1");
+    FGT_REQUIRE(ps_out != 32 || (C % 32 == 0 && ldo >= 2 * C), "fgt_fold: an interleaved output (ps_out = 32) needs C %% 32 == 0 and ldo >= 2 * C elements");
     FgtProfScope prof(FGT_PROF_FOLD, 0.0, (double)frames * th * tw * k * k * C * (y_f16 ? 2.0 : 4.0) +
                                               (double)frames * Hf * Wf * C * ((ps_out < 0 ? 2.0 : 4.0) + (res ? 4.0 : 0.0)), stream);
     if (y_f16)

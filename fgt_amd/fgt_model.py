@@ -389,7 +389,8 @@ class FGT(nn.Module):
         ng = (nh // gd) * (nw // gd)
         dev = x.device
         sc = self._split_chain()
-        new = (lambda r, ch: ops.Split.empty((r, ch), dev)) if sc else (lambda r, ch: torch.empty(r, ch, dtype=torch.float32, device=dev))
+        # (GEMM operands written by fgt_layernorm: interleaved hi/lo rows in bf16x3 mode — one 128-byte line per 32 channels for the wide kernel)
+        new = (lambda r, ch: ops.Split.empty((r, ch), dev, interleaved=ops.split_il(ch))) if sc else (lambda r, ch: torch.empty(r, ch, dtype=torch.float32, device=dev))
         # LN outputs = GEMM operands: rows [0, R) real tokens, row R the padded token, rows R+1.. the frames' global tokens
         kin, vin, q_ln = new(R + 1 + bt * ng, c + cf), new(R + 1 + bt * ng, c), new(R + 1, c + cf)
         gk = torch.empty(bt * ng, c + cf, dtype=torch.float32, device=dev)
@@ -463,16 +464,21 @@ class FGT(nn.Module):
                 x0 = e                                                         # model.py:58-59
             osp = ("both" if sc else None) if i == 8 else sc                   # the last layer also feeds fold()'s fp32 residual
             dst = o_enc if i == 8 else None
+            # split outputs: interleaved where every consumer is a single-source conv (layers 0-2 and the last one, which feeds patch2vec);
+            # layers 3-7 feed the two-source grouped convs, whose 640 -> 256 g8 member has 48 channels per group from the second source (not
+            # a multiple of 32) and both sources of a conv share one layout: planes there
+            il = ops.split_il(E[i].Cout) and (i <= 2 or i == 8)
             if i <= 4:
-                e = ops.conv2d(e, E[i], stride=strides[i], pad=1, act="lrelu", out_split=osp, out=dst)
+                e = ops.conv2d(e, E[i], stride=strides[i], pad=1, act="lrelu", out_split=osp, out=dst, out_il=il)
             else:
-                e = ops.conv2d(x0, E[i], x1=e, stride=1, pad=1, act="lrelu", out_split=osp, out=dst)    # grouped concat, model.py:60-65
+                e = ops.conv2d(x0, E[i], x1=e, stride=1, pad=1, act="lrelu", out_split=osp, out=dst, out_il=il)    # grouped concat, model.py:60-65
         enc, enc_in = e if sc else (e, e)
         FE = P["fenc"]
-        fe = self._block(f_in, FE[0], stride=1, pad=2, pad_mode="replicate", out_split=sc)    # ReplicationPad2d(2) + 5x5 conv
-        fe = self._block(fe, FE[1], stride=2, pad=1, out_split=sc)
-        fe = self._block(fe, FE[2], stride=1, pad=1, out_split=sc)
-        fe = self._block(fe, FE[3], stride=2, pad=1, out_split=sc)
+        il = lambda blk: ops.split_il(blk[0].Cout)
+        fe = self._block(f_in, FE[0], stride=1, pad=2, pad_mode="replicate", out_split=sc, out_il=il(FE[0]))    # ReplicationPad2d(2) + 5x5 conv
+        fe = self._block(fe, FE[1], stride=2, pad=1, out_split=sc, out_il=il(FE[1]))
+        fe = self._block(fe, FE[2], stride=1, pad=1, out_split=sc, out_il=il(FE[2]))
+        fe = self._block(fe, FE[3], stride=2, pad=1, out_split=sc, out_il=il(FE[3]))
         s, p = cfg["s"][0], cfg["p"][0]
         tok = ops.conv2d(enc_in, P["p2v"], stride=s, pad=p, out=None if o_tok is None else o_tok.view(bt, th, tw, -1))
         ftok = ops.conv2d(fe, P["fp2v"], stride=s, pad=p, out=None if o_ftok is None else o_ftok.view(bt, th, tw, -1))
@@ -536,8 +542,8 @@ class FGT(nn.Module):
         # soft composition + encoder residual; split mode: written pre-split for the decoder's first conv (its only consumer)
         feat = ops.fold(Y, bt, th, tw, P["v2p_c"], cfg["k"][0], cfg["s"][0], cfg["p"][0], Hf, Wf, normalize=False, res=enc, out_split=bool(sc))
         D = P["dec"]
-        y = self._block(feat, D[0], stride=1, pad=1, upsample=True, out_split=sc)
-        y = self._block(y, D[1], stride=1, pad=1, out_split=sc)
+        y = self._block(feat, D[0], stride=1, pad=1, upsample=True, out_split=sc, out_il=ops.split_il(D[0][0].Cout))
+        y = self._block(y, D[1], stride=1, pad=1, out_split=sc, out_il=ops.split_il(D[1][0].Cout))
         # the Cout = 3 kernel below gathers fp32 — or, in the f16 mode, the fp16 map (64 channels at full resolution: the largest activation
         # of the path, 2.3 GB per clip pass as fp32); its LDS-tiled form needs an 8 x 32 output tile
         h_last = self._f16() and 4 * Hf >= 8 and 4 * Wf >= 32 and D[3][0].Cg % 16 == 0 and D[3][0].Cout <= 4

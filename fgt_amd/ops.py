@@ -29,13 +29,15 @@ TILE_CANDIDATES = ("128x128", "64x64", "128x64", "256x128", "128x32", "128x128x8
                    "128x128ea", "64x64ea", "128x64ea", "128x128x8ea", "256x128x16ea", "256x64x8ea",
                    # fp16 kernel only (csrc/conv_f16.hip): one more early-release tile, and every tile on the wide LDS image
                    "256x128ea", "128x128w", "64x64w", "128x64w", "256x128w", "128x32w", "128x128x8w", "256x128x16w", "256x64x8w",
-                   "128x128eaw", "64x64eaw", "128x64eaw", "128x128x8eaw", "256x128x16eaw", "256x64x8eaw", "256x128eaw")
+                   "128x128eaw", "64x64eaw", "128x64eaw", "128x128x8eaw", "256x128x16eaw", "256x64x8eaw", "256x128eaw",
+                   # bf16x3 on interleaved inputs only (csrc/conv_wide.hip): the 8-phase schedule on 256-row tiles
+                   "256x256p8w", "256x128p8w")
 _tile_cache = {}
 
 
 def mode_key():
     """Everything outside the tensors that changes what a launch sequence computes: graph caches key on it (fgt_amd/graph.py)."""
-    return (DEFAULT_CONV_PRECISION, DEFAULT_ATTN_PRECISION, WEIGHTS_INTERLEAVED)
+    return (DEFAULT_CONV_PRECISION, DEFAULT_ATTN_PRECISION, WEIGHTS_INTERLEAVED, SPLIT_INTERLEAVED)
 
 
 def tuning_table():
@@ -231,6 +233,16 @@ class PackedConv:
 
 
 WEIGHTS_INTERLEAVED = os.environ.get("FGT_W_IL", "1") != "0"
+# bf16x3 mode: split tensors whose producer can write the interleaved layout ([hi 32 | lo 32] per 32 channels: conv epilogue, fgt_split,
+# fgt_layernorm, fgt_fold) and whose consumers are convs / GEMMs use it, so that the consumer can run on the wide LDS image (csrc/conv_wide.hip:
+# 8-row x 128-byte LDS-DMA pieces; the autotuner picks per shape between it and the 16-row x 64-byte kernel).  Same values, same products:
+# results are bit-identical either way.  FGT_SPLIT_IL=0: planes everywhere (A/B measurements).
+SPLIT_INTERLEAVED = os.environ.get("FGT_SPLIT_IL", "1") != "0"
+
+
+def split_il(channels):
+    """Should a new split tensor of `channels` channels be interleaved?  (bf16 pairs only: the 'f16' mode has its own single-plane format)"""
+    return SPLIT_INTERLEAVED and DEFAULT_CONV_PRECISION == "bf16x3" and channels % 32 == 0
 
 
 def _f16_weights(pc):
@@ -441,25 +453,26 @@ def linear(x, pc, **kw):
     return {None: out, False: out, "only": out_s, "both": (out, out_s)}[osp]
 
 
-def _out_desc(t):
-    """(pointer-holding tensor, row stride, plane stride) of an fp32 tensor (ps = 0) or a planes-layout Split."""
+def _out_desc(t, allow_il=False):
+    """(pointer-holding tensor, row stride, plane stride) of an fp32 tensor (ps = 0) or a Split (interleaved: ps = 32, row stride in
+    elements of the 2C-wide rows — fgt_layernorm / fgt_fold; the attention kernels write planes or fp16 only)."""
     if isinstance(t, Split):
-        assert not t.il, "fused split outputs use the planes layout (or fp16)"
+        assert allow_il or not t.il, "this producer writes the planes layout (or fp16)"
         return t.hi, t.hi.stride(0), t.ps
     return t, (0 if t is None else t.stride(0)), 0
 
 
 def layernorm(x0, gA, bA, x1=None, gB=None, bB=None, outA=None, outB=None, eps=1e-5, splitA=False, splitB=False):
     """Row LayerNorm over [x0 | x1]; optional second affine output sharing the statistics.  splitA / splitB (or passing a
-    Split as outA / outB) writes that output pre-split for the GEMM that consumes it."""
+    Split as outA / outB) writes that output pre-split for the GEMM that consumes it (interleaved when split_il() says so)."""
     _require_dev(x0, x1, gA, bA, gB, bB)
     rows, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[1]
     if outA is None:
-        outA = Split.empty((rows, C0 + C1), x0.device) if splitA else torch.empty(rows, C0 + C1, dtype=torch.float32, device=x0.device)
+        outA = Split.empty((rows, C0 + C1), x0.device, split_il(C0 + C1)) if splitA else torch.empty(rows, C0 + C1, dtype=torch.float32, device=x0.device)
     if gB is not None and outB is None:
-        outB = Split.empty((rows, C0 + C1), x0.device) if splitB else torch.empty(rows, C0 + C1, dtype=torch.float32, device=x0.device)
-    (tA, ldA, psA), (tB, ldB, psB) = _out_desc(outA), _out_desc(outB)
+        outB = Split.empty((rows, C0 + C1), x0.device, split_il(C0 + C1)) if splitB else torch.empty(rows, C0 + C1, dtype=torch.float32, device=x0.device)
+    (tA, ldA, psA), (tB, ldB, psB) = _out_desc(outA, True), _out_desc(outB, True)
     check(_lib.lib().fgt_layernorm(_ptr(x0), C0, x0.stride(0), _ptr(x1), C1, 0 if x1 is None else x1.stride(0), rows, eps,
                                    _ptr(gA), _ptr(bA), _ptr(tA), ldA, _ptr(gB), _ptr(bB), _ptr(tB), ldB, psA, psB, _stream()),
           "fgt_layernorm")
@@ -577,7 +590,7 @@ def fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize, res=None, out=None, 
         _require_dev(Y)
     _require_dev(res)
     if out is None:
-        out = Split.empty((frames, Hf, Wf, Cc), Y.device) if out_split else torch.empty(frames, Hf, Wf, Cc, dtype=torch.float32, device=Y.device)
+        out = Split.empty((frames, Hf, Wf, Cc), Y.device, split_il(Cc)) if out_split else torch.empty(frames, Hf, Wf, Cc, dtype=torch.float32, device=Y.device)
     ldres = 0 if res is None else _as_map(res)[5]
     if isinstance(out, Split):
         optr, ldo, ps = out.hi, _as_map(out.hi)[5], out.ps

@@ -185,7 +185,8 @@ int fgt_split(const float* x, long rows, int C, int ldx, void* out_s, int ld_s, 
  * Replaces nn.LayerNorm at FGT/models/model.py:126,128,147 and attention_flow.py:84-85,96 (q_norm/k_norm
  * share statistics for window tokens; v_norm).
  * psA / psB > 0: that output is written as a split tensor for the next GEMM (fgt_conv_desc.in_split): the pointer is the bf16 hi
- * plane, ld in bf16 elements, the lo plane ps elements further; 0 = fp32; -1 = one fp16 plane (fgt_conv_desc.in_split = 3). */
+ * plane, ld in bf16 elements, the lo plane ps elements further; 0 = fp32; -1 = one fp16 plane (fgt_conv_desc.in_split = 3);
+ * 32 = the interleaved layout of fgt_conv_desc.in_split = 2 (rows of >= 2 * C elements, C % 32 == 0: one 128-byte line per 32 channels). */
 int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, long rows, float eps,
                   const float* gA, const float* bA, float* outA, int ldA,
                   const float* gB, const float* bB, float* outB, int ldB, long long psA, long long psB, void* stream);
@@ -251,7 +252,8 @@ int fgt_dw3x3_residual(const float* x, int bt, int h, int w, int C, const float*
 int fgt_fold(const float* Y, int ldy, int frames, int th, int tw, int C, int k, int s, int p, int Hf, int Wf,
              int normalize, const float* res, int ldres, float* out, int ldo,
              int relu /* max(.,0) last: the FFN's ReLU in front of its second Linear, ffn_base.py:40 */,
-             long long ps_out /* > 0: `out` is the hi plane of a split tensor (bf16 elements), lo plane ps_out further; -1: one fp16 plane */,
+             long long ps_out /* > 0: `out` is the hi plane of a split tensor (bf16 elements), lo plane ps_out further (32: interleaved
+                               * layout, C % 32 == 0, ldo >= 2 * C); -1: one fp16 plane */,
              int y_f16 /* 1: Y is the fp16 plane a GEMM wrote with pso = -1 (ldy in fp16 elements); the sums stay fp32 */, void* stream);
 
 /* NCHW -> channels-last slice: dst[n, y, x, coff + c] = src[n, c, y, x] * scale + shift for c < C;

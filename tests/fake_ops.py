@@ -23,6 +23,10 @@ def _f16_mode():
     return DEFAULT_CONV_PRECISION == "f16"
 
 
+def split_il(channels):
+    return False                                  # layouts are not modelled on the CPU (ops.split_il)
+
+
 def f16_round(x):
     """The fp16 activation / weight format of the 'f16' mode (csrc/common.h fgt_half4): f16_rne(clamp(x, +-65504)), as fp32 values."""
     return x.clamp(-65504.0, 65504.0).to(torch.float16).float()
@@ -39,8 +43,8 @@ class Split:
         self.x = f16_round(x) if self.h else x
 
     @staticmethod
-    def empty(shape, device=None, h=None):
-        return Split(torch.zeros(tuple(shape)), h)
+    def empty(shape, device=None, interleaved=False, h=None):
+        return Split(torch.zeros(tuple(shape)), h)           # (the hi/lo layout — planes or interleaved — is a kernel property: not modelled)
 
     def put(self, val):
         self.x.copy_(f16_round(val) if self.h else val)

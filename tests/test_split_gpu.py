@@ -318,3 +318,61 @@ def test_fold_relu_split_output(dev):
     bsp = ops.conv2d(ops.fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize=True, relu=True, out_split=True), pc, stride=s, pad=p,
                      precision="bf16x3")
     assert torch.equal(a, bsp)
+
+
+# ---- interleaved split outputs of the fused producers (ps = 32) and the model on them
+def test_layernorm_and_fold_interleaved_outputs(dev, monkeypatch):
+    from fgt_amd import ops
+    rows = 501
+    x0, x1 = _rand(rows, 512, seed=1, scale=2.0).to(dev), _rand(rows, 256, seed=2).to(dev)
+    gA, bA, gB, bB = (_rand(768, seed=s).to(dev) for s in (3, 4, 5, 6))
+    pa, pb = ops.layernorm(x0, gA, bA, x1=x1, gB=gB, bB=bB, splitA=True, splitB=True)             # planes (default mode: fp32)
+    ia, ib = ops.Split.empty((rows + 7, 768), dev, interleaved=True), ops.Split.empty((rows, 768), dev, interleaved=True)
+    ia.data.zero_()
+    ops.layernorm(x0, gA, bA, x1=x1, gB=gB, bB=bB, outA=ia[:rows], outB=ib)                          # a row slice of a longer interleaved buffer
+    for il, pl in ((ia[:rows], pa), (ib, pb)):
+        hi, lo = il.planes()
+        assert torch.equal(hi, pl.data[0]) and torch.equal(lo, pl.data[1])
+    assert float(ia.data[rows:].float().abs().max()) == 0.0
+    monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", "bf16x3")                                   # split_il(): new split tensors are interleaved
+    auto = ops.layernorm(x0, gA, bA, x1=x1, splitA=True)
+    assert auto.il and torch.equal(auto.data, ia[:rows].data)
+    frames, th, tw, Cc, k, s, p, Hf, Wf = 2, 20, 36, 128, 7, 3, 3, 60, 108
+    Y = _rand(frames * th * tw, k * k * Cc, seed=7).to(dev)
+    res = _rand(frames, Hf, Wf, Cc, seed=8).to(dev)
+    f_il = ops.fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize=False, res=res, out_split=True)
+    monkeypatch.setattr(ops, "SPLIT_INTERLEAVED", False)
+    f_pl = ops.fold(Y, frames, th, tw, Cc, k, s, p, Hf, Wf, normalize=False, res=res, out_split=True)
+    assert f_il.il and not f_pl.il
+    hi, lo = f_il.planes()
+    assert torch.equal(hi, f_pl.data[0]) and torch.equal(lo, f_pl.data[1])
+
+
+def test_fgt_forward_bit_equal_with_interleaved_split_tensors(dev, monkeypatch):
+    """The bf16x3 model with its GEMM operands in the interleaved layout (LayerNorm / fold / conv epilogue write [hi 32 | lo 32] rows, the
+    consumers may run on the wide kernel) == the same model on planes, bit for bit, whatever tiles the autotuner picks."""
+    from fgt_amd import ops
+    from fgt_amd.fgt_model import DEFAULT_CONFIG, Model
+    from fgt_amd.synth import synth_state_dict
+    from util import fgt_inputs
+    monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", "bf16x3")
+    monkeypatch.setattr(ops, "DEFAULT_ATTN_PRECISION", "bf16x3")
+    m = Model(dict(DEFAULT_CONFIG)).eval()
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=0), strict=True)
+    m = m.to(dev)
+    mf, fl, ms = (t.to(dev) for t in fgt_inputs(64, 96, 3, seed=4))
+    outs = {}
+    for il in (True, False):
+        monkeypatch.setattr(ops, "SPLIT_INTERLEAVED", il)
+        outs[il] = m(mf, fl, ms).clone()
+    assert torch.equal(outs[True], outs[False])
+    # and with every conv forced onto a wide tile where its input is interleaved (the autotuner may not have picked one above)
+    real = ops.conv2d
+
+    def forced(x, pc, *a, **kw):
+        if isinstance(x, ops.Split) and x.il and kw.get("tile") is None and pc.Cout // pc.groups > 4:
+            kw["tile"] = "128x128x8eaw"
+        return real(x, pc, *a, **kw)
+    monkeypatch.setattr(ops, "SPLIT_INTERLEAVED", True)
+    monkeypatch.setattr(ops, "conv2d", forced)
+    assert torch.equal(m(mf, fl, ms), outs[False])

@@ -57,7 +57,9 @@ def wrap(name):
             pc = args[1]
             x1 = kw.get("x1")
             o = out[0] if isinstance(out, tuple) else out
-            M = o.numel() // pc.Cout
+            M = 1
+            for d_ in tuple(o.shape)[:-1]:
+                M *= d_
             flops = 2.0 * M * (pc.Cout // pc.groups) * pc.k_alg * pc.groups
             key = f"{name} {tuple(x.shape)} +{0 if x1 is None else x1.shape[-1]} -> {pc.Cout} k{pc.kh}x{pc.kw} {kw.get('act') or '-'} {kw.get('epi') or '-'}"
         elif hasattr(x, "shape"):
