@@ -318,19 +318,14 @@ int launch_tile(int tile, const ConvP& p, hipStream_t s) {
 
 }  // namespace
 
-static bool taps_enabled() {
-    static const int taps_env = [] { const char* e = getenv("FGT_CONV_TAPS"); return e ? atoi(e) : 1; }();
+#ifdef FGT_DIAG
+// diagnostic builds: the tap-reusing kernel (csrc/diag/conv_taps.hip) is reachable through its explicit tile codes (+ 200), and with
+// FGT_CONV_TAPS=1 every layer it serves is routed to it when desc.tile == 0 (so that whole-model measurements are possible)
+static bool taps_routing() {
+    static const int taps_env = [] { const char* e = getenv("FGT_CONV_TAPS"); return e ? atoi(e) : 0; }();
     return taps_env != 0;
 }
-
-extern "C" int fgt_conv_taps_route(const fgt_conv_desc* dd) {
-    if (!dd || !taps_enabled() || dd->groups <= 0 || dd->tile != 0) return 0;
-    ConvP p;
-    p.d = *dd;
-    p.Cg0 = dd->C0 / dd->groups; p.Cg1 = dd->C1 / dd->groups; p.Cg = p.Cg0 + p.Cg1; p.Cout_g = dd->Cout / dd->groups;
-    p.K = dd->kh * dd->kw * p.Cg;
-    return fgt_conv_taps_eligible(p) ? 1 : 0;
-}
+#endif
 
 extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* x1v, const float* w_packed,
                           const float* cscale, const float* cbias, const float* aux1, const float* aux2,
@@ -401,9 +396,14 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     p.out_s = static_cast<__bf16*>(out_s); p.pso = d.pso; p.ps0 = d.ps0; p.ps1 = d.C1 ? d.ps1 : d.ps0;
 
     int tile = d.tile;
-    const bool taps = taps_enabled() && (d.tile == 0 || d.tile >= FGT_TILE_TAPS) && fgt_conv_taps_eligible(p);
+#ifdef FGT_DIAG
+    const bool taps = ((d.tile == 0 && taps_routing()) || d.tile >= FGT_TILE_TAPS) && fgt_conv_taps_eligible(p);
     FGT_REQUIRE(d.tile < FGT_TILE_TAPS || taps, "fgt_conv2d: tile %d (tap-reusing kernel) on a layer it does not serve", d.tile);
     if (taps && tile == 0) tile = FGT_TILE_TAPS + (p.Cout_g <= 64 ? FGT_TILE_128x64 : FGT_TILE_128x128x8);
+#else
+    constexpr bool taps = false;
+    FGT_REQUIRE(d.tile < FGT_TILE_TAPS, "fgt_conv2d: tile %d (tap-reusing kernel) exists in diagnostic builds only", d.tile);
+#endif
     if (tile == 0) {
         // static fallback (profiles/r01_run2_tune_conv_*.txt); fgt_amd.ops autotunes per shape on first use
         if (p.Cout_g <= 32) tile = FGT_TILE_128x32;
@@ -431,7 +431,9 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     int rc;
     if (direct) rc = fgt_conv_direct(p, s);   // Cout <= 4: VALU direct conv (fp32)
     else if (d.in_split == 3) rc = fgt_conv_f16_launch(tile, p, s);
+#ifdef FGT_DIAG
     else if (taps) rc = fgt_conv_taps_launch(tile - FGT_TILE_TAPS, p, s);
+#endif
     else if (d.in_split == 2 && tile >= FGT_TILE_WIDE) {
         if (d.w_il != 1 || d.Kpad != p.K) { fgt_set_error("fgt_conv2d: the wide bf16x3 tiles need interleaved weights (w_il = 1) and K %% 32 == 0"); rc = FGT_EINVAL; }
         else rc = fgt_conv_wide_launch(tile - FGT_TILE_WIDE, p, s);

@@ -1,3 +1,7 @@
+// DIAGNOSTIC BUILDS ONLY (fgt_amd.build.build(variant="diag")): measured in round 3 and NOT adopted — correct (tests/test_taps_gpu.py: 20 geometries,
+// errors vs fp64 equal to conv_split's), 31-39 % fewer LDS-DMA instructions per flop, and 4-12 % SLOWER than the early-release kernel on every
+// layer but one (profiles/r03_run6_split_sweep_taps_vs_early_release.txt): the K loop is not bound by the LDS-DMA instruction count alone.
+//
 // bf16x3 implicit-GEMM convolution for STRIDE-1 "SAME" convolutions with kw >= 3 on pre-split (planes) operands: the im2col rows of a
 // (ky, 32-channel chunk) stay in LDS for ALL kx taps (gfx950).
 //
@@ -21,7 +25,7 @@
 // conv_tile.h: any 16 consecutive rows are conflict free, so the shifted reads are too), two B stages [hi BN | lo BN], one zero row.
 // 128x128: 2 * 18 KB + 2 * 16 KB = 68 KB: two workgroups per CU.  Schedule: per step the B tile of the next step and a third of the
 // next (ky, chunk)'s A rows are requested at the top, fragments read, MFMAs, vmcnt(0), barrier.
-#include "conv_tile.h"
+#include "../conv_tile.h"
 
 namespace {
 

@@ -32,9 +32,6 @@ TILE_CANDIDATES = ("128x128", "64x64", "128x64", "256x128", "128x32", "128x128x8
                    "128x128eaw", "64x64eaw", "128x64eaw", "128x128x8eaw", "256x128x16eaw", "256x64x8eaw", "256x128eaw",
                    # bf16x3 on interleaved inputs only (csrc/conv_wide.hip): the 8-phase schedule on 256-row tiles
                    "256x256p8w", "256x128p8w")
-# Layers that fgt_conv2d routes to the tap-reusing kernel (csrc/conv_taps.hip; decided by geometry: fgt_conv_taps_route) are tuned among ITS
-# tiles only: it accumulates in another order than the other kernels, so the kernel family must never depend on tuning.
-TAPS_CANDIDATES = ("128x128x8t", "128x128t", "128x64t", "64x64t")
 _tile_cache = {}
 
 
@@ -373,13 +370,12 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
             _ptr(None if out_s is None else out_s.data))
     if d.tile == 0 and AUTOTUNE and pc.Cout // pc.groups > 4:
         key = (N, H, W, C0, C1, pc.Cout, pc.groups, pc.kh, pc.kw, sh, sw, ph, pw, dh, dw, d.upsample, d.epi, d.out_nchw, d.precision,
-               d.in_split, d.out_split, d.w_il, int(bool(osp) and out_s.il) + 2 * int(bool(osp) and out_s.h))
+               d.in_split, d.out_split, d.w_il, int(bool(osp) and out_s.il) + 2 * int(bool(osp) and out_s.h), d.pad_mode, d.in_relu)
         best = _tile_cache.get(key)
         if best is None and not torch.cuda.is_current_stream_capturing() and not _aliases(out, out_s, x, x1, aux1, aux2):
             # (tuning re-launches the kernel into the caller's buffers and synchronises: illegal under stream capture, and it would
             #  corrupt an output that aliases an input / aux operand — such calls run on the static tile and are not cached)
-            taps = bool(_lib.lib().fgt_conv_taps_route(C.byref(d)))
-            best = _tile_cache[key] = _autotune(d, args, TAPS_CANDIDATES if taps else TILE_CANDIDATES)
+            best = _tile_cache[key] = _autotune(d, args)
         d.tile = best or 0
     check(_lib.lib().fgt_conv2d(*args, _stream()), "fgt_conv2d")
     return {0: out, 1: out_s, 2: (out, out_s)}[osp]
