@@ -320,7 +320,7 @@ int launch_tile(int tile, const ConvP& p, hipStream_t s) {
 
 #ifdef FGT_DIAG
 // diagnostic builds: the tap-reusing kernel (csrc/diag/conv_taps.hip) is reachable through its explicit tile codes (+ 200), and with
-// FGT_CONV_TAPS=1 every layer it serves is routed to it when desc.tile == 0 (so that whole-model measurements are possible)
+// FGT_CONV_TAPS=1 every layer it serves is routed to it whatever tile the descriptor names (so that whole-model measurements are possible)
 static bool taps_routing() {
     static const int taps_env = [] { const char* e = getenv("FGT_CONV_TAPS"); return e ? atoi(e) : 0; }();
     return taps_env != 0;
@@ -397,9 +397,9 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
 
     int tile = d.tile;
 #ifdef FGT_DIAG
-    const bool taps = ((d.tile == 0 && taps_routing()) || d.tile >= FGT_TILE_TAPS) && fgt_conv_taps_eligible(p);
+    const bool taps = (taps_routing() || d.tile >= FGT_TILE_TAPS) && fgt_conv_taps_eligible(p);
     FGT_REQUIRE(d.tile < FGT_TILE_TAPS || taps, "fgt_conv2d: tile %d (tap-reusing kernel) on a layer it does not serve", d.tile);
-    if (taps && tile == 0) tile = FGT_TILE_TAPS + (p.Cout_g <= 64 ? FGT_TILE_128x64 : FGT_TILE_128x128x8);
+    if (taps && tile < FGT_TILE_TAPS) tile = FGT_TILE_TAPS + (p.Cout_g <= 64 ? FGT_TILE_128x64 : FGT_TILE_128x128x8);   // (FGT_CONV_TAPS=1 overrides tuned tiles too)
 #else
     constexpr bool taps = false;
     FGT_REQUIRE(d.tile < FGT_TILE_TAPS, "fgt_conv2d: tile %d (tap-reusing kernel) exists in diagnostic builds only", d.tile);

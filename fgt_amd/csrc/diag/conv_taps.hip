@@ -1,30 +1,32 @@
-// DIAGNOSTIC BUILDS ONLY (fgt_amd.build.build(variant="diag")): measured in round 3 and NOT adopted — correct (tests/test_taps_gpu.py: 20 geometries,
-// errors vs fp64 equal to conv_split's), 31-39 % fewer LDS-DMA instructions per flop, and 4-12 % SLOWER than the early-release kernel on every
-// layer but one (profiles/r03_run6_split_sweep_taps_vs_early_release.txt): the K loop is not bound by the LDS-DMA instruction count alone.
+// DIAGNOSTIC BUILDS ONLY (fgt_amd.build.build(variant="diag")) until it beats the early-release tiles of conv_split.hip / conv_wide.hip.
+// Version 1 of this kernel (round 3, git history) was correct and 4-12 % SLOWER than those tiles with 31 % fewer LDS-DMA instructions
+// (profiles/r03_run6_split_sweep_taps_vs_early_release.txt).  Its K loop carried 118 VALU + 131 SALU instructions per step next to 12 MFMAs
+// (the early-release kernel: 70 + 42), 40 of them v_readlane reloads of spilled scalars, and one B tile in flight instead of two.  This is
+// version 2: kw is a template parameter (the kx loop is unrolled: piece ownership, shifts and wait counts are compile-time), the weight
+// pointers and the im2col source are iterators (one add per piece and step), the zero row is a ROW INDEX select ahead of the address
+// arithmetic, and the schedule is the early-release one (two B tiles in flight).
 //
-// bf16x3 implicit-GEMM convolution for STRIDE-1 "SAME" convolutions with kw >= 3 on pre-split (planes) operands: the im2col rows of a
+// bf16x3 implicit-GEMM convolution for STRIDE-1 "SAME" convolutions with kw in {3, 5, 7} on pre-split operands: the im2col rows of a
 // (ky, 32-channel chunk) stay in LDS for ALL kx taps (gfx950).
 //
-// conv_split.hip streams, per K-step, a 16 KB A (im2col) tile and a 16 KB B (weight) tile; its K loop runs at the rate the vector-memory
-// pipe delivers 1-KB LDS-DMA instructions to a CU (NOTEBOOK.md: the fp16 kernel — same instruction count per step, a third of the MFMAs —
-// takes the same time per step).  For a stride-1 convolution whose output map has the size of its input map, the A tile of tap (ky, kx) is
-// the A tile of tap (ky, 0) shifted by kx * dw PIXELS in the flattened (n, y, x) index: output pixel m reads input pixel
-// m + (ky*dh - ph) * W + (kx*dw - pw) whenever that pixel is in the same image row.  So this kernel walks K in the order
-// (ky, chunk, kx) and loads, per (ky, chunk), BM + 16 consecutive input rows ONCE (9 pieces per plane instead of 8 per tap): for a 3x3
-// layer 18 + 3 * 16 = 66 LDS-DMA instructions per (ky, chunk) instead of 96 (-31 %), for the 1x5 GRU convs of RAFT 18 + 80 instead of
-// 160 (-39 %).  Tap kx reads its MFMA fragments from LDS rows r + kx*dw; a pixel whose tap leaves the image row (x + kx*dw - pw outside
-// [0, W)) reads a zero row instead (per-lane address select); rows whose input row y + ky*dh - ph is outside the image were never
-// fetched (the DMA read the zero page).
+// For a stride-1 convolution whose output map has the size of its input map, the A tile of tap (ky, kx) is the A tile of tap (ky, 0)
+// shifted by kx * dw PIXELS in the flattened (n, y, x) index: output pixel m reads input pixel m + (ky*dh - ph) * W + (kx*dw - pw)
+// whenever that pixel is in the same image row.  So this kernel walks K in the order (ky, chunk, kx) and loads, per (ky, chunk), BM + 16
+// consecutive input rows ONCE (9 pieces per plane instead of 8 per tap): for a 3x3 layer 18 + 3 * 16 = 66 LDS-DMA instructions per
+// (ky, chunk) instead of 96 (-31 %), for the 1x5 GRU convs of RAFT 18 + 80 instead of 160 (-39 %) — and the pieces that remain are mostly
+// WEIGHT rows (L2 hits), the im2col stream from the Infinity Cache / HBM shrinks by kw.  Tap kx reads its MFMA fragments from LDS rows
+// r + kx*dw; a pixel whose tap leaves the image row (x + kx*dw - pw outside [0, W)) reads the plane's zero row instead; rows whose input
+// row y + ky*dh - ph is outside the image were never fetched (the DMA read the zero page).
 //
 // Numerics: the same products as conv_split.hip, accumulated in the order (ky, chunk, kx) instead of (ky, kx, chunk) — NOT bit-identical
 // to the other kernels (fp32 accumulation order), identical in error (tests/test_taps_gpu.py: both within 2e-5 of fp64 on the same split
-// operands).  Which kernel a layer runs on is therefore decided by its GEOMETRY alone (fgt_conv_taps_eligible), never by the autotuner:
-// an eligible split-input layer always runs here, so results do not depend on tuning.  Tiles of this kernel are bit-identical to each other.
+// operands).  Tiles of this kernel are bit-identical to each other.
 //
-// LDS: two A buffers [hi: BM+16 rows | lo: BM+16 rows] of 64-byte rows (the four 16-byte slots XOR-swizzled with (row >> 2) & 3 as in
-// conv_tile.h: any 16 consecutive rows are conflict free, so the shifted reads are too), two B stages [hi BN | lo BN], one zero row.
-// 128x128: 2 * 18 KB + 2 * 16 KB = 68 KB: two workgroups per CU.  Schedule: per step the B tile of the next step and a third of the
-// next (ky, chunk)'s A rows are requested at the top, fragments read, MFMAs, vmcnt(0), barrier.
+// LDS: two B stages [hi BN | lo BN] of 64-byte rows, two A buffers [hi: BM+16 rows + zero row | lo: BM+16 rows + zero row] (the four
+// 16-byte slots of a row XOR-swizzled with (row >> 2) & 3 as in conv_tile.h: any 16 consecutive rows are conflict free, so the shifted
+// reads are too).  128x128: 2 * 16 KB + 2 * 18.1 KB = 68.3 KB: two workgroups per CU.
+// Step (ss, kx): read fragments (A buffer ss & 1 shifted by kx*dw, B stage) | lgkmcnt(0) | barrier | request this step's share of
+// super-step ss+1's A rows, then the B tile of step + 2 into the stage just read | MFMAs | vmcnt(B pieces of this step) | barrier.
 #include "../conv_tile.h"
 
 namespace {
@@ -36,21 +38,27 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
 }
 
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 constexpr int HALO = 16;          // extra A rows per (ky, chunk): (kw - 1) * dw <= 16
 
-template <int BM, int BN, int WM, int WN, int MINW>
+template <int BM, int BN, int WM, int WN, int MINW, int KW>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const ConvP p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
-    constexpr int AR = BM + HALO;                        // A rows per plane
+    constexpr int AR = BM + HALO;                        // A rows per plane filled by DMA; row AR is the zero row
+    constexpr int APL = (AR + 1) * 64;                   // bytes per A plane
     constexpr int GA = AR / 16, GB = BN / 16;            // 16-row DMA groups per plane
     constexpr int NPA = 2 * GA;                          // A pieces per (ky, chunk): piece j -> plane j / GA, group j % GA
     constexpr int B_IT = 2 * GB / NW;                    // B pieces per wavefront and step
-    constexpr int A_BYTES = 2 * AR * 64, B_BYTES = 2 * BN * 64;
-    constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES + 64;
+    constexpr int A_BYTES = 2 * APL, B_BYTES = 2 * BN * 64;
+    constexpr int LDS_BYTES = 2 * B_BYTES + 2 * A_BYTES;
     constexpr int STAGE = LDS_BYTES / 8;                 // floats in half of the LDS (the epilogue's view of its scratch)
     constexpr int APW = (NPA + NW - 1) / NW;             // A pieces a wavefront owns per (ky, chunk)
-    static_assert(AR % 16 == 0 && (2 * GB) % NW == 0 && B_IT >= 1 && TM >= 1 && TN >= 1 && APW <= 5, "tile / wavefront geometry (APW < 2 kw for kw >= 3)");
+    constexpr int ASTEPS = KW - 1;                       // they go out in steps 0 .. KW-2 of the previous super-step (piece it in step it % ASTEPS)
+    static_assert(AR % 16 == 0 && (2 * GB) % NW == 0 && B_IT >= 1 && TM >= 1 && TN >= 1 && BN <= 128 && KW >= 3, "tile / wavefront geometry");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const fgt_conv_desc& d = p.d;
@@ -62,78 +70,91 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     const int bm0 = m_idx * BM, bn0 = n_idx * BN, g = blockIdx.y;
 
     char* const lds = reinterpret_cast<char*>(smem);
-    char* const Abuf = lds;                              // [2][hi AR rows | lo AR rows]
-    char* const Bbuf = lds + 2 * A_BYTES;                // [2][hi BN rows | lo BN rows]
-    char* const zrow = lds + 2 * A_BYTES + 2 * B_BYTES;  // 64 zero bytes
-    if (tid < 16) reinterpret_cast<float*>(zrow)[tid] = 0.f;
+    char* const Bst = lds;                               // [2][hi BN rows | lo BN rows]
+    char* const Abuf = lds + 2 * B_BYTES;                // [2][hi AR rows, zero row | lo AR rows, zero row]
+    if (tid < 64) reinterpret_cast<float*>(Abuf + (tid >> 5) * A_BYTES + ((tid >> 4) & 1) * APL + AR * 64)[tid & 15] = 0.f;
 
-    const __bf16* const x0 = reinterpret_cast<const __bf16*>(p.x0);
-    const __bf16* const x1 = reinterpret_cast<const __bf16*>(p.x1);
-    const int ld0 = d.ld0, ld1 = d.ld1;
-    const int chb0 = d.off0 + g * p.Cg0, chb1 = d.off1 + g * p.Cg1 - p.Cg0;     // (interleaved: off* are logical channels, multiples of 32)
-    const long ps0 = p.ps0, ps1 = p.ps1;
+    const int W = d.W, H = d.H, dwx = d.dw;
+    const int HW = H * W;
     const bool il = d.in_split == 2;
-    const int Cg0 = p.Cg0, nchunk = p.Cg / 32;
-    const int W = d.W, H = d.H, kw = d.kw, kh = d.kh, dwx = d.dw;
-    const long HW = (long)H * W, NHW = (long)d.N * HW;
+    const int nch0 = p.Cg0 / 32, nch1 = p.Cg1 / 32, nchunk = nch0 + nch1;
+    const int nss = d.kh * nchunk;
+    const long cstride = il ? 128 : 64;                  // bytes from one 32-channel chunk of a pixel to the next
 
-    // ---- this lane's A rows: row (lane >> 2) of each of its pieces j = wave + it * NW (plane j / GA, group j % GA), chunk column kc
+    // ---- im2col source iterator (wave-uniform): the super-step whose A rows are requested next.  Byte pointers to chunk (ky, c) of pixel 0:
+    // planes: channel c at element c, lo plane ps further; interleaved: element (c / 32) * 64 + c % 32, lo 32 elements further.
+    auto src_hi = [&](int s) {
+        const __bf16* x = reinterpret_cast<const __bf16*>(s ? p.x1 : p.x0);
+        const long c0 = s ? (long)d.off1 + (long)g * p.Cg1 : (long)d.off0 + (long)g * p.Cg0;
+        return reinterpret_cast<const char*>(x + (il ? 2 * c0 : c0));
+    };
+    auto src_lo_off = [&](int s) { return il ? 64l : 2 * (s ? p.ps1 : p.ps0); };
+    const char* a_hi = src_hi(0);
+    const char* a_lo = a_hi + src_lo_off(0);
+    int a_ld = d.ld0, a_left = nch0, a_src = 0;
+    int a_dy = -d.ph, a_dyW = -d.ph * W;
+    auto a_advance = [&]() {
+        a_hi += cstride; a_lo += cstride;
+        if (--a_left == 0) {
+            if (a_src == 0 && nch1 > 0) {
+                a_src = 1; a_left = nch1; a_ld = d.ld1;
+            } else {
+                a_src = 0; a_left = nch0; a_ld = d.ld0;
+                a_dy += d.dh; a_dyW += d.dh * W;
+            }
+            a_hi = src_hi(a_src);
+            a_lo = a_hi + src_lo_off(a_src);
+        }
+    };
+
+    // ---- this lane's A rows: row (lane >> 2) of each of its pieces j = wave + it * NW (plane j / GA, group j % GA), 16-byte column kc
     const int lrow = lane >> 2;
     const int kc = (lane & 3) ^ ((lane >> 4) & 3);       // swizzle on the source side
-    long a_off[APW];                                     // element offset of the row's pixel for ky*dh - ph = 0 (center row), or -1
-    int a_y[APW];                                        // its y coordinate
+    int a_q[APW], a_y[APW];                              // flattened input pixel of the row for ky*dh - ph = 0, and its y (far negative: never fetched)
 #pragma unroll
     for (int it = 0; it < APW; ++it) {
         const int j = wave + it * NW;
-        const int grp = j % GA;
-        const long q = (long)bm0 - d.pw + grp * 16 + lrow;     // flattened input pixel of LDS row grp*16 + lrow for the center row
-        if (j < NPA && q >= 0 && q < NHW) {
-            const long rem = q % HW;
-            a_y[it] = (int)(rem / W);
-            a_off[it] = q;
-        } else {
-            a_y[it] = 0; a_off[it] = -1;
-        }
+        const long q = (long)bm0 - d.pw + (j % GA) * 16 + lrow;
+        const bool valid = j < NPA && q >= 0 && q < (long)d.N * HW;
+        a_q[it] = valid ? (int)q : 0;
+        a_y[it] = valid ? (int)(q % HW) / W : -(1 << 30);
     }
-    // weights: interleaved rows [Kpad/32][hi 32 | lo 32]; piece (plane, group) of B: row bn0 + grp*16 + lrow
-    const __bf16* wbase[B_IT];
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-        const int piece = wave + it * NW, plane = piece / GB, grp = piece % GB;
-        const int brow = bn0 + grp * 16 + lrow;          // rows past Npad: zeros
-        wbase[it] = brow < d.Npad ? reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + brow) * (2 * d.Kpad) + plane * 32 + kc * 8 : nullptr;
-    }
-    const unsigned long zpi = reinterpret_cast<unsigned long>(p.zero_page);
-    auto sel = [&](const __bf16* ptr, bool ok) {
-        const unsigned long a = reinterpret_cast<unsigned long>(ptr);
-        return reinterpret_cast<const void*>(zpi + ((a - zpi) & (ok ? ~0ul : 0ul)));
-    };
-    // the A rows of super-step (ky, chunk) -> A buffer `ab`; `it`: which of this wavefront's pieces
-    auto issue_A = [&](int it, int ky, int chunk, int ab) {
+    const char* const zp = reinterpret_cast<const char*>(p.zero_page);
+    auto issue_A = [&](int it, int ab) {
         const int j = wave + it * NW;
         if (j >= NPA) return;                             // (wave-uniform)
         const int plane = j / GA, grp = j % GA;
-        const int ci = chunk * 32;
-        const bool in0 = ci < Cg0;
-        const __bf16* src = in0 ? x0 : x1;
-        const int ld = in0 ? ld0 : ld1;
-        // planes: channel c of a pixel at element c, the lo plane ps further; interleaved (in_split = 2): (c / 32) * 64 + c % 32, lo 32 further
-        const int cch = (in0 ? chb0 : chb1) + ci;                   // first channel of the chunk (a multiple of 32 when interleaved)
-        const long eo = il ? 2 * (long)cch + kc * 8 + plane * 32 : (long)cch + kc * 8 + (plane ? (in0 ? ps0 : ps1) : 0);
-        const int dy = ky * d.dh - d.ph;
-        const bool ok = a_off[it] >= 0 && (unsigned)(a_y[it] + dy) < (unsigned)H;
-        const __bf16* ptr = src + (a_off[it] + (long)dy * W) * ld + eo;
-        glds16(sel(ptr, ok), Abuf + ab * A_BYTES + plane * AR * 64 + grp * 1024);
+        const char* ptr = (plane ? a_lo : a_hi) + 2 * ((long)(a_q[it] + a_dyW) * a_ld + kc * 8);
+        const bool ok = (unsigned)(a_y[it] + a_dy) < (unsigned)H;
+        glds16(ok ? ptr : zp, Abuf + ab * A_BYTES + plane * APL + grp * 1024);
     };
-    // the B tile of step (ky, chunk, kx) -> B stage `bs`
-    auto issue_B = [&](int ky, int chunk, int kx, int bs) {
-        const long kstep = ((long)(ky * kw + kx) * p.Cg + chunk * 32) / 32;
+
+    // ---- weights: interleaved rows [Kpad/32][hi 32 | lo 32] (128 bytes per K-step of 32 channels); running pointers, K-step order
+    // kstep(ky, c, kx) = (ky*KW + kx) * nchunk + c: + nchunk inside a super-step, 1 - (KW-1) * nchunk to the next chunk, + 1 to the next ky
+    const char* wp[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int piece = wave + it * NW, plane = piece / GB, grp = piece % GB;
+        const int brow = bn0 + grp * 16 + lrow;          // (< Npad: Npad is a multiple of 128 >= BN)
+        wp[it] = reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + brow) * (2 * d.Kpad) + plane * 32 + kc * 8);
+    }
+    const long dkx = (long)nchunk * 128, dss = (1 - (long)(KW - 1) * nchunk) * 128;
+    int b_c = 0;                                          // chunk (within its ky) of the super-step the B stream is in
+    auto issue_B = [&](int bs) {
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             const int piece = wave + it * NW, plane = piece / GB, grp = piece % GB;
-            const bool bok = BN <= 128 || wbase[it] != nullptr;
-            glds16(sel(wbase[it] + kstep * 64, bok), Bbuf + bs * B_BYTES + plane * BN * 64 + grp * 1024);
+            glds16(wp[it], Bst + bs * B_BYTES + plane * BN * 64 + grp * 1024);
         }
+    };
+    auto advance_B = [&](bool last_kx) {                  // behind the B tile of a step with kx = KW-1 (last_kx) or kx < KW-1
+        long dlt = dkx;
+        if (last_kx) {
+            dlt = dss;
+            if (++b_c == nchunk) { b_c = 0; dlt = 128; }
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) wp[it] += dlt;
     };
 
     f32x16 acc[TM][TN];
@@ -145,123 +166,135 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
-    // x coordinate of this lane's output pixels (one per 32-row block): the taps that leave the image row read the zero row
-    int oxv[TM];
+    // LDS row of this lane's output pixels for kx = 0 (one per 32-row block), and x - pw of the pixel (the taps that leave the image row read the zero row)
+    int Rb[TM], oxp[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) oxv[i] = (bm0 + wm * WTM + i * 32 + l31) % W;
+    for (int i = 0; i < TM; ++i) {
+        Rb[i] = wm * WTM + i * 32 + l31;
+        oxp[i] = (bm0 + Rb[i]) % W - d.pw;
+    }
+    const unsigned b_lane = (unsigned)((wn * WTN + l31) * 64);     // B fragment rows: wave-tile base (multiple of 32) + l31
 
-    // ---- prologue: A rows of (0, 0) and the B tile of step 0
-    const int nss = kh * nchunk, nsteps = nss * kw;
+    // ---- prologue: A rows of super-step 0, the B tiles of steps 0 and 1 (KW >= 3: both in super-step 0)
 #pragma unroll
-    for (int it = 0; it < APW; ++it) issue_A(it, 0, 0, 0);
-    issue_B(0, 0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int it = 0; it < APW; ++it) issue_A(it, 0);
+    a_advance();
+    issue_B(0); advance_B(false);
+    issue_B(1); advance_B(KW == 2);
+    wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 
-    int ky = 0, chunk = 0, kx = 0, ss = 0;                // this step (wave-uniform scalar state)
-    int nky = 0, nchk = 0;                                // the next super-step
-    if (nss > 1) { nchk = 1; if (nchk == nchunk) { nchk = 0; nky = 1; } }
-    for (int step = 0; step < nsteps; ++step) {
-        // ---- requests at the top of the step: the next step's B tile, and this step's share of the next super-step's A rows
-        {
-            int bkx = kx + 1, bch = chunk, bky = ky;
-            if (bkx == kw) { bkx = 0; bch = nchk; bky = nky; }
-            if (step + 1 < nsteps) issue_B(bky, bch, bkx, (step + 1) & 1);
-            if (ss + 1 < nss) {
-                // this wavefront's APW pieces spread over the kw steps of the super-step: piece `it` goes out in step it mod kw (APW < 2 kw)
+    int bs = 0;                                           // B stage of this step
+    for (int ss = 0; ss < nss; ++ss) {
+        const bool last = ss + 1 == nss;
+        const unsigned Ab = (unsigned)(2 * B_BYTES + (ss & 1) * A_BYTES);          // byte offset of this super-step's A buffer in the LDS
+        static_for<KW>([&](auto KX) {
+            constexpr int kx = decltype(KX)::value;
+            bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+            {
+                int sh = kx * dwx;
+                // (kw = 3: hipcc hoists the fragment addresses of the three taps out of the loop, 128 registers hold them; for kw = 5, 7 they
+                //  would spill: keep the shift opaque so that they are recomputed per step, 9 VALU instructions per 32-row block)
+                if constexpr (KW > 3) asm volatile("" : "+s"(sh));
 #pragma unroll
-                for (int it = 0; it < APW; ++it) {
-                    const int b = it >= kw ? it - kw : it;
-                    if (b == kx) issue_A(it, nky, nchk, (ss + 1) & 1);
+                for (int i = 0; i < TM; ++i) {
+                    const bool xin = (unsigned)(oxp[i] + sh) < (unsigned)W;
+                    const int R = xin ? Rb[i] + sh : AR;
+                    const unsigned a0 = Ab + (unsigned)R * 64u + (unsigned)(((R >> 2) & 3) ^ lh) * 16u;     // k-half 0: slot lh; k-half 1: slot 2 + lh
+                    const unsigned a1 = a0 ^ 32u;
+                    ah[0][i] = *reinterpret_cast<const bf16x8*>(lds + a0);
+                    al[0][i] = *reinterpret_cast<const bf16x8*>(lds + a0 + APL);
+                    ah[1][i] = *reinterpret_cast<const bf16x8*>(lds + a1);
+                    al[1][i] = *reinterpret_cast<const bf16x8*>(lds + a1 + APL);
                 }
-            }
-        }
-        // ---- fragments of this step: A rows shifted by kx*dw (zero row where the tap leaves the image row), B stage step & 1
-        bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
-        {
-            const char* Ab = Abuf + (ss & 1) * A_BYTES;
-            const char* Bb = Bbuf + (step & 1) * B_BYTES;
-            const int sh = kx * dwx;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int R = wm * WTM + i * 32 + l31 + sh;
-                const bool xin = (unsigned)(oxv[i] + sh - d.pw) < (unsigned)W;
-                const int rs = (R >> 2) & 3;
+                const unsigned bb = (unsigned)(bs * B_BYTES) + b_lane;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    const int so = ((ks * 2 + lh) ^ rs) * 16;
-                    const char* a_hi = xin ? Ab + R * 64 + so : zrow;
-                    const char* a_lo = xin ? Ab + AR * 64 + R * 64 + so : zrow;
-                    ah[ks][i] = *reinterpret_cast<const bf16x8*>(a_hi);
-                    al[ks][i] = *reinterpret_cast<const bf16x8*>(a_lo);
+                    const unsigned so = (unsigned)swz(l31, ks * 2 + lh) * 2u;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        bh[ks][j] = *reinterpret_cast<const bf16x8*>(lds + bb + so + j * 32 * 64);
+                        bl[ks][j] = *reinterpret_cast<const bf16x8*>(lds + bb + so + BN * 64 + j * 32 * 64);
+                    }
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();                 // every wavefront holds its fragments: the B stage can be refilled
+            if constexpr (kx < ASTEPS) {
+                if (!last) {
+#pragma unroll
+                    for (int it = 0; it < APW; ++it)
+                        if (it % ASTEPS == kx) issue_A(it, (ss + 1) & 1);
+                }
+            }
+            constexpr bool crosses = kx + 2 >= KW;        // the step two ahead belongs to the next super-step
+            const bool more = !crosses || !last;
+            if (more) { issue_B(bs); advance_B((kx + 2) % KW == KW - 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            // same products as conv_split.hip (lo*hi, hi*lo, hi*hi per k-half)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const int so = swz(l31, ks * 2 + lh);    // B rows: wave-tile base (multiple of 32) + l31
-                const __bf16* Bhi = reinterpret_cast<const __bf16*>(Bb) + (wn * WTN + l31) * LDB + so;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    bh[ks][j] = *reinterpret_cast<const bf16x8*>(Bhi + j * 32 * LDB);
-                    bl[ks][j] = *reinterpret_cast<const bf16x8*>(Bhi + BN * LDB + j * 32 * LDB);
-                }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);               // keep the fragment reads ahead of the MFMAs
-        // same products as conv_split.hip (lo*hi, hi*lo, hi*hi per k-half)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // ---- advance (ky, chunk, kx)
-        if (++kx == kw) {
-            kx = 0; chunk = nchk; ky = nky; ++ss;
-            if (++nchk == nchunk) { nchk = 0; ++nky; }
-        }
+            __builtin_amdgcn_sched_barrier(0);
+            // everything older than this step's B pieces has landed: the B tile of the next step and (requested ahead of them) this step's A rows
+            if (more) wait_vmcnt<B_IT>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            bs ^= 1;
+        });
+        a_advance();
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
 }
 
-template <int BM, int BN, int WM, int WN, int MINW>
-int launch(const ConvP& p, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int MINW, int KW>
+int launch_kw(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
-    constexpr size_t smem = (size_t)2 * (2 * (BM + HALO) * 64) + (size_t)2 * (2 * BN * 64) + 64;
+    constexpr size_t smem = (size_t)2 * (2 * BN * 64) + (size_t)2 * (2 * (BM + HALO + 1) * 64);
     static_assert(smem <= 160 * 1024, "LDS buffers do not fit");
     static std::atomic<unsigned long long> lds_set{0};
-    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_taps_kernel<BM, BN, WM, WN, MINW>), (int)smem, lds_set, "conv_taps")) return rc;
+    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_taps_kernel<BM, BN, WM, WN, MINW, KW>), (int)smem, lds_set, "conv_taps")) return rc;
     ConvP q = p;
     q.mtiles = cdiv(p.M, BM);
     q.ntiles = cdiv(p.Cout_g, BN);
     q.mchunk = cdiv(q.mtiles, 8);
     dim3 grid(q.xcd_swizzle ? 8 * q.mchunk * q.ntiles : q.mtiles * q.ntiles, p.d.groups);
-    hipLaunchKernelGGL((conv_taps_kernel<BM, BN, WM, WN, MINW>), grid, dim3(NT), smem, s, q);
+    hipLaunchKernelGGL((conv_taps_kernel<BM, BN, WM, WN, MINW, KW>), grid, dim3(NT), smem, s, q);
     return fgt_check_launch("conv_taps");
+}
+
+template <int BM, int BN, int WM, int WN, int MINW>
+int launch(const ConvP& p, hipStream_t s) {
+    switch (p.d.kw) {
+        case 3: return launch_kw<BM, BN, WM, WN, MINW, 3>(p, s);
+        case 5: return launch_kw<BM, BN, WM, WN, MINW, 5>(p, s);
+        case 7: return launch_kw<BM, BN, WM, WN, MINW, 7>(p, s);
+        default: fgt_set_error("fgt_conv2d: the tap-reusing kernel is built for kw = 3, 5, 7 (got %d)", p.d.kw); return FGT_EINVAL;
+    }
 }
 
 }  // namespace
 
 // Geometry this kernel serves (decided by the layer alone, never by tuning): bf16x3 on split inputs (planes or interleaved) with interleaved weights,
-// stride 1, no upsample, zero padding, output map = input map ("same"), 3 <= kw, (kw - 1) * dw <= 16, Cin/groups a multiple of 32 per source.
+// stride 1, no upsample, zero padding, output map = input map ("same"), kw in {3, 5, 7}, (kw - 1) * dw <= 16, Cin/groups a multiple of 32 per source.
 bool fgt_conv_taps_eligible(const ConvP& p) {
     const fgt_conv_desc& d = p.d;
     return d.precision == FGT_PREC_BF16X3 && (d.in_split == 1 || d.in_split == 2) && d.w_il == 1 && d.sh == 1 && d.sw == 1 && !d.upsample && d.pad_mode == 0 &&
-           d.in_relu == 0 && d.Ho == d.H && d.Wo == d.W && d.kw >= 3 && (d.kw - 1) * d.dw <= HALO && p.Cg0 % 32 == 0 && p.Cg1 % 32 == 0 &&
+           d.in_relu == 0 && d.Ho == d.H && d.Wo == d.W && (d.kw == 3 || d.kw == 5 || d.kw == 7) && (d.kw - 1) * d.dw <= HALO && p.Cg0 % 32 == 0 && p.Cg1 % 32 == 0 &&
            d.Kpad == p.K && p.Cout_g > 4;
 }
 
