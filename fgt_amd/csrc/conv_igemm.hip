@@ -400,6 +400,7 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     const bool taps = (taps_routing() || d.tile >= FGT_TILE_TAPS) && fgt_conv_taps_eligible(p);
     FGT_REQUIRE(d.tile < FGT_TILE_TAPS || taps, "fgt_conv2d: tile %d (tap-reusing kernel) on a layer it does not serve", d.tile);
     if (taps && tile < FGT_TILE_TAPS) tile = FGT_TILE_TAPS + (p.Cout_g <= 64 ? FGT_TILE_128x64 : FGT_TILE_128x128x8);   // (FGT_CONV_TAPS=1 overrides tuned tiles too)
+    FGT_REQUIRE(!taps || d.w_il == (tile >= 300 ? 2 : 1), "fgt_conv2d: tile %d takes weights with w_il = %d", tile, tile >= 300 ? 2 : 1);
 #else
     constexpr bool taps = false;
     FGT_REQUIRE(d.tile < FGT_TILE_TAPS, "fgt_conv2d: tile %d (tap-reusing kernel) exists in diagnostic builds only", d.tile);
@@ -432,7 +433,7 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     if (direct) rc = fgt_conv_direct(p, s);   // Cout <= 4: VALU direct conv (fp32)
     else if (d.in_split == 3) rc = fgt_conv_f16_launch(tile, p, s);
 #ifdef FGT_DIAG
-    else if (taps) rc = fgt_conv_taps_launch(tile - FGT_TILE_TAPS, p, s);
+    else if (taps) rc = tile >= 300 ? fgt_conv_taps_breg_launch(tile - 300, p, s) : fgt_conv_taps_launch(tile - FGT_TILE_TAPS, p, s);
 #endif
     else if (d.in_split == 2 && tile >= FGT_TILE_WIDE) {
         if (d.w_il != 1 || d.Kpad != p.K) { fgt_set_error("fgt_conv2d: the wide bf16x3 tiles need interleaved weights (w_il = 1) and K %% 32 == 0"); rc = FGT_EINVAL; }

@@ -30,6 +30,8 @@ int fgt_conv_wide_launch(int tile, const ConvP& p, hipStream_t s);
 // in LDS for all kx taps; accumulation order (ky, chunk, kx).  Measured slower than the early-release tiles: not in the product library.
 bool fgt_conv_taps_eligible(const ConvP& p);
 int fgt_conv_taps_launch(int tile, const ConvP& p, hipStream_t s);
+// diag/conv_taps_breg.hip (diagnostic builds only): the same with the weight fragments loaded straight into registers (w_il = 2, tile code - 300)
+int fgt_conv_taps_breg_launch(int tile, const ConvP& p, hipStream_t s);
 
 // conv_f16.hip: FGT_PREC_F16 — fp16 inputs (one plane) through LDS-DMA, one MFMA per product
 int fgt_conv_f16_launch(int tile, const ConvP& p, hipStream_t s);

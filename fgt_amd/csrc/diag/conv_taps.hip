@@ -293,7 +293,7 @@ int launch(const ConvP& p, hipStream_t s) {
 // stride 1, no upsample, zero padding, output map = input map ("same"), kw in {3, 5, 7}, (kw - 1) * dw <= 16, Cin/groups a multiple of 32 per source.
 bool fgt_conv_taps_eligible(const ConvP& p) {
     const fgt_conv_desc& d = p.d;
-    return d.precision == FGT_PREC_BF16X3 && (d.in_split == 1 || d.in_split == 2) && d.w_il == 1 && d.sh == 1 && d.sw == 1 && !d.upsample && d.pad_mode == 0 &&
+    return d.precision == FGT_PREC_BF16X3 && (d.in_split == 1 || d.in_split == 2) && (d.w_il == 1 || d.w_il == 2) && d.sh == 1 && d.sw == 1 && !d.upsample && d.pad_mode == 0 &&
            d.in_relu == 0 && d.Ho == d.H && d.Wo == d.W && (d.kw == 3 || d.kw == 5 || d.kw == 7) && (d.kw - 1) * d.dw <= HALO && p.Cg0 % 32 == 0 && p.Cg1 % 32 == 0 &&
            d.Kpad == p.K && p.Cout_g > 4;
 }

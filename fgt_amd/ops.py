@@ -273,6 +273,17 @@ def _split_weights(pc, interleaved=None):
     return cache[il], il
 
 
+def _frag_weights(pc):
+    """The bf16 hi/lo weight image in MFMA fragment order (fgt_conv_desc.w_il = 2, diagnostic builds): [groups, Kpad/32, Npad/32, hi | lo,
+    k-half, 64 lanes] 16 bytes, lane = (k / 8 % 2) * 32 + channel-out % 32 — a wave-wide 16-byte load is 1 KB of consecutive memory."""
+    cache = pc.__dict__.setdefault("_w_split_cache", {})
+    if "frag" not in cache:
+        il, _ = _split_weights(pc, interleaved=True)                       # [G, Npad, Kpad/32, 2, 32]
+        G, Np, KS = il.shape[:3]
+        cache["frag"] = il.view(G, Np // 32, 32, KS, 2, 2, 2, 8).permute(0, 3, 1, 4, 5, 6, 2, 7).contiguous()
+    return cache["frag"]
+
+
 def prepack_weights(pc, mode=None):
     """Build the weight images fgt_conv2d would otherwise create lazily on its first launch in arithmetic `mode` (default: the
     current one): the bf16 hi/lo image for 'bf16x3' (and for the GEMMs that still take fp32 inputs in the 'f16' mode) and the fp16
@@ -366,6 +377,8 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     else:
         wbuf, wil = _split_weights(pc)
         d.w_il = int(wil)
+        if d.tile >= 300:                    # diagnostic builds: weights in MFMA fragment order (csrc/diag/conv_taps_breg.hip)
+            wbuf, d.w_il = _frag_weights(pc), 2
     args = (C.byref(d), _ptr(x), _ptr(x1), _ptr(wbuf), _ptr(pc.scale), _ptr(pc.bias), _ptr(aux1), _ptr(aux2), _ptr(out),
             _ptr(None if out_s is None else out_s.data))
     if d.tile == 0 and AUTOTUNE and pc.Cout // pc.groups > 4:

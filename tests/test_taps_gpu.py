@@ -16,7 +16,7 @@ from fgt_amd import _lib
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif("diag" not in _lib.LIB_PATH, reason="the tap-reusing kernel exists in diagnostic builds only (FGT_HIP_LIB)")]
 torch.set_grad_enabled(False)
-TAPS = ["128x128x8t", "128x128t", "128x64t", "64x64t"]
+TAPS = ["128x128x8t", "128x128t", "128x64t", "64x64t", "128x128x8r", "128x128r", "128x64r", "64x64r"]     # ...r: weights fed through registers (same order)
 
 
 def _rand(*shape, seed=0, scale=1.0):
