@@ -318,14 +318,25 @@ int launch_tile(int tile, const ConvP& p, hipStream_t s) {
 
 }  // namespace
 
-#ifdef FGT_DIAG
-// diagnostic builds: the tap-reusing kernel (csrc/diag/conv_taps.hip) is reachable through its explicit tile codes (+ 200), and with
-// FGT_CONV_TAPS=1 every layer it serves is routed to it whatever tile the descriptor names (so that whole-model measurements are possible)
-static bool taps_routing() {
-    static const int taps_env = [] { const char* e = getenv("FGT_CONV_TAPS"); return e ? atoi(e) : 0; }();
+// The tap-reusing kernel (conv_taps.hip) serves every layer fgt_conv_taps_eligible accepts: decided by the layer's geometry, never by tuning
+// (its accumulation order differs from the other kernels').  FGT_CONV_TAPS=0 turns the routing off (A/B measurements).
+static bool taps_enabled() {
+    static const int taps_env = [] { const char* e = getenv("FGT_CONV_TAPS"); return e ? atoi(e) : 1; }();
     return taps_env != 0;
 }
-#endif
+
+static void conv_params(const fgt_conv_desc& d, ConvP& p) {
+    p.d = d;
+    p.Cg0 = d.C0 / d.groups; p.Cg1 = d.C1 / d.groups; p.Cg = p.Cg0 + p.Cg1;
+    p.K = d.kh * d.kw * p.Cg; p.Cout_g = d.Cout / d.groups;
+}
+
+extern "C" int fgt_conv_taps_route(const fgt_conv_desc* dd) {
+    if (!dd || !taps_enabled() || dd->groups <= 0 || dd->tile != 0) return 0;
+    ConvP p{};
+    conv_params(*dd, p);
+    return fgt_conv_taps_eligible(p) ? 1 : 0;
+}
 
 extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* x1v, const float* w_packed,
                           const float* cscale, const float* cbias, const float* aux1, const float* aux2,
@@ -396,14 +407,14 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     p.out_s = static_cast<__bf16*>(out_s); p.pso = d.pso; p.ps0 = d.ps0; p.ps1 = d.C1 ? d.ps1 : d.ps0;
 
     int tile = d.tile;
-#ifdef FGT_DIAG
-    const bool taps = (taps_routing() || d.tile >= FGT_TILE_TAPS) && fgt_conv_taps_eligible(p);
+    // tile = 0 or a +200 code on a layer conv_taps.hip serves: that kernel (geometry decides, see taps_enabled); an explicit tile of another
+    // family on such a layer selects that family (A/B measurements, tests)
+    const bool taps = (taps_enabled() || d.tile >= FGT_TILE_TAPS) && (d.tile == 0 || d.tile >= FGT_TILE_TAPS) && fgt_conv_taps_eligible(p);
     FGT_REQUIRE(d.tile < FGT_TILE_TAPS || taps, "fgt_conv2d: tile %d (tap-reusing kernel) on a layer it does not serve", d.tile);
-    if (taps && tile < FGT_TILE_TAPS) tile = FGT_TILE_TAPS + (p.Cout_g <= 64 ? FGT_TILE_128x64 : FGT_TILE_128x128x8);   // (FGT_CONV_TAPS=1 overrides tuned tiles too)
-    FGT_REQUIRE(!taps || d.w_il == (tile >= 300 ? 2 : 1), "fgt_conv2d: tile %d takes weights with w_il = %d", tile, tile >= 300 ? 2 : 1);
-#else
-    constexpr bool taps = false;
-    FGT_REQUIRE(d.tile < FGT_TILE_TAPS, "fgt_conv2d: tile %d (tap-reusing kernel) exists in diagnostic builds only", d.tile);
+    if (taps && tile == 0) tile = FGT_TILE_TAPS + (p.Cout_g <= 192 ? FGT_TILE_128x64 : FGT_TILE_128x128x8);
+    FGT_REQUIRE(!taps || d.w_il == (tile >= FGT_TILE_TAPS_BREG ? 2 : 1), "fgt_conv2d: tile %d takes weights with w_il = %d", tile, tile >= FGT_TILE_TAPS_BREG ? 2 : 1);
+#ifndef FGT_DIAG
+    FGT_REQUIRE(tile < FGT_TILE_TAPS_BREG, "fgt_conv2d: tile %d (register-fed weights) exists in diagnostic builds only", tile);
 #endif
     if (tile == 0) {
         // static fallback (profiles/r01_run2_tune_conv_*.txt); fgt_amd.ops autotunes per shape on first use
@@ -433,8 +444,9 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     if (direct) rc = fgt_conv_direct(p, s);   // Cout <= 4: VALU direct conv (fp32)
     else if (d.in_split == 3) rc = fgt_conv_f16_launch(tile, p, s);
 #ifdef FGT_DIAG
-    else if (taps) rc = tile >= 300 ? fgt_conv_taps_breg_launch(tile - 300, p, s) : fgt_conv_taps_launch(tile - FGT_TILE_TAPS, p, s);
+    else if (taps && tile >= FGT_TILE_TAPS_BREG) rc = fgt_conv_taps_breg_launch(tile - FGT_TILE_TAPS_BREG, p, s);
 #endif
+    else if (taps) rc = fgt_conv_taps_launch(tile - FGT_TILE_TAPS, p, s);
     else if (d.in_split == 2 && tile >= FGT_TILE_WIDE) {
         if (d.w_il != 1 || d.Kpad != p.K) { fgt_set_error("fgt_conv2d: the wide bf16x3 tiles need interleaved weights (w_il = 1) and K %% 32 == 0"); rc = FGT_EINVAL; }
         else rc = fgt_conv_wide_launch(tile - FGT_TILE_WIDE, p, s);

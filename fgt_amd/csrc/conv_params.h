@@ -26,8 +26,8 @@ int fgt_conv_split_launch(int tile, const ConvP& p, hipStream_t s);
 // conv_wide.hip: bf16x3 on interleaved pre-split inputs (in_split = 2, w_il = 1) with full-line LDS-DMA pieces; `tile` = tile code - 100
 int fgt_conv_wide_launch(int tile, const ConvP& p, hipStream_t s);
 
-// diag/conv_taps.hip (diagnostic builds only): bf16x3 for stride-1 "same" convs with kw >= 3 on split inputs, the A rows of a (ky, chunk) stay
-// in LDS for all kx taps; accumulation order (ky, chunk, kx).  Measured slower than the early-release tiles: not in the product library.
+// conv_taps.hip: bf16x3 for stride-1 "same" convs with kw in {3, 5, 7} on split inputs: the A rows of a (ky, chunk) stay in LDS for all kx taps.
+// Selected by GEOMETRY (fgt_conv_taps_eligible), never by tuning: its accumulation order (ky, chunk, kx) differs from the other kernels'.
 bool fgt_conv_taps_eligible(const ConvP& p);
 int fgt_conv_taps_launch(int tile, const ConvP& p, hipStream_t s);
 // diag/conv_taps_breg.hip (diagnostic builds only): the same with the weight fragments loaded straight into registers (w_il = 2, tile code - 300)

@@ -1,10 +1,11 @@
-// DIAGNOSTIC BUILDS ONLY (fgt_amd.build.build(variant="diag")) until it beats the early-release tiles of conv_split.hip / conv_wide.hip.
-// Version 1 of this kernel (round 3, git history) was correct and 4-12 % SLOWER than those tiles with 31 % fewer LDS-DMA instructions
-// (profiles/r03_run6_split_sweep_taps_vs_early_release.txt).  Its K loop carried 118 VALU + 131 SALU instructions per step next to 12 MFMAs
-// (the early-release kernel: 70 + 42), 40 of them v_readlane reloads of spilled scalars, and one B tile in flight instead of two.  This is
-// version 2: kw is a template parameter (the kx loop is unrolled: piece ownership, shifts and wait counts are compile-time), the weight
-// pointers and the im2col source are iterators (one add per piece and step), the zero row is a ROW INDEX select ahead of the address
-// arithmetic, and the schedule is the early-release one (two B tiles in flight).
+// Round 3.  Version 1 of this kernel (git history) was correct and 4-12 % SLOWER than the early-release tiles of conv_split.hip with 31 % fewer
+// LDS-DMA instructions (profiles/r03_run6_split_sweep_taps_vs_early_release.txt): its K loop carried 118 VALU + 131 SALU instructions per step
+// next to 12 MFMAs (the early-release kernel: 70 + 42), 40 of them v_readlane reloads of spilled scalars, and one B tile in flight instead of
+// two.  This version: kw is a template parameter (the kx loop is unrolled: piece ownership, shifts and wait counts are compile-time), the
+// weight pointers and the im2col source are iterators (one add per piece and step), the zero row is a ROW INDEX select ahead of the address
+// arithmetic (20-40 VALU + 22 SALU per step), and the schedule is the early-release one (two B tiles in flight).  Measured
+// (profiles/r03_run7_split_sweep_taps_v2.txt, r03_run9_*): +4...10 % over the early-release tiles on the Cout >= 256 layers, +15...27 % on the
+// Cout <= 192 layers of RAFT / LAFC / the decoder, where the 128x64 tile fits three workgroups per CU.
 //
 // bf16x3 implicit-GEMM convolution for STRIDE-1 "SAME" convolutions with kw in {3, 5, 7} on pre-split operands: the im2col rows of a
 // (ky, 32-channel chunk) stay in LDS for ALL kx taps (gfx950).
@@ -20,14 +21,16 @@
 //
 // Numerics: the same products as conv_split.hip, accumulated in the order (ky, chunk, kx) instead of (ky, kx, chunk) — NOT bit-identical
 // to the other kernels (fp32 accumulation order), identical in error (tests/test_taps_gpu.py: both within 2e-5 of fp64 on the same split
-// operands).  Tiles of this kernel are bit-identical to each other.
+// operands).  Which kernel a layer runs on is therefore decided by its GEOMETRY alone (fgt_conv_taps_eligible), never by the autotuner: an
+// eligible split-input layer always runs here (the autotuner picks among THIS kernel's tiles, which are bit-identical to each other), so
+// results do not depend on tuning.
 //
 // LDS: two B stages [hi BN | lo BN] of 64-byte rows, two A buffers [hi: BM+16 rows + zero row | lo: BM+16 rows + zero row] (the four
 // 16-byte slots of a row XOR-swizzled with (row >> 2) & 3 as in conv_tile.h: any 16 consecutive rows are conflict free, so the shifted
 // reads are too).  128x128: 2 * 16 KB + 2 * 18.1 KB = 68.3 KB: two workgroups per CU.
 // Step (ss, kx): read fragments (A buffer ss & 1 shifted by kx*dw, B stage) | lgkmcnt(0) | barrier | request this step's share of
 // super-step ss+1's A rows, then the B tile of step + 2 into the stage just read | MFMAs | vmcnt(B pieces of this step) | barrier.
-#include "../conv_tile.h"
+#include "conv_tile.h"
 
 namespace {
 
@@ -193,9 +196,9 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
             bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
             {
                 int sh = kx * dwx;
-                // (kw = 3: hipcc hoists the fragment addresses of the three taps out of the loop, 128 registers hold them; for kw = 5, 7 they
-                //  would spill: keep the shift opaque so that they are recomputed per step, 9 VALU instructions per 32-row block)
-                if constexpr (KW > 3) asm volatile("" : "+s"(sh));
+                // (kw = 3 on 4 wavefronts: hipcc hoists the fragment addresses of the three taps out of the loop; for kw = 5, 7 and in the
+                //  128-register tiles they would spill: the shift is opaque there, so they are recomputed per step, 9 VALU instructions per block)
+                if constexpr (KW > 3 || NW >= 8) asm volatile("" : "+s"(sh));
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const bool xin = (unsigned)(oxp[i] + sh) < (unsigned)W;
@@ -304,6 +307,7 @@ int fgt_conv_taps_launch(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_128x128: return launch<128, 128, 2, 2, 2>(p, s);
         case FGT_TILE_128x64: return launch<128, 64, 2, 2, 2>(p, s);
         case FGT_TILE_64x64: return launch<64, 64, 2, 2, 2>(p, s);
+        case FGT_TILE_128x32: return launch<128, 64, 4, 2, 6>(p, s);          // "128x64x8t": 128x64 on 8 wavefronts of 32x32, three workgroups per CU
         default: fgt_set_error("fgt_conv2d: tile %d is not built for the tap-reusing kernel", tile + FGT_TILE_TAPS); return FGT_EINVAL;
     }
 }

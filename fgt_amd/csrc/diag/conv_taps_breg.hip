@@ -1,5 +1,7 @@
-// DIAGNOSTIC BUILDS ONLY — experiment: the tap-reusing bf16x3 kernel of conv_taps.hip with the WEIGHT fragments loaded straight into
-// registers (tile codes + 300, weights in "fragment order": fgt_conv_desc.w_il = 2).
+// DIAGNOSTIC BUILDS ONLY — experiment, measured and NOT adopted (profiles/r03_run8_split_sweep_taps_breg.txt: bit-identical to conv_taps.hip,
+// 3-9 % slower on the Cout >= 256 layers, +2...10 % on two decoder layers only): the tap-reusing bf16x3 kernel of conv_taps.hip with the
+// WEIGHT fragments loaded straight into registers (tile codes + 300, weights in "fragment order": fgt_conv_desc.w_il = 2).  Neither the
+// barriers nor the LDS round trip of the B tile is what bounds conv_taps.hip: the same bytes through plain loads cost the same or more.
 //
 // conv_taps.hip still moves a 16 KB B (weight) tile through LDS per K-step: 16 of its 22 LDS-DMA instructions, a stage that must be
 // released by a barrier after the fragment reads and published by another one after the copy.  Here the weight image is stored the way

@@ -32,6 +32,9 @@ TILE_CANDIDATES = ("128x128", "64x64", "128x64", "256x128", "128x32", "128x128x8
                    "128x128eaw", "64x64eaw", "128x64eaw", "128x128x8eaw", "256x128x16eaw", "256x64x8eaw", "256x128eaw",
                    # bf16x3 on interleaved inputs only (csrc/conv_wide.hip): the 8-phase schedule on 256-row tiles
                    "256x256p8w", "256x128p8w")
+# Layers that fgt_conv2d routes to the tap-reusing kernel (csrc/conv_taps.hip; decided by geometry: fgt_conv_taps_route) are tuned among ITS
+# tiles only — they are bit-identical to each other, so results never depend on tuning.
+TAPS_CANDIDATES = ("128x128x8t", "128x128t", "128x64t", "128x64x8t", "64x64t")
 _tile_cache = {}
 
 
@@ -388,7 +391,8 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
         if best is None and not torch.cuda.is_current_stream_capturing() and not _aliases(out, out_s, x, x1, aux1, aux2):
             # (tuning re-launches the kernel into the caller's buffers and synchronises: illegal under stream capture, and it would
             #  corrupt an output that aliases an input / aux operand — such calls run on the static tile and are not cached)
-            best = _tile_cache[key] = _autotune(d, args)
+            taps = bool(_lib.lib().fgt_conv_taps_route(C.byref(d)))
+            best = _tile_cache[key] = _autotune(d, args, TAPS_CANDIDATES if taps else TILE_CANDIDATES)
         d.tile = best or 0
     check(_lib.lib().fgt_conv2d(*args, _stream()), "fgt_conv2d")
     return {0: out, 1: out_s, 2: (out, out_s)}[osp]

@@ -113,7 +113,7 @@ typedef struct fgt_conv_desc {
     int ldo_s, ooff_s;      /* row stride / first channel of out_s (bf16 elements; out_split with pso == 32 writes the
                              * interleaved layout of in_split = 2: ldo_s >= 2*Cout, needs Cout/groups % 32 == 0;
                              * pso == -1 writes the single fp16 plane of in_split = 3, whatever `precision` computed it)   */
-    int w_il;               /* 1: w_packed is [groups][Npad][Kpad/32][hi 32 | lo 32] (interleaved) instead of two planes   */
+    int w_il;               /* 1: w_packed is [groups][Npad][Kpad/32][hi 32 | lo 32] (interleaved) instead of two planes; 2 (diagnostic builds): MFMA fragment order */
     int k_alg;              /* profiling only: kh*kw*Cin/groups BEFORE zero-padding of the input channels (flow 2 -> 4, RGB 3 -> 4),
                              * the K that fgt_prof_* credits as algorithmic work; 0 = use the padded K                        */
     long long ps0, ps1, pso;/* plane strides (bf16 elements) of x0, x1, out_s                                            */
@@ -161,15 +161,22 @@ typedef struct fgt_conv_desc {
                                   * K-step, an LDS-DMA instruction copies 8 full cache lines instead of 16 half lines.  FGT_PREC_F16 (below) and, since
                                   * ABI 6, FGT_PREC_BF16X3 with INTERLEAVED inputs (in_split = 2, w_il = 1: csrc/conv_wide.hip; codes 1-8, 26-31, 38 and the
                                   * 8-phase tiles 17 / 18).  Bit-identical results. */
-#define FGT_TILE_TAPS 200        /* DIAGNOSTIC BUILDS ONLY: tile code + 200 (codes 1, 2, 3, 6) = the tap-reusing kernel (csrc/diag/conv_taps.hip) for stride-1
-                                  * "same" convolutions with kw >= 3 on split inputs: the im2col rows of a (ky, 32-channel chunk) are loaded once for all kx
-                                  * taps (3x3: -31 % LDS-DMA instructions).  Accumulates in the order (ky, chunk, kx): not bit-identical to the other
-                                  * kernels.  Measured 4-12 % slower than the early-release tiles (round 3): rejected by the product library. */
+#define FGT_TILE_TAPS 200        /* tile code + 200 (codes 1, 2, 3, 4 = 128x64 on 8 wavefronts, 6) = the tap-reusing kernel (csrc/conv_taps.hip) for stride-1 "same"
+                                  * convolutions with kw in {3, 5, 7} on split inputs: the im2col rows of a (ky, 32-channel chunk) are loaded once for all kx taps
+                                  * (3x3: -31 % LDS-DMA instructions, the im2col stream from memory shrinks by kw).  It accumulates in the order (ky, chunk, kx):
+                                  * NOT bit-identical to the other kernels, same error.  fgt_conv2d therefore routes by GEOMETRY: a layer this kernel serves runs
+                                  * on it whenever tile = 0 (or a +200 code); an explicit tile of another family selects that family.  Its tiles are bit-identical
+                                  * to each other.  FGT_CONV_TAPS=0 (environment) turns the routing off. */
+#define FGT_TILE_TAPS_BREG 300   /* DIAGNOSTIC BUILDS ONLY: the same kernel with weights in MFMA fragment order (w_il = 2) loaded straight into registers */
 #define FGT_TILE_F16_WIDE 100    /* FGT_PREC_F16 only: tile code + 100 = the same tile on the "wide" LDS image (a stage row is the pixel's whole
                                   * 128-byte line of the 64-channel K-step; an LDS-DMA instruction copies 8 full cache lines instead of 16 half
                                   * lines).  Codes 1-8, 26-31 and 38.  Bit-identical results. */
 #define FGT_TILE_256x256_P8N 19   /* 17 without s_setprio (A/B measurements) */
 #define FGT_TILE_256x256_P8L 20   /* 17 with both wavefront groups in lock step (A/B measurements) */
+
+/* 1 when fgt_conv2d would route this descriptor (with tile = 0) to the tap-reusing kernel: the autotuner of a caller then restricts its
+ * candidates to the +200 tile codes, so that tuning never changes which accumulation order a layer gets. */
+int fgt_conv_taps_route(const fgt_conv_desc* d);
 
 int fgt_conv2d(const fgt_conv_desc* d, const void* x0, const void* x1, const float* w_packed,
                const float* cscale /* [Cout] or NULL */, const float* cbias /* [Cout] or NULL */,

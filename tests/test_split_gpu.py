@@ -134,7 +134,8 @@ def test_conv_out_split_epilogue(mode, dev):
     w2, b2 = _rand(64, 128, 3, 3, seed=5, scale=0.05), _rand(64, seed=6)
     pc2 = ops.PackedConv(w2.to(dev), b2.to(dev))
     a = ops.conv2d(ops.conv2d(x, pc, pad=1, act="lrelu", precision="bf16x3"), pc2, pad=1, stride=2, precision="bf16x3")
-    s1 = ops.conv2d(ops.split(x), pc, pad=1, act="lrelu", precision="bf16x3", out_split="only")
+    # (explicit tile: a 3x3 / stride-1 layer on split inputs is otherwise routed to the tap-reusing kernel, whose accumulation order differs)
+    s1 = ops.conv2d(ops.split(x), pc, pad=1, act="lrelu", precision="bf16x3", out_split="only", tile="128x128")
     bsp = ops.conv2d(s1, pc2, pad=1, stride=2, precision="bf16x3")
     assert torch.equal(a, bsp)
 
@@ -194,7 +195,7 @@ def test_conv_interleaved_two_source_and_out_il(dev):
     w, b = _rand(512, 640 // g, 3, 3, seed=3, scale=0.05), _rand(512, seed=4)
     pc = ops.PackedConv(w.to(dev), b.to(dev), groups=g)
     ref = ops.conv2d(x0, pc, x1=o, stride=1, pad=1, act="lrelu", precision="bf16x3")
-    for tile in ("auto", "128x128x8", "64x64"):
+    for tile in ("128x128x8", "64x64"):            # (tile = auto would route this 3x3 / stride-1 layer to the tap-reusing kernel: tests/test_taps_gpu.py)
         r32, rs = ops.conv2d(ops.split(x0, interleave=True), pc, x1=ops.split(o, interleave=True), stride=1, pad=1, act="lrelu",
                              precision="bf16x3", tile=tile, out_split="both", out_il=True)
         assert torch.equal(r32, ref) and rs.il
@@ -370,7 +371,9 @@ def test_fgt_forward_bit_equal_with_interleaved_split_tensors(dev, monkeypatch):
     real = ops.conv2d
 
     def forced(x, pc, *a, **kw):
-        if isinstance(x, ops.Split) and x.il and kw.get("tile") is None and pc.Cout // pc.groups > 4:
+        # (3x3 / stride-1 layers are routed to the tap-reusing kernel by geometry in both layouts: not forced)
+        tap_routed = pc.kw >= 3 and kw.get("stride", 1) == 1 and not kw.get("upsample") and kw.get("pad_mode", "zeros") == "zeros"
+        if isinstance(x, ops.Split) and x.il and kw.get("tile") is None and pc.Cout // pc.groups > 4 and not tap_routed:
             kw["tile"] = "128x128x8eaw"
         return real(x, pc, *a, **kw)
     monkeypatch.setattr(ops, "SPLIT_INTERLEAVED", True)

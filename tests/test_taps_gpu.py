@@ -1,22 +1,21 @@
-"""The tap-reusing conv kernel (csrc/diag/conv_taps.hip, tile codes + 200) on a real MI355X — DIAGNOSTIC BUILDS ONLY: the kernel was measured
-4-12 % slower than the early-release tiles (profiles/r03_run6_*) and is not in the product library.  Run with
-    python -c "from fgt_amd import build; build.build(variant='diag')"; FGT_HIP_LIB=fgt_amd/lib/libfgt_hip_diag.so pytest tests/test_taps_gpu.py -m gpu
-(the recorded run: profiles/r03_run6_pytest_taps.log); skipped against the product library.
+"""The tap-reusing conv kernel (csrc/conv_taps.hip, tile codes + 200) on a real MI355X.
 
 It computes the same products as the other bf16x3 kernels but accumulates them in the order (ky, chunk, kx) instead of (ky, kx, chunk):
 NOT bit-identical to them, so its gate is (i) distance to fp64 on the same split operands no larger than the other kernels', (ii) bit
-equality among its own tiles, (iii) tile = auto never reaches it."""
+equality among its own tiles, (iii) the routing: a layer's kernel family is decided by geometry, never by tuning."""
 import math
 
 import pytest
 import torch
 import torch.nn.functional as F
 
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
 from fgt_amd import _lib
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif("diag" not in _lib.LIB_PATH, reason="the tap-reusing kernel exists in diagnostic builds only (FGT_HIP_LIB)")]
-torch.set_grad_enabled(False)
-TAPS = ["128x128x8t", "128x128t", "128x64t", "64x64t", "128x128x8r", "128x128r", "128x64r", "64x64r"]     # ...r: weights fed through registers (same order)
+TAPS = ["128x128x8t", "128x128t", "128x64t", "128x64x8t", "64x64t"]
+if "diag" in _lib.LIB_PATH:        # diagnostic builds: the same kernel with register-fed weights (csrc/diag/conv_taps_breg.hip), bit-identical
+    TAPS += ["128x128x8r", "128x128r", "128x64r", "64x64r"]
 
 
 def _rand(*shape, seed=0, scale=1.0):
@@ -70,9 +69,9 @@ def test_taps_kernel_vs_fp64_and_other_kernels(case, il, dev):
     assert torch.equal(other, ops.conv2d(x, pc, x1=x1, pad=pad, dil=dil, act="lrelu", tile="128x128", precision="bf16x3"))
     e_other = (other.double() - ref).abs().max().item()
     scale = ref.abs().max().item()
-    auto = ops.conv2d(xs, pc, x1=x1s, pad=pad, dil=dil, act="lrelu", precision="bf16x3")                           # autotuned: the other families only
-    assert torch.equal(auto, other)
+    auto = ops.conv2d(xs, pc, x1=x1s, pad=pad, dil=dil, act="lrelu", precision="bf16x3")                           # routed by geometry
     if kw == 1:
+        assert torch.equal(auto, other)
         with pytest.raises(RuntimeError, match="does not serve"):
             ops.conv2d(xs, pc, x1=x1s, pad=pad, dil=dil, act="lrelu", tile="128x128x8t", precision="bf16x3")
         return
@@ -84,6 +83,7 @@ def test_taps_kernel_vs_fp64_and_other_kernels(case, il, dev):
         assert e <= max(2.0 * e_other, 2e-6 * scale) and e <= 2e-5 * scale, f"{name} {t}: {e:.3e} vs other kernels {e_other:.3e} (scale {scale:.2e})"
         first = got if first is None else first
         assert torch.equal(got, first), f"{name}: tile {t} differs from {TAPS[0]}"
+    assert torch.equal(auto, first), "an eligible layer with tile = auto must run on the tap-reusing kernel"
     print(f"[parity] conv_taps {name} ({'interleaved' if il else 'planes'}): max |taps - fp64| {(first.double() - ref).abs().max().item():.2e}, "
           f"|conv_split - fp64| {e_other:.2e}, |taps - conv_split| {(first - other).abs().max().item():.2e} (outputs up to {scale:.2f})")
 
@@ -100,35 +100,34 @@ def test_taps_epilogues_and_split_outputs(dev):
     ns, xs = ops.split(net), ops.split(xb)
     for epi, kw in (("gru", dict(act="tanh", epi="gru", aux1=z, aux2=hprev)), ("mul", dict(act="sigmoid", epi="mul", aux1=hprev)), ("none", dict(act="sigmoid"))):
         ref = ops.conv2d(ns, pc, x1=xs, pad=(0, 2), tile="128x128", precision="bf16x3", **kw)
-        o32, osp = ops.conv2d(ns, pc, x1=xs, pad=(0, 2), tile="128x128x8t", precision="bf16x3", out_split="both", **kw)
+        o32, osp = ops.conv2d(ns, pc, x1=xs, pad=(0, 2), precision="bf16x3", out_split="both", **kw)
         assert (o32 - ref).abs().max().item() <= 3e-6 * max(1.0, ref.abs().max().item()), epi
         assert torch.equal(osp.data, ops.split(o32).data)
-        only = ops.conv2d(ns, pc, x1=xs, pad=(0, 2), tile="128x64t", precision="bf16x3", out_split="only", **kw)
+        only = ops.conv2d(ns, pc, x1=xs, pad=(0, 2), precision="bf16x3", out_split="only", **kw)
         assert torch.equal(only.data, osp.data)
     wide = ops.Split.empty((rows, 256), dev)
     wide.data.zero_()
     w2 = _rand(128, 256, 3, 3, seed=7, scale=0.02)
     pc2 = ops.PackedConv(w2.to(dev), None)
-    full = ops.conv2d(xs, pc2, pad=1, act="relu", tile="128x128t", precision="bf16x3", out_split="only")
-    ops.conv2d(xs, pc2, pad=1, act="relu", tile="128x128t", precision="bf16x3", out_split="only", out_s=wide.channels(128, 256))
+    full = ops.conv2d(xs, pc2, pad=1, act="relu", precision="bf16x3", out_split="only")
+    ops.conv2d(xs, pc2, pad=1, act="relu", precision="bf16x3", out_split="only", out_s=wide.channels(128, 256))
     assert torch.equal(wide.data[:, :, 128:], full.data.view(2, rows, 128)) and float(wide.data[:, :, :128].float().abs().max()) == 0.0
 
 
-def test_taps_tiles_are_rejected_on_layers_they_do_not_serve(dev):
+def test_taps_routing_is_geometry_only(dev):
     from fgt_amd import ops
     xf = _rand(1, 16, 20, 64, seed=1).to(dev)
     x = ops.split(xf)
     pc = ops.PackedConv(_rand(64, 64, 3, 3, seed=2, scale=0.05).to(dev), None)
-    ops.conv2d(x, pc, pad=1, precision="bf16x3", tile="128x128x8t")
-    # not served: stride 2, upsample, replicate padding, "valid" padding, Cin / groups not a multiple of 32, fp32 inputs
+    base = ops.conv2d(x, pc, pad=1, precision="bf16x3")                               # tile = auto on an eligible layer: the tap kernel
+    assert torch.equal(base, ops.conv2d(x, pc, pad=1, precision="bf16x3", tile="128x128x8t"))
+    # not served: stride 2, upsample, replicate padding, "valid" padding, Cin / groups not a multiple of 32, fp32 inputs — all run on the
+    # other kernels, bit-identical to the register-staged bf16x3 kernel on fp32 inputs
     for kw in (dict(stride=2, pad=1), dict(pad=1, upsample=True), dict(pad=1, pad_mode="replicate"), dict(pad=0)):
-        with pytest.raises(RuntimeError, match="does not serve"):
-            ops.conv2d(x, pc, precision="bf16x3", tile="128x128x8t", **kw)
-        a = ops.conv2d(x, pc, precision="bf16x3", **kw)                              # autotuned (one cache entry per padding mode)
+        a = ops.conv2d(x, pc, precision="bf16x3", **kw)
         assert torch.equal(a, ops.conv2d(xf, pc, precision="bf16x3", tile="128x128", **kw)), kw
     x40 = _rand(1, 16, 20, 40, seed=3).to(dev)
     pc40 = ops.PackedConv(_rand(64, 40, 3, 3, seed=4, scale=0.05).to(dev), None)
-    with pytest.raises(RuntimeError, match="does not serve"):
-        ops.conv2d(ops.split(x40), pc40, pad=1, precision="bf16x3", tile="128x128t")
-    with pytest.raises(RuntimeError, match="does not serve"):
-        ops.conv2d(xf, pc, pad=1, precision="bf16x3", tile="128x128t")
+    assert torch.equal(ops.conv2d(ops.split(x40), pc40, pad=1, precision="bf16x3"), ops.conv2d(x40, pc40, pad=1, precision="bf16x3", tile="128x128"))
+    # an explicit tile of another family on an eligible layer selects that family (A/B measurements): equal to the fp32-input kernel
+    assert torch.equal(ops.conv2d(x, pc, pad=1, precision="bf16x3", tile="128x128x8ea"), ops.conv2d(xf, pc, pad=1, precision="bf16x3", tile="128x128"))

@@ -19,7 +19,7 @@ from collections import defaultdict
 
 
 def kind_of(name):
-    if "conv_split_kernel" in name or "conv_igemm_kernel" in name or "conv_f16" in name or "conv_wide" in name:
+    if "conv_split_kernel" in name or "conv_igemm_kernel" in name or "conv_f16" in name or "conv_wide" in name or "conv_taps" in name:
         return "conv"
     if "attn_" in name:
         # spatial windows run the 2-wavefront instances (64 queries), temporal zones the 4- / 8-wavefront ones
