@@ -680,13 +680,21 @@ def avgpool2(src, rows, H, W):
     return out
 
 
-def corr_lookup(pyr, B, H1, W1, radius, coords, out):
-    """pyr: list of level volumes; coords [B,H1,W1,2]; out channels-last [B,H1,W1,levels*(2r+1)^2] (may be a slice)."""
+def corr_lookup(pyr, B, H1, W1, radius, coords, out=None, out_s=None):
+    """pyr: list of level volumes; coords [B,H1,W1,2]; out channels-last [B,H1,W1,levels*(2r+1)^2] (may be a slice) and / or out_s, a planes
+    `Split` of >= that many channels (a multiple of 32 for the LDS-DMA conv kernels: the extra channels are written as zeros)."""
     _require_dev(coords, out, *pyr)
     arr = (C.c_void_p * len(pyr))(*[p.data_ptr() for p in pyr])
-    check(_lib.lib().fgt_corr_lookup(arr, len(pyr), B, H1, W1, radius, _ptr(coords.contiguous()), _ptr(out), _as_map(out)[5],
-                                     _stream()), "fgt_corr_lookup")
-    return out
+    ldo = 0 if out is None else _as_map(out)[5]
+    ld_s = ps = nch_pad = 0
+    if out_s is not None:
+        assert not out_s.il and not out_s.h, "corr_lookup writes the planes layout"
+        _, sN, sH, sW, nch_pad, ld_s = _as_map(out_s.hi)
+        assert sN * sH * sW == B * H1 * W1
+        ps = out_s.ps
+    check(_lib.lib().fgt_corr_lookup_split(arr, len(pyr), B, H1, W1, radius, _ptr(coords.contiguous()), _ptr(out), ldo,
+                                           _ptr(None if out_s is None else out_s.data), ld_s, ps, nch_pad, _stream()), "fgt_corr_lookup")
+    return out if out_s is None else (out_s if out is None else (out, out_s))
 
 
 def convex_upsample(flow, mask):

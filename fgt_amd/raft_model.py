@@ -151,6 +151,11 @@ class RAFT(nn.Module):
             cw, cb = u.encoder.conv.weight.detach(), u.encoder.conv.bias.detach()
             P["enc"]["conv128"] = PackedConv(torch.cat([cw, torch.zeros(2, *cw.shape[1:], device=cw.device, dtype=cw.dtype)], 0),
                                              torch.cat([cb, torch.zeros(2, device=cb.device, dtype=cb.dtype)], 0))
+            # convc1 with its input channels zero-padded 324 -> 352 (a multiple of 32): in the split chain the correlation lookup writes its
+            # taps as a split tensor (zeros in the padding) and this 1x1 conv runs on the LDS-DMA kernel instead of the register-staged one
+            c1w, c1b = u.encoder.convc1.weight.detach(), u.encoder.convc1.bias.detach()
+            cpad = (-c1w.shape[1]) % 32
+            P["enc"]["convc1p"] = PackedConv(torch.cat([c1w, torch.zeros(c1w.shape[0], cpad, 1, 1, device=c1w.device, dtype=c1w.dtype)], 1), c1b)
             P["gru"] = {n: self._pk(getattr(u.gru, n)) for n in ("convz1", "convr1", "convq1", "convz2", "convr2", "convq2")}
             P["fh"] = (self._pk(u.flow_head.conv1), self._pk(u.flow_head.conv2))
             P["mask"] = (self._pk(u.mask[0]), self._pk(u.mask[2]))
@@ -252,16 +257,20 @@ class RAFT(nn.Module):
         s4 = lambda sp: sp.view(B, h8, w8, sp.shape[-1])
         if sc:
             cor1_s, cor2_s, flo1_s, flo2_s, rh_s, net_s, xbuf_s = S(256), S(192), S(128), S(64), S(128), S(128), S(256)
+            corr_s = S(E["convc1p"].Cin)                                            # 324 taps + 28 zero channels
             ops.split(cmap.view(rows, 256)[:, 128:], relu=True, out=xbuf_s.channels(0, 128))       # inp = relu(cnet[:, 128:])
             ops.split(net, out=net_s)
             motion_s, flow_s = xbuf_s.channels(128, 256), xbuf_s.channels(254, 256)
         ups = []
         for it in range(iters):
-            ops.corr_lookup(pyr, B, h8, w8, self.corr_radius, coords1, m4(corr))
+            if sc:
+                ops.corr_lookup(pyr, B, h8, w8, self.corr_radius, coords1, out_s=s4(corr_s))
+            else:
+                ops.corr_lookup(pyr, B, h8, w8, self.corr_radius, coords1, m4(corr))
             ops.axpby(coords1, 1.0, coords0, -1.0, out=flow4[:, :2])               # flow = coords1 - coords0
             if sc:
                 # BasicMotionEncoder (update.py:62-76)
-                ops.conv2d(m4(corr), E["convc1"], act="relu", out_split="only", out_s=cor1_s)
+                ops.conv2d(s4(corr_s), E["convc1p"], act="relu", out_split="only", out_s=cor1_s)
                 ops.conv2d(s4(cor1_s), E["convc2"], pad=1, act="relu", out_split="only", out_s=cor2_s)
                 ops.conv2d(m4(flow4), E["convf1"], pad=3, act="relu", out_split="only", out_s=flo1_s)
                 ops.conv2d(s4(flo1_s), E["convf2"], pad=1, act="relu", out_split="only", out_s=flo2_s)

@@ -299,6 +299,11 @@ int fgt_avgpool2(const float* src, long rows, int H, int W, float* dst, void* st
  * out [B,H1,W1, 4*(2r+1)^2] channels-last with the reference's channel order (level, dx-major "transposed" window). */
 int fgt_corr_lookup(const float* const* pyr, int levels, int B, int H1, int W1, int radius, const float* coords,
                     float* out, int ldo, void* stream);
+/* The same with an optional split output for the LDS-DMA conv kernels (bf16 hi plane at out_s, lo plane `ps` elements further, row stride
+ * ld_s, channels [4*(2r+1)^2, nch_pad) written as zeros so that the consumer's K is a multiple of 32); out may be NULL when out_s is given.
+ * Both forms hold the same values (hi + lo is the 16-bit split of the fp32 result). */
+int fgt_corr_lookup_split(const float* const* pyr, int levels, int B, int H1, int W1, int radius, const float* coords,
+                          float* out, int ldo, void* out_s, int ld_s, long ps, int nch_pad, void* stream);
 
 /* RAFT convex upsampling (RAFT/raft.py:73-84): flow [B,H,W,2] (ld), mask [B,H,W,576] (ld) -> up [B,2,8H,8W] NCHW */
 int fgt_convex_upsample(const float* flow, int ldf, const float* mask, int ldm, int B, int H, int W, float* out,

@@ -349,7 +349,7 @@ def laplace_fill(maps, masks, iters=1000, tol=1e-6):
     return torch.from_numpy(np.stack(out).astype(np.float32))
 
 
-def corr_lookup(pyr, B, H1, W1, radius, coords, out):
+def corr_lookup(pyr, B, H1, W1, radius, coords, out=None, out_s=None):
     r = radius
     c = coords.reshape(B * H1 * W1, 1, 1, 2)
     d = torch.linspace(-r, r, 2 * r + 1)
@@ -358,8 +358,13 @@ def corr_lookup(pyr, B, H1, W1, radius, coords, out):
     for i, lvl in enumerate(pyr):
         Hl, Wl = H1 >> i, W1 >> i
         res.append(_sample(lvl.reshape(B * H1 * W1, 1, Hl, Wl), c / 2 ** i + delta).view(B, H1, W1, -1))
-    out.copy_(torch.cat(res, -1))
-    return out
+    val = torch.cat(res, -1)
+    if out is not None:
+        out.copy_(val)
+    if out_s is not None:                                    # split output: the taps, then zero channels up to the tensor's width
+        out_s.x.zero_()
+        out_s.x[..., :val.shape[-1]].copy_(val)
+    return out if out_s is None else (out_s if out is None else (out, out_s))
 
 
 def convex_upsample(flow, mask):

@@ -100,6 +100,19 @@ def test_raft_helper_kernels(dev):
     out = torch.empty(B, H1, W1, 324, device=dev)
     ops.corr_lookup(dpyr, B, H1, W1, 4, coords.permute(0, 2, 3, 1).contiguous().to(dev), out)
     assert report("corr_lookup", out.permute(0, 3, 1, 2), ref)[0] < 1e-4
+    # split output (RAFT's update block in bf16x3 mode): the same values as a bf16 hi / lo pair, zero channels up to a multiple of 32;
+    # both forms from one launch; coordinates far outside the map and exactly on integers (taps outside the staged window / zero weights)
+    cs = ops.Split.empty((B, H1, W1, 352), dev, h=False)
+    out2 = torch.empty_like(out)
+    ops.corr_lookup(dpyr, B, H1, W1, 4, coords.permute(0, 2, 3, 1).contiguous().to(dev), out2, out_s=cs)
+    assert torch.equal(out2, out)
+    assert torch.equal(cs.data[..., :324], ops.split(out, h=False).data) and float(cs.data[..., 324:].float().abs().max()) == 0.0
+    c2 = (RO.coords_grid(B, H1, W1) + torch.randn(B, 2, H1, W1, generator=g).round() * 7).clone()
+    c2[:, :, :2] = 1e4
+    c2[:, :, 2:4] = -37.5
+    ref2 = RO.corr_lookup(pyr, c2)
+    ops.corr_lookup(dpyr, B, H1, W1, 4, c2.permute(0, 2, 3, 1).contiguous().to(dev), out2)
+    assert report("corr_lookup (integer / far coordinates)", out2.permute(0, 3, 1, 2), ref2)[0] < 1e-4
     flow = torch.randn(B, 2, H1, W1, generator=g)
     mask = torch.randn(B, 576, H1, W1, generator=g)
     f4 = torch.zeros(B, H1, W1, 4)
