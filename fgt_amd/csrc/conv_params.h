@@ -12,6 +12,7 @@ struct ConvP {
     const float* zero_page;   // 256 zero bytes in device memory: target of out-of-range gathers
     int mtiles, ntiles, mchunk, xcd_swizzle;   // tile grid and XCD-aware ordering (set by the launcher)
     int pipe;   // bf16x3: software-pipelined K loop (FGT_CONV_PIPE=0 selects the plain double-buffered loop)
+    int tr_li = 0;  // conv_taps.hip, k x 1 convolutions: != 0 (= H) when the tile's rows walk the image in (n, x, y) order; the epilogue maps them back
     int nt_store;   // epilogue stores non-temporal (default; FGT_CONV_NT=0 for A/B measurements): the output is written once and read by the NEXT
                     // kernel — keeping it out of the XCD's L2 leaves the cache to the A / B tiles this kernel re-reads.  Measured per layer
                     // (profiles/r03_run2_split_sweep_nt_stores.txt): K = 512 GEMMs +5...10 %, 3x3 layers +2 %, none slower

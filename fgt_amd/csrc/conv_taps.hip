@@ -77,11 +77,19 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     char* const Abuf = lds + 2 * B_BYTES;                // [2][hi AR rows, zero row | lo AR rows, zero row]
     if (tid < 64) reinterpret_cast<float*>(Abuf + (tid >> 5) * A_BYTES + ((tid >> 4) & 1) * APL + AR * 64)[tid & 15] = 0.f;
 
-    const int W = d.W, H = d.H, dwx = d.dw;
+    // Axes.  Normal mode: the reused taps are the kx taps, the tile's rows are consecutive pixels of the flattened (n, y, x) index.  TRANSPOSED
+    // mode (p.tr_li != 0: k x 1 convolutions, RAFT's vertical GRU pass): the reused taps are the ky taps and the tile's rows walk the image
+    // in (n, x, y) order — row m' = (n, x, y) is pixel n*H*W + y*W + x; every LDS-DMA lane carries its own address, so a column strip costs
+    // what a row strip costs, and the epilogue maps m' back to the pixel (conv_out_row).  "inner" = the reused axis, "outer" = the other one.
+    const bool tr = p.tr_li != 0;
+    const int W = d.W, H = d.H;
     const int HW = H * W;
+    const int Li = tr ? H : W, Lo = tr ? W : H;             // extents
+    const int Si = tr ? W : 1, So = tr ? 1 : W;             // pixel strides
+    const int dwx = tr ? d.dh : d.dw, d_o = tr ? d.dw : d.dh, p_i = tr ? d.ph : d.pw, p_o = tr ? d.pw : d.ph;
     const bool il = d.in_split == 2;
     const int nch0 = p.Cg0 / 32, nch1 = p.Cg1 / 32, nchunk = nch0 + nch1;
-    const int nss = d.kh * nchunk;
+    const int nss = (tr ? d.kw : d.kh) * nchunk;
     const long cstride = il ? 128 : 64;                  // bytes from one 32-channel chunk of a pixel to the next
 
     // ---- im2col source iterator (wave-uniform): the super-step whose A rows are requested next.  Byte pointers to chunk (ky, c) of pixel 0:
@@ -95,7 +103,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     const char* a_hi = src_hi(0);
     const char* a_lo = a_hi + src_lo_off(0);
     int a_ld = d.ld0, a_left = nch0, a_src = 0;
-    int a_dy = -d.ph, a_dyW = -d.ph * W;
+    int a_dy = -p_o, a_dyW = -p_o * So;                   // outer tap shift: in outer coordinates / in pixels
     auto a_advance = [&]() {
         a_hi += cstride; a_lo += cstride;
         if (--a_left == 0) {
@@ -103,7 +111,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
                 a_src = 1; a_left = nch1; a_ld = d.ld1;
             } else {
                 a_src = 0; a_left = nch0; a_ld = d.ld0;
-                a_dy += d.dh; a_dyW += d.dh * W;
+                a_dy += d_o; a_dyW += d_o * So;
             }
             a_hi = src_hi(a_src);
             a_lo = a_hi + src_lo_off(a_src);
@@ -117,10 +125,12 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
 #pragma unroll
     for (int it = 0; it < APW; ++it) {
         const int j = wave + it * NW;
-        const long q = (long)bm0 - d.pw + (j % GA) * 16 + lrow;
+        const long q = (long)bm0 - p_i + (j % GA) * 16 + lrow;      // tile-order index of the LDS row for the centre taps
         const bool valid = j < NPA && q >= 0 && q < (long)d.N * HW;
-        a_q[it] = valid ? (int)q : 0;
-        a_y[it] = valid ? (int)(q % HW) / W : -(1 << 30);
+        const int rem = valid ? (int)(q % HW) : 0;
+        const int co = rem / Li, ci = rem - co * Li;                // outer / inner coordinate
+        a_q[it] = valid ? (int)(q - rem) + co * So + ci * Si : 0;   // its pixel
+        a_y[it] = valid ? co : -(1 << 30);
     }
     const char* const zp = reinterpret_cast<const char*>(p.zero_page);
     auto issue_A = [&](int it, int ab) {
@@ -128,7 +138,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
         if (j >= NPA) return;                             // (wave-uniform)
         const int plane = j / GA, grp = j % GA;
         const char* ptr = (plane ? a_lo : a_hi) + 2 * ((long)(a_q[it] + a_dyW) * a_ld + kc * 8);
-        const bool ok = (unsigned)(a_y[it] + a_dy) < (unsigned)H;
+        const bool ok = (unsigned)(a_y[it] + a_dy) < (unsigned)Lo;
         glds16(ok ? ptr : zp, Abuf + ab * A_BYTES + plane * APL + grp * 1024);
     };
 
@@ -141,7 +151,8 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
         const int brow = bn0 + grp * 16 + lrow;          // (< Npad: Npad is a multiple of 128 >= BN)
         wp[it] = reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + brow) * (2 * d.Kpad) + plane * 32 + kc * 8);
     }
-    const long dkx = (long)nchunk * 128, dss = (1 - (long)(KW - 1) * nchunk) * 128;
+    // (transposed: the reused taps are ky: + kw * nchunk per tap, and the step to the next kx is the step to the next chunk)
+    const long dkx = (long)nchunk * (tr ? d.kw : 1) * 128, dss = 128 - (KW - 1) * dkx, dky = tr ? dss : 128;
     int b_c = 0;                                          // chunk (within its ky) of the super-step the B stream is in
     auto issue_B = [&](int bs) {
 #pragma unroll
@@ -154,7 +165,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
         long dlt = dkx;
         if (last_kx) {
             dlt = dss;
-            if (++b_c == nchunk) { b_c = 0; dlt = 128; }
+            if (++b_c == nchunk) { b_c = 0; dlt = dky; }
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) wp[it] += dlt;
@@ -174,7 +185,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         Rb[i] = wm * WTM + i * 32 + l31;
-        oxp[i] = (bm0 + Rb[i]) % W - d.pw;
+        oxp[i] = (bm0 + Rb[i]) % Li - p_i;
     }
     const unsigned b_lane = (unsigned)((wn * WTN + l31) * 64);     // B fragment rows: wave-tile base (multiple of 32) + l31
 
@@ -201,7 +212,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
                 if constexpr (KW > 3 || NW >= 8) asm volatile("" : "+s"(sh));
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const bool xin = (unsigned)(oxp[i] + sh) < (unsigned)W;
+                    const bool xin = (unsigned)(oxp[i] + sh) < (unsigned)Li;
                     const int R = xin ? Rb[i] + sh : AR;
                     const unsigned a0 = Ab + (unsigned)R * 64u + (unsigned)(((R >> 2) & 3) ^ lh) * 16u;     // k-half 0: slot lh; k-half 1: slot 2 + lh
                     const unsigned a1 = a0 ^ 32u;
@@ -282,11 +293,13 @@ int launch_kw(const ConvP& p, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int MINW>
 int launch(const ConvP& p, hipStream_t s) {
-    switch (p.d.kw) {
-        case 3: return launch_kw<BM, BN, WM, WN, MINW, 3>(p, s);
-        case 5: return launch_kw<BM, BN, WM, WN, MINW, 5>(p, s);
-        case 7: return launch_kw<BM, BN, WM, WN, MINW, 7>(p, s);
-        default: fgt_set_error("fgt_conv2d: the tap-reusing kernel is built for kw = 3, 5, 7 (got %d)", p.d.kw); return FGT_EINVAL;
+    ConvP q = p;
+    q.tr_li = p.d.kw == 1 ? p.d.H : 0;                    // k x 1: transposed mode
+    switch (q.tr_li ? p.d.kh : p.d.kw) {
+        case 3: return launch_kw<BM, BN, WM, WN, MINW, 3>(q, s);
+        case 5: return launch_kw<BM, BN, WM, WN, MINW, 5>(q, s);
+        case 7: return launch_kw<BM, BN, WM, WN, MINW, 7>(q, s);
+        default: fgt_set_error("fgt_conv2d: the tap-reusing kernel is built for 3, 5, 7 reused taps (got %d x %d)", p.d.kh, p.d.kw); return FGT_EINVAL;
     }
 }
 
@@ -297,7 +310,9 @@ int launch(const ConvP& p, hipStream_t s) {
 bool fgt_conv_taps_eligible(const ConvP& p) {
     const fgt_conv_desc& d = p.d;
     return d.precision == FGT_PREC_BF16X3 && (d.in_split == 1 || d.in_split == 2) && (d.w_il == 1 || d.w_il == 2) && d.sh == 1 && d.sw == 1 && !d.upsample && d.pad_mode == 0 &&
-           d.in_relu == 0 && d.Ho == d.H && d.Wo == d.W && (d.kw == 3 || d.kw == 5 || d.kw == 7) && (d.kw - 1) * d.dw <= HALO && p.Cg0 % 32 == 0 && p.Cg1 % 32 == 0 &&
+           d.in_relu == 0 && d.Ho == d.H && d.Wo == d.W && p.Cg0 % 32 == 0 && p.Cg1 % 32 == 0 &&
+           (((d.kw == 3 || d.kw == 5 || d.kw == 7) && (d.kw - 1) * d.dw <= HALO) ||                        // kx taps reused
+            (d.kw == 1 && (d.kh == 3 || d.kh == 5 || d.kh == 7) && (d.kh - 1) * d.dh <= HALO)) &&           // k x 1: ky taps reused (transposed tile order)
            d.Kpad == p.K && p.Cout_g > 4;
 }
 

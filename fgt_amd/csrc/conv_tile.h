@@ -52,6 +52,15 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
+// Output pixel of tile row m.  Every kernel but the transposed mode of conv_taps.hip walks the output in (n, y, x) order: m IS the pixel.
+// Transposed (p.tr_li = H): m = (n, x, y) -> n*H*W + y*W + x.
+__device__ __forceinline__ int conv_out_row(const ConvP& p, int m) {
+    if (!p.tr_li) return m;
+    const int n = m / p.HoWo, rem = m - n * p.HoWo;
+    const int x = rem / p.tr_li, y = rem - x * p.tr_li;
+    return n * p.HoWo + y * (p.HoWo / p.tr_li) + x;
+}
+
 // ---- epilogue.  The accumulators go through LDS (the tile buffers are free now) so that the global side is a compact,
 // coalesced float4 loop shared by every epilogue flavour: bias / per-channel scale, activation, mul / add / GRU combine,
 // then the fp32 store (NHWC slice or NCHW) and / or the pre-split bf16 store (desc.out_split) the next conv's LDS-DMA
@@ -112,8 +121,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
 #pragma unroll
                 for (int u0 = 0; u0 < UN; ++u0) {
                     const int it = c0 + u0;
-                    const int m = mrow + it * RPI;
-                    ok[u0] = col_ok && m < p.M;
+                    const int mt = mrow + it * RPI;
+                    ok[u0] = col_ok && mt < p.M;
+                    const int m = conv_out_row(p, mt);
                     cv[u0] = *reinterpret_cast<const float4*>(Ws + (r0 + it * RPI) * WTN + c4 * 4);
                     // (out-of-range lanes read the zero page: the select is on the address, the loads stay back to back)
                     a1[u0] = zero;
@@ -125,7 +135,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 }
 #pragma unroll
                 for (int u0 = 0; u0 < UN; ++u0) {
-                    const int m = mrow + (c0 + u0) * RPI;
+                    const int m = conv_out_row(p, mrow + (c0 + u0) * RPI);
                     float v[4] = {cv[u0].x * sc.x + bi.x, cv[u0].y * sc.y + bi.y, cv[u0].z * sc.z + bi.z, cv[u0].w * sc.w + bi.w};
                     const float x1[4] = {a1[u0].x, a1[u0].y, a1[u0].z, a1[u0].w};
                     const float x2[4] = {a2[u0].x, a2[u0].y, a2[u0].z, a2[u0].w};
@@ -192,9 +202,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         const int mbase = bm0 + ps * EP_BM;
         for (int idx = tid; idx < EP_BM * (BN / 4); idx += NT) {
             const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
-            const int m = mbase + row;
             const int n = bn0 + c4 * 4;
-            if (m >= p.M || n >= p.Cout_g) continue;
+            if (mbase + row >= p.M || n >= p.Cout_g) continue;
+            const int m = conv_out_row(p, mbase + row);
             const float4 cv = *reinterpret_cast<const float4*>(Cs + row * BN + c4 * 4);
             float v[4] = {cv.x, cv.y, cv.z, cv.w};
             const int co = g * p.Cout_g + n;

@@ -131,13 +131,14 @@ __device__ __forceinline__ float corr_tap_global(const float* vol, int Hl, int W
 }
 
 // All (2r+1)^2 taps of a (pixel, level) read the same (2r+2)^2 integer-aligned window of that pixel's correlation map (the taps differ by
-// whole pixels).  A block stages the windows of CL_PB pixels x 4 levels in LDS — 12 x 12 values each for r = 4, one margin column / row on
+// whole pixels).  A block stages the windows of CL_PB pixels x 4 levels in LDS — 10 rows x 12 values each for r = 4: one margin COLUMN on
 // either side because floor() of the per-tap coordinate may land one off floor(x) + (a - r) after the reference's normalise / un-normalise
-// round trip — with row-contiguous loads, zeros outside the map; then every thread computes 4 consecutive output channels from LDS with the
+// round trip (it costs no extra cache line), no margin rows (each row is its own line of a 5.4 GB volume: the kernel is bound by those
+// fetches) — with row-contiguous loads, zeros outside the map; then every thread computes 4 consecutive output channels from LDS with the
 // per-tap weights (a value * weight sum in the same order as corr_tap_global: adding 0 * w for an outside corner is exact, so the two paths
 // are bit-identical; a tap whose corner falls outside the staged window takes the global path).  The one-thread-per-tap kernel this
 // replaces issued 4 scattered 4-byte loads per output (adjacent lanes = adjacent map ROWS): 0.43 ms per call at 864x480 x 32 pairs.
-constexpr int CL_PB = 8, CL_WIN = 12, CL_PITCH = 13, CL_WSZ = CL_WIN * CL_PITCH;
+constexpr int CL_PB = 8, CL_WIN = 12, CL_ROWS = 10, CL_PITCH = 13, CL_WSZ = CL_ROWS * CL_PITCH;
 __global__ void __launch_bounds__(256) corr_lookup_kernel(PyrPtrs pyr, int levels, long npix, int H1, int W1, int radius, const float* coords,
                                                           float* out, int ldo, __bf16* out_s, int ld_s, long ps, int nch_pad) {
     __shared__ float win[CL_PB * 4 * CL_WSZ];
@@ -150,11 +151,11 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(PyrPtrs pyr, int level
         const int pl = tid / levels, lvl = tid - pl * levels;
         const float scale = (float)(1 << lvl);
         wbase[tid][0] = (int)floorf(coords[(q0 + pl) * 2] / scale) - radius - 1;
-        wbase[tid][1] = (int)floorf(coords[(q0 + pl) * 2 + 1] / scale) - radius - 1;
+        wbase[tid][1] = (int)floorf(coords[(q0 + pl) * 2 + 1] / scale) - radius;
     }
     __syncthreads();
-    for (int idx = tid; idx < npx * levels * CL_WIN * CL_WIN; idx += 256) {
-        const int w = idx / (CL_WIN * CL_WIN), e = idx - w * (CL_WIN * CL_WIN);
+    for (int idx = tid; idx < npx * levels * CL_ROWS * CL_WIN; idx += 256) {
+        const int w = idx / (CL_ROWS * CL_WIN), e = idx - w * (CL_ROWS * CL_WIN);
         const int j = e / CL_WIN, i = e - j * CL_WIN;
         const int pl = w / levels, lvl = w - pl * levels;
         const int Hl = H1 >> lvl, Wl = W1 >> lvl;
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(PyrPtrs pyr, int level
             const Bilin bl = bilin(ix, iy);
             const int w = pl * levels + lvl;
             const int rx = bl.x0 - wbase[w][0], ry = bl.y0 - wbase[w][1];
-            if ((unsigned)rx < (unsigned)(CL_WIN - 1) && (unsigned)ry < (unsigned)(CL_WIN - 1)) {
+            if ((unsigned)rx < (unsigned)(CL_WIN - 1) && (unsigned)ry < (unsigned)(CL_ROWS - 1)) {
                 const float* wv = win + w * CL_WSZ + ry * CL_PITCH + rx;
                 float s = 0.f;
                 s += wv[0] * bl.wnw;
@@ -307,7 +308,7 @@ extern "C" int fgt_corr_lookup_split(const float* const* pyr, int levels, int B,
                                      float* out, int ldo, void* out_s, int ld_s, long ps, int nch_pad, void* stream) {
     FGT_REQUIRE(pyr && coords && (out || out_s) && levels >= 1 && levels <= 4, "fgt_corr_lookup: bad arguments");
     const int side = 2 * radius + 1, nch = levels * side * side;
-    FGT_REQUIRE(radius >= 1 && 2 * radius + 4 <= CL_WIN, "fgt_corr_lookup: radius %d (the staged window holds radius <= %d)", radius, (CL_WIN - 4) / 2);
+    FGT_REQUIRE(radius >= 1 && radius <= (CL_ROWS - 2) / 2, "fgt_corr_lookup: radius %d (the staged window holds radius <= %d)", radius, (CL_ROWS - 2) / 2);
     FGT_REQUIRE(nch % 4 == 0, "fgt_corr_lookup: levels * (2 radius + 1)^2 = %d is not a multiple of 4", nch);
     FGT_REQUIRE(!out || (ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0), "fgt_corr_lookup: out must be 16-byte aligned with a row stride that is a multiple of 4 floats");
     FGT_REQUIRE(!out_s || (nch_pad >= nch && nch_pad % 4 == 0 && ld_s >= nch_pad && ld_s % 4 == 0 && ps % 4 == 0 && (reinterpret_cast<uintptr_t>(out_s) & 7) == 0),

@@ -29,7 +29,10 @@ CASES = [
     ("3x3_rows_cross_images", 3, 7, 9, 32, 0, 64, (3, 3), (1, 1), 1, 1),            # W = 9: a 128-row tile spans 14 image rows and 2-3 images
     ("3x3_w_smaller_than_halo", 2, 33, 5, 32, 0, 32, (3, 3), (1, 1), 1, 1),
     ("1x5_gru", 2, 15, 27, 128, 256, 128, (1, 5), (0, 2), 1, 1),                    # RAFT SepConvGRU horizontal pass, two sources
-    ("5x1_not_routed", 1, 15, 27, 64, 0, 64, (5, 1), (2, 0), 1, 1),                 # kw = 1: served by the other kernels
+    ("5x1_gru_vertical", 2, 15, 27, 128, 256, 128, (5, 1), (2, 0), 1, 1),           # RAFT SepConvGRU vertical pass: ky taps reused, tile rows in (n, x, y) order
+    ("3x1_h_smaller_than_halo", 2, 5, 33, 32, 0, 32, (3, 1), (1, 0), 1, 1),
+    ("7x1_dil2_cout_200", 1, 40, 21, 64, 0, 200, (7, 1), (6, 0), 2, 1),
+    ("1x1_not_served", 1, 15, 27, 64, 0, 64, (1, 1), (0, 0), 1, 1),                 # no taps to reuse: the other kernels
     ("3x3_dil2", 1, 30, 27, 96, 0, 96, (3, 3), (2, 2), 2, 1),
     ("3x3_dil8", 1, 40, 44, 192, 0, 192, (3, 3), (8, 8), 8, 1),                     # LAFC middle: (kw - 1) * dw = 16 = the halo
     ("3x3_g2_two_source", 2, 15, 27, 256, 384, 512, (3, 3), (1, 1), 1, 2),          # encoder group-interleaved concat
@@ -70,7 +73,7 @@ def test_taps_kernel_vs_fp64_and_other_kernels(case, il, dev):
     e_other = (other.double() - ref).abs().max().item()
     scale = ref.abs().max().item()
     auto = ops.conv2d(xs, pc, x1=x1s, pad=pad, dil=dil, act="lrelu", precision="bf16x3")                           # routed by geometry
-    if kw == 1:
+    if kw == 1 and kh == 1:
         assert torch.equal(auto, other)
         with pytest.raises(RuntimeError, match="does not serve"):
             ops.conv2d(xs, pc, x1=x1s, pad=pad, dil=dil, act="lrelu", tile="128x128x8t", precision="bf16x3")
@@ -89,22 +92,26 @@ def test_taps_kernel_vs_fp64_and_other_kernels(case, il, dev):
 
 
 def test_taps_epilogues_and_split_outputs(dev):
-    """GRU / mul / add epilogues, fp32 + split outputs, output written into a channel slice — through the tap kernel (RAFT's update block)."""
+    """GRU / mul / add epilogues, fp32 + split outputs, output written into a channel slice — through the tap kernel (RAFT's update block:
+    horizontal 1x5 pass, and the vertical 5x1 pass whose tile rows are in (n, x, y) order: aux operands and outputs are mapped back)."""
     from fgt_amd import ops
     B, H, W = 2, 15, 27
     rows = B * H * W
     net, xb = _rand(B, H, W, 128, seed=1).to(dev), _rand(B, H, W, 256, seed=2).to(dev)
     z, hprev = torch.sigmoid(_rand(rows, 128, seed=3)).to(dev), _rand(rows, 128, seed=4).to(dev)
-    w, b = _rand(128, 384, 1, 5, seed=5, scale=0.03), _rand(128, seed=6)
-    pc = ops.PackedConv(w.to(dev), b.to(dev))
     ns, xs = ops.split(net), ops.split(xb)
-    for epi, kw in (("gru", dict(act="tanh", epi="gru", aux1=z, aux2=hprev)), ("mul", dict(act="sigmoid", epi="mul", aux1=hprev)), ("none", dict(act="sigmoid"))):
-        ref = ops.conv2d(ns, pc, x1=xs, pad=(0, 2), tile="128x128", precision="bf16x3", **kw)
-        o32, osp = ops.conv2d(ns, pc, x1=xs, pad=(0, 2), precision="bf16x3", out_split="both", **kw)
-        assert (o32 - ref).abs().max().item() <= 3e-6 * max(1.0, ref.abs().max().item()), epi
-        assert torch.equal(osp.data, ops.split(o32).data)
-        only = ops.conv2d(ns, pc, x1=xs, pad=(0, 2), precision="bf16x3", out_split="only", **kw)
-        assert torch.equal(only.data, osp.data)
+    for ksz, pad in (((1, 5), (0, 2)), ((5, 1), (2, 0))):
+        w, b = _rand(128, 384, *ksz, seed=5, scale=0.03), _rand(128, seed=6)
+        pc = ops.PackedConv(w.to(dev), b.to(dev))
+        for epi, kw in (("gru", dict(act="tanh", epi="gru", aux1=z, aux2=hprev)), ("mul", dict(act="sigmoid", epi="mul", aux1=hprev)), ("none", dict(act="sigmoid"))):
+            ref = ops.conv2d(ns, pc, x1=xs, pad=pad, tile="128x128", precision="bf16x3", **kw)
+            o32, osp = ops.conv2d(ns, pc, x1=xs, pad=pad, precision="bf16x3", out_split="both", **kw)
+            assert (o32 - ref).abs().max().item() <= 3e-6 * max(1.0, ref.abs().max().item()), (ksz, epi)
+            assert torch.equal(osp.data, ops.split(o32).data)
+            only = ops.conv2d(ns, pc, x1=xs, pad=pad, precision="bf16x3", out_split="only", **kw)
+            assert torch.equal(only.data, osp.data)
+            nchw = ops.conv2d(ns, pc, x1=xs, pad=pad, precision="bf16x3", out_nchw=True, tile="128x64t", **kw)      # general (workgroup-wide) epilogue
+            assert torch.equal(nchw.permute(0, 2, 3, 1), o32.view(B, H, W, 128))
     wide = ops.Split.empty((rows, 256), dev)
     wide.data.zero_()
     w2 = _rand(128, 256, 3, 3, seed=7, scale=0.02)

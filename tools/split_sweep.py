@@ -48,6 +48,7 @@ LAYERS = {  # name: (N, H, W, C0, C1, Cout, groups, k, stride, pad)
     "raft fh1 128->256 3x3": (32, 60, 108, 128, 0, 256, 1, 3, 1, 1),
     "raft motion 192+64->128 3x3": (32, 60, 108, 192, 64, 128, 1, 3, 1, 1),
     "raft gru 128+256->128 1x5": (32, 60, 108, 128, 256, 128, 1, (1, 5), 1, (0, 2)),
+    "raft gru 128+256->128 5x1": (32, 60, 108, 128, 256, 128, 1, (5, 1), 1, (2, 0)),
     # LAFC, 8 pivots x 3 flows
     "lafc 96->96 3x3 120x216": (24, 120, 216, 96, 0, 96, 1, 3, 1, 1),
     "lafc 192->192 3x3 60x108": (24, 60, 108, 192, 0, 192, 1, 3, 1, 1),
