@@ -103,84 +103,108 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 sc = (p.cscale && col_ok) ? *reinterpret_cast<const float4*>(p.cscale + co) : one;
         const float4 bi = (p.cbias && col_ok) ? *reinterpret_cast<const float4*>(p.cbias + co) : zero;
-        static_for<TM>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
+        // The body is instantiated per number of aux operands (AUX = 0: no epilogue operand, 1: mul / add, 2: GRU) and dispatched on desc.epi.
+        // With desc.epi tested at run time inside ONE body, hipcc put `s_waitcnt vmcnt(0)` in front of every row group (the join of the
+        // paths with and without aux loads) — and on gfx9 that counter also holds the STORES until they are acknowledged: every group of
+        // stores was waited for before the next one was issued, 13 k cycles for 64 KB per workgroup in the K = 512 GEMMs
+        // (profiles/r02_run8_conv_trace_qkv_epilogue.txt).  AUX = 0 has no load behind its first store: the stores stream.
+        auto body = [&](auto auxc) {
+        constexpr int AUX = decltype(auxc)::value;
+        // loads of UN row groups in flight together (the 128-accumulator-register tiles have little room: 2 at a time)
+        // (two aux operands, each held for two groups: 2 rows at a time as well)
+        constexpr int UN = (TM * TN >= 8 || AUX == 2) ? 2 : ITER;
+        constexpr int GPB = ITER / UN, NG = TM * GPB;                  // row groups per 32-row block, per wavefront
+        // Aux operands are requested ONE GROUP AHEAD, in front of the previous group's stores: the wait for a group's operands then covers
+        // the loads older than those stores, not the stores (same counter, in order) — otherwise every group would wait for the write
+        // acknowledgements of the group before it.
+        float4 ax1[2][UN], ax2[2][UN];
+        auto load_aux = [&](auto gc, float4 (&a1)[UN], float4 (&a2)[UN]) {
+            constexpr int gi = decltype(gc)::value, i = gi / GPB, c0 = (gi % GPB) * UN;
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int u0 = 0; u0 < UN; ++u0) {
+                const int mt = bm0 + wm * WTM + i * 32 + r0 + (c0 + u0) * RPI;
+                const bool okk = col_ok && mt < p.M;
+                const int m = conv_out_row(p, mt);
+                // (out-of-range lanes read the zero page: the select is on the address, the loads stay back to back)
+                if constexpr (AUX >= 1) a1[u0] = *reinterpret_cast<const float4*>(okk ? p.aux1 + (long)m * d.ld_aux1 + co : p.zero_page);
+                if constexpr (AUX >= 2) a2[u0] = *reinterpret_cast<const float4*>(okk ? p.aux2 + (long)m * d.ld_aux2 + co : p.zero_page);
+            }
+        };
+        if constexpr (AUX >= 1) load_aux(std::integral_constant<int, 0>{}, ax1[0], ax2[0]);
+        static_for<NG>([&](auto gc) {
+            constexpr int gi = decltype(gc)::value, i = gi / GPB, c0 = (gi % GPB) * UN;
+            if constexpr (gi % GPB == 0) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) Ws[((e & 3) + 8 * (e >> 2) + 4 * lh) * WTN + j * 32 + l31] = acc[i][j][e];
-            __builtin_amdgcn_wave_barrier();                           // the patch is exchanged between lanes of this wavefront only
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) Ws[((e & 3) + 8 * (e >> 2) + 4 * lh) * WTN + j * 32 + l31] = acc[i][j][e];
+                __builtin_amdgcn_wave_barrier();                       // the patch is exchanged between lanes of this wavefront only
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if constexpr (AUX >= 1 && gi + 1 < NG) load_aux(std::integral_constant<int, gi + 1>{}, ax1[(gi + 1) & 1], ax2[(gi + 1) & 1]);
             const int mrow = bm0 + wm * WTM + i * 32 + r0;
-            // loads of UN row groups in flight together (the 128-accumulator-register tiles have little room: 2 at a time)
-            constexpr int UN = (TM * TN >= 8) ? 2 : ITER;
+            float4 cv[UN];
+            bool ok[UN];
 #pragma unroll
-            for (int c0 = 0; c0 < ITER; c0 += UN) {
-                float4 cv[UN], a1[UN], a2[UN];
-                bool ok[UN];
+            for (int u0 = 0; u0 < UN; ++u0) {
+                const int it = c0 + u0;
+                ok[u0] = col_ok && mrow + it * RPI < p.M;
+                cv[u0] = *reinterpret_cast<const float4*>(Ws + (r0 + it * RPI) * WTN + c4 * 4);
+            }
 #pragma unroll
-                for (int u0 = 0; u0 < UN; ++u0) {
-                    const int it = c0 + u0;
-                    const int mt = mrow + it * RPI;
-                    ok[u0] = col_ok && mt < p.M;
-                    const int m = conv_out_row(p, mt);
-                    cv[u0] = *reinterpret_cast<const float4*>(Ws + (r0 + it * RPI) * WTN + c4 * 4);
-                    // (out-of-range lanes read the zero page: the select is on the address, the loads stay back to back)
-                    a1[u0] = zero;
-                    a2[u0] = zero;
-                    if (d.epi != FGT_EPI_NONE)
-                        a1[u0] = *reinterpret_cast<const float4*>(ok[u0] ? p.aux1 + (long)m * d.ld_aux1 + co : p.zero_page);
-                    if (d.epi == FGT_EPI_GRU)
-                        a2[u0] = *reinterpret_cast<const float4*>(ok[u0] ? p.aux2 + (long)m * d.ld_aux2 + co : p.zero_page);
-                }
+            for (int u0 = 0; u0 < UN; ++u0) {
+                const int m = conv_out_row(p, mrow + (c0 + u0) * RPI);
+                float v[4] = {cv[u0].x * sc.x + bi.x, cv[u0].y * sc.y + bi.y, cv[u0].z * sc.z + bi.z, cv[u0].w * sc.w + bi.w};
+                float x1[4] = {0.f, 0.f, 0.f, 0.f}, x2[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (AUX >= 1) { const float4 t = ax1[gi & 1][u0]; x1[0] = t.x; x1[1] = t.y; x1[2] = t.z; x1[3] = t.w; }
+                if constexpr (AUX >= 2) { const float4 t = ax2[gi & 1][u0]; x2[0] = t.x; x2[1] = t.y; x2[2] = t.z; x2[3] = t.w; }
 #pragma unroll
-                for (int u0 = 0; u0 < UN; ++u0) {
-                    const int m = conv_out_row(p, mrow + (c0 + u0) * RPI);
-                    float v[4] = {cv[u0].x * sc.x + bi.x, cv[u0].y * sc.y + bi.y, cv[u0].z * sc.z + bi.z, cv[u0].w * sc.w + bi.w};
-                    const float x1[4] = {a1[u0].x, a1[u0].y, a1[u0].z, a1[u0].w};
-                    const float x2[4] = {a2[u0].x, a2[u0].y, a2[u0].z, a2[u0].w};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        float x = fgt_act(v[u], d.act, d.slope) * d.out_scale;
+                for (int u = 0; u < 4; ++u) {
+                    float x = fgt_act(v[u], d.act, d.slope) * d.out_scale;
+                    if constexpr (AUX == 1) {
                         if (d.epi == FGT_EPI_MUL) x *= x1[u];
-                        else if (d.epi == FGT_EPI_ADD) x = fgt_act(x + x1[u], d.act2, d.slope);
-                        else if (d.epi == FGT_EPI_GRU) x = (1.f - x1[u]) * x2[u] + x1[u] * x;
-                        v[u] = x;
+                        else x = fgt_act(x + x1[u], d.act2, d.slope);
                     }
-                    if (ok[u0]) {
-                        typedef float nt_f4 __attribute__((ext_vector_type(4)));
-                        typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
-                        const bool nt = p.nt_store != 0;
-                        if (want_f32) {
-                            float* o = p.out + (long)m * d.ldo + d.ooff + co;
-                            if (nt) __builtin_nontemporal_store(nt_f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<nt_f4*>(o));
-                            else *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                        }
-                        if (want_split) {
-                            const int cs = d.ooff_s + co;       // pso == 32: interleaved layout, channel c -> (c/32)*64 + c%32, lo 32 further
-                            if (p.pso < 0) {                    // pso == -1: one fp16 plane (in_split = 3 of the consumer)
-                                const uint2 h = fgt_half4(make_float4(v[0], v[1], v[2], v[3]));
-                                __bf16* o = p.out_s + (long)m * d.ldo_s + cs;
-                                if (nt) __builtin_nontemporal_store(nt_u2{h.x, h.y}, reinterpret_cast<nt_u2*>(o));
-                                else *reinterpret_cast<uint2*>(o) = h;
+                    if constexpr (AUX == 2) x = (1.f - x1[u]) * x2[u] + x1[u] * x;
+                    v[u] = x;
+                }
+                if (ok[u0]) {
+                    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                    typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
+                    const bool nt = p.nt_store != 0;
+                    if (want_f32) {
+                        float* o = p.out + (long)m * d.ldo + d.ooff + co;
+                        if (nt) __builtin_nontemporal_store(nt_f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<nt_f4*>(o));
+                        else *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                    if (want_split) {
+                        const int cs = d.ooff_s + co;       // pso == 32: interleaved layout, channel c -> (c/32)*64 + c%32, lo 32 further
+                        if (p.pso < 0) {                    // pso == -1: one fp16 plane (in_split = 3 of the consumer)
+                            const uint2 h = fgt_half4(make_float4(v[0], v[1], v[2], v[3]));
+                            __bf16* o = p.out_s + (long)m * d.ldo_s + cs;
+                            if (nt) __builtin_nontemporal_store(nt_u2{h.x, h.y}, reinterpret_cast<nt_u2*>(o));
+                            else *reinterpret_cast<uint2*>(o) = h;
+                        } else {
+                            uint2 hi, lo;
+                            split4(make_float4(v[0], v[1], v[2], v[3]), hi, lo);
+                            __bf16* o = p.out_s + (long)m * d.ldo_s + (p.pso == 32 ? ((cs >> 5) << 6) + (cs & 31) : cs);
+                            if (nt) {
+                                __builtin_nontemporal_store(nt_u2{hi.x, hi.y}, reinterpret_cast<nt_u2*>(o));
+                                __builtin_nontemporal_store(nt_u2{lo.x, lo.y}, reinterpret_cast<nt_u2*>(o + p.pso));
                             } else {
-                                uint2 hi, lo;
-                                split4(make_float4(v[0], v[1], v[2], v[3]), hi, lo);
-                                __bf16* o = p.out_s + (long)m * d.ldo_s + (p.pso == 32 ? ((cs >> 5) << 6) + (cs & 31) : cs);
-                                if (nt) {
-                                    __builtin_nontemporal_store(nt_u2{hi.x, hi.y}, reinterpret_cast<nt_u2*>(o));
-                                    __builtin_nontemporal_store(nt_u2{lo.x, lo.y}, reinterpret_cast<nt_u2*>(o + p.pso));
-                                } else {
-                                    *reinterpret_cast<uint2*>(o) = hi;
-                                    *reinterpret_cast<uint2*>(o + p.pso) = lo;
-                                }
+                                *reinterpret_cast<uint2*>(o) = hi;
+                                *reinterpret_cast<uint2*>(o + p.pso) = lo;
                             }
                         }
                     }
                 }
             }
-            __builtin_amdgcn_wave_barrier();                           // the patch is rewritten by the next row block
+            if constexpr (gi % GPB == GPB - 1) __builtin_amdgcn_wave_barrier();     // the patch is rewritten by the next row block
         });
+        };
+        if (d.epi == FGT_EPI_NONE) body(std::integral_constant<int, 0>{});
+        else if (d.epi == FGT_EPI_GRU) body(std::integral_constant<int, 2>{});
+        else body(std::integral_constant<int, 1>{});
         return;
     }
 
