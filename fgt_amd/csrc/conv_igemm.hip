@@ -335,7 +335,7 @@ extern "C" int fgt_conv_taps_route(const fgt_conv_desc* dd) {
     if (!dd || !taps_enabled() || dd->groups <= 0 || dd->tile != 0) return 0;
     ConvP p{};
     conv_params(*dd, p);
-    return fgt_conv_taps_eligible(p) ? 1 : 0;
+    return fgt_conv_taps_preferred(p) ? 1 : 0;
 }
 
 extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* x1v, const float* w_packed,
@@ -409,7 +409,7 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     int tile = d.tile;
     // tile = 0 or a +200 code on a layer conv_taps.hip serves: that kernel (geometry decides, see taps_enabled); an explicit tile of another
     // family on such a layer selects that family (A/B measurements, tests)
-    const bool taps = (taps_enabled() || d.tile >= FGT_TILE_TAPS) && (d.tile == 0 || d.tile >= FGT_TILE_TAPS) && fgt_conv_taps_eligible(p);
+    const bool taps = d.tile >= FGT_TILE_TAPS ? fgt_conv_taps_eligible(p) : (d.tile == 0 && taps_enabled() && fgt_conv_taps_preferred(p));
     FGT_REQUIRE(d.tile < FGT_TILE_TAPS || taps, "fgt_conv2d: tile %d (tap-reusing kernel) on a layer it does not serve", d.tile);
     if (taps && tile == 0) tile = FGT_TILE_TAPS + (p.Cout_g <= 192 ? FGT_TILE_128x64 : FGT_TILE_128x128x8);
     FGT_REQUIRE(!taps || d.w_il == (tile >= FGT_TILE_TAPS_BREG ? 2 : 1), "fgt_conv2d: tile %d takes weights with w_il = %d", tile, tile >= FGT_TILE_TAPS_BREG ? 2 : 1);

@@ -29,7 +29,8 @@ int fgt_conv_wide_launch(int tile, const ConvP& p, hipStream_t s);
 
 // conv_taps.hip: bf16x3 for stride-1 "same" convs with kw in {3, 5, 7} on split inputs: the A rows of a (ky, chunk) stay in LDS for all kx taps.
 // Selected by GEOMETRY (fgt_conv_taps_eligible), never by tuning: its accumulation order (ky, chunk, kx) differs from the other kernels'.
-bool fgt_conv_taps_eligible(const ConvP& p);
+bool fgt_conv_taps_eligible(const ConvP& p);     // the kernel can run the layer (explicit +200 tiles)
+bool fgt_conv_taps_preferred(const ConvP& p);    // ... and tile = 0 routes the layer to it
 int fgt_conv_taps_launch(int tile, const ConvP& p, hipStream_t s);
 // diag/conv_taps_breg.hip (diagnostic builds only): the same with the weight fragments loaded straight into registers (w_il = 2, tile code - 300)
 int fgt_conv_taps_breg_launch(int tile, const ConvP& p, hipStream_t s);

@@ -316,6 +316,13 @@ bool fgt_conv_taps_eligible(const ConvP& p) {
            d.Kpad == p.K && p.Cout_g > 4;
 }
 
+// Layers routed to this kernel when the caller leaves the tile to the library (geometry only, like eligibility).  Not the k x 1 convolutions over
+// a SHORT reused axis: LAFC's temporal 3 x 1 convs run over T = 3 — a third of the taps fall outside, the tile's rows are 3-pixel columns —
+// and measure 12 % slower to 2 % faster than the early-release tiles (profiles/r03_run13_split_sweep_lafc_temporal.txt).
+bool fgt_conv_taps_preferred(const ConvP& p) {
+    return fgt_conv_taps_eligible(p) && (p.d.kw > 1 || p.d.H >= 16);
+}
+
 int fgt_conv_taps_launch(int tile, const ConvP& p, hipStream_t s) {
     switch (tile) {
         case FGT_TILE_128x128x8: return launch<128, 128, 2, 4, 4>(p, s);

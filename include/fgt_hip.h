@@ -165,7 +165,7 @@ typedef struct fgt_conv_desc {
                                   * convolutions with kw in {3, 5, 7} on split inputs: the im2col rows of a (ky, 32-channel chunk) are loaded once for all kx taps
                                   * (3x3: -31 % LDS-DMA instructions, the im2col stream from memory shrinks by kw).  It accumulates in the order (ky, chunk, kx):
                                   * NOT bit-identical to the other kernels, same error.  fgt_conv2d therefore routes by GEOMETRY: a layer this kernel serves runs
-                                  * on it whenever tile = 0 (or a +200 code); an explicit tile of another family selects that family.  Its tiles are bit-identical
+                                  * on it whenever tile = 0 (k x 1 layers only when H >= 16) or a +200 code; an explicit tile of another family selects that family.  Its tiles are bit-identical
                                   * to each other.  FGT_CONV_TAPS=0 (environment) turns the routing off. */
 #define FGT_TILE_TAPS_BREG 300   /* DIAGNOSTIC BUILDS ONLY: the same kernel with weights in MFMA fragment order (w_il = 2) loaded straight into registers */
 #define FGT_TILE_F16_WIDE 100    /* FGT_PREC_F16 only: tile code + 100 = the same tile on the "wide" LDS image (a stage row is the pixel's whole

@@ -80,13 +80,16 @@ def test_taps_kernel_vs_fp64_and_other_kernels(case, il, dev):
         return
     first = None
     for t in TAPS:
+        if kw == 1 and t.endswith("r"):
+            continue                         # (the register-fed-weights experiment has no transposed mode)
         got = ops.conv2d(xs, pc, x1=x1s, pad=pad, dil=dil, act="lrelu", tile=t, precision="bf16x3")
         torch.cuda.synchronize()
         e = (got.double() - ref).abs().max().item()
         assert e <= max(2.0 * e_other, 2e-6 * scale) and e <= 2e-5 * scale, f"{name} {t}: {e:.3e} vs other kernels {e_other:.3e} (scale {scale:.2e})"
         first = got if first is None else first
         assert torch.equal(got, first), f"{name}: tile {t} differs from {TAPS[0]}"
-    assert torch.equal(auto, first), "an eligible layer with tile = auto must run on the tap-reusing kernel"
+    routed = kw > 1 or H >= 16             # (k x 1 over a short axis: the kernel serves it, the library does not prefer it)
+    assert torch.equal(auto, first if routed else other), "tile = auto: the tap-reusing kernel exactly on the layers the library routes to it"
     print(f"[parity] conv_taps {name} ({'interleaved' if il else 'planes'}): max |taps - fp64| {(first.double() - ref).abs().max().item():.2e}, "
           f"|conv_split - fp64| {e_other:.2e}, |taps - conv_split| {(first - other).abs().max().item():.2e} (outputs up to {scale:.2f})")
 
@@ -95,7 +98,7 @@ def test_taps_epilogues_and_split_outputs(dev):
     """GRU / mul / add epilogues, fp32 + split outputs, output written into a channel slice — through the tap kernel (RAFT's update block:
     horizontal 1x5 pass, and the vertical 5x1 pass whose tile rows are in (n, x, y) order: aux operands and outputs are mapped back)."""
     from fgt_amd import ops
-    B, H, W = 2, 15, 27
+    B, H, W = 2, 17, 27                     # (H >= 16: the vertical pass is routed to the tap-reusing kernel as well)
     rows = B * H * W
     net, xb = _rand(B, H, W, 128, seed=1).to(dev), _rand(B, H, W, 256, seed=2).to(dev)
     z, hprev = torch.sigmoid(_rand(rows, 128, seed=3)).to(dev), _rand(rows, 128, seed=4).to(dev)

@@ -52,6 +52,9 @@ LAYERS = {  # name: (N, H, W, C0, C1, Cout, groups, k, stride, pad)
     # LAFC, 8 pivots x 3 flows
     "lafc 96->96 3x3 120x216": (24, 120, 216, 96, 0, 96, 1, 3, 1, 1),
     "lafc 192->192 3x3 60x108": (24, 60, 108, 192, 0, 192, 1, 3, 1, 1),
+    # LAFC P3D temporal convs: 3 x 1 over (T = 3, H*W)
+    "lafc p3d 96 3x1 T": (8, 3, 25920, 96, 0, 96, 1, (3, 1), 1, (1, 0)),
+    "lafc p3d 192 3x1 T": (8, 3, 6480, 192, 0, 192, 1, (3, 1), 1, (1, 0)),
 }
 TILES = ["128x128", "256x128", "128x128x8", "256x128x16", "256x64x8", "128x128x8ea", "128x128x8eaw"]
 
