@@ -29,50 +29,65 @@ __device__ __forceinline__ void store_f32_or_split(float* out, long off, long ps
     }
 }
 
-// ------------------------------------------------------------------ LayerNorm: one wavefront per row
+// ------------------------------------------------------------------ LayerNorm: one wavefront per LN_R rows
+// (LN_R = 2 rows per wavefront, their loads issued together: with one row per wavefront the kernel sat at 0.57 of the HBM roof — a full
+//  chip of one-row wavefronts holds 16 MB in flight, about what 8 TB/s x 2 us needs; per-row arithmetic is unchanged)
 constexpr int LN_MAXV = 4;  // float4 per lane -> C <= 1024
+constexpr int LN_R = 2;
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1,
                                                         long rows, float eps, const float* gA, const float* bA, float* outA,
                                                         int ldA, const float* gB, const float* bB, float* outB, int ldB,
                                                         long psA, long psB) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_R;
+    if (row0 >= rows) return;
     const int C = C0 + C1, nv = C >> 2;
-    float4 v[LN_MAXV];
-    float s = 0.f;
+    float4 v[LN_R][LN_MAXV];
+    float s[LN_R];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < C) {
-            v[i] = c < C0 ? *reinterpret_cast<const float4*>(x0 + row * ld0 + c)
-                          : *reinterpret_cast<const float4*>(x1 + row * ld1 + (c - C0));
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        } else {
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < LN_R; ++r) {
+        const long row = row0 + r < rows ? row0 + r : row0;          // (a wavefront's last row may not exist: it re-reads row0, nothing is stored)
+        s[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < C) {
+                v[r][i] = c < C0 ? *reinterpret_cast<const float4*>(x0 + row * ld0 + c)
+                                 : *reinterpret_cast<const float4*>(x1 + row * ld1 + (c - C0));
+            } else {
+                v[r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     }
-    const float mean = wave_sum(s) / (float)C;
-    float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        if ((lane + 64 * i) < nv) {
-            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
-            ss += (a * a + b * b) + (c * c + e * e);
+    for (int r = 0; r < LN_R; ++r) {
+        if (row0 + r >= rows) break;
+        const long row = row0 + r;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i)
+            if ((lane + 64 * i) * 4 < C) s[r] += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+        const float mean = wave_sum(s[r]) / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            if ((lane + 64 * i) < nv) {
+                const float a = v[r][i].x - mean, b = v[r][i].y - mean, c = v[r][i].z - mean, e = v[r][i].w - mean;
+                ss += (a * a + b * b) + (c * c + e * e);
+            }
         }
-    }
-    const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)C + eps);
+        const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)C + eps);
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < C) {
-            const float4 n = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd,
-                                         (v[i].w - mean) * rstd);
-            const float4 g = *reinterpret_cast<const float4*>(gA + c), b = *reinterpret_cast<const float4*>(bA + c);
-            store_f32_or_split(outA, row * ldA + c, psA, make_float4(n.x * g.x + b.x, n.y * g.y + b.y, n.z * g.z + b.z, n.w * g.w + b.w), c);
-            if (outB) {
-                const float4 g2 = *reinterpret_cast<const float4*>(gB + c), b2 = *reinterpret_cast<const float4*>(bB + c);
-                store_f32_or_split(outB, row * ldB + c, psB, make_float4(n.x * g2.x + b2.x, n.y * g2.y + b2.y, n.z * g2.z + b2.z, n.w * g2.w + b2.w), c);
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < C) {
+                const float4 n = make_float4((v[r][i].x - mean) * rstd, (v[r][i].y - mean) * rstd, (v[r][i].z - mean) * rstd,
+                                             (v[r][i].w - mean) * rstd);
+                const float4 g = *reinterpret_cast<const float4*>(gA + c), b = *reinterpret_cast<const float4*>(bA + c);
+                store_f32_or_split(outA, row * ldA + c, psA, make_float4(n.x * g.x + b.x, n.y * g.y + b.y, n.z * g.z + b.z, n.w * g.w + b.w), c);
+                if (outB) {
+                    const float4 g2 = *reinterpret_cast<const float4*>(gB + c), b2 = *reinterpret_cast<const float4*>(bB + c);
+                    store_f32_or_split(outB, row * ldB + c, psB, make_float4(n.x * g2.x + b2.x, n.y * g2.y + b2.y, n.z * g2.z + b2.z, n.w * g2.w + b2.w), c);
+                }
             }
         }
     }
@@ -452,7 +467,7 @@ extern "C" int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, 
                 "fgt_layernorm: an interleaved output (ps = 32) needs C %% 32 == 0 and a row stride of at least 2 * C elements");
     const auto ob = [](long long ps) { return ps < 0 ? 2.0 : 4.0; };
     FgtProfScope prof(FGT_PROF_LAYERNORM, 0.0, (double)rows * ((C0 + C1) * 4.0 + (C0 + C1) * (ob(psA) + (outB ? ob(psB) : 0.0))), stream);
-    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, rows,
+    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4 * LN_R)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, rows,
                        eps, gA, bA, outA, ldA, gB, bB, outB, ldB, (long)psA, (long)psB);
     return fgt_check_launch("layernorm");
 }
