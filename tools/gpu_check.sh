@@ -28,18 +28,18 @@ if has bench; then
   grep '^{' gpurun_out/bench.log | python -c "
 import sys,json; d=json.loads(sys.stdin.read())
 print(d['value'],'fps', d['ms_per_step'],'ms; cpu', d.get('cpu_baseline',{}).get('value'), 'parity', d.get('parity_vs_cpu_oracle',{}).get('max_abs_diff'))
-for r in d.get('rooflines',[]): print('  ', r['kind'], r['frac'], r['algorithmic_tflops'],'TF alg', r['kernel_ms_per_step'],'ms/step', r['avg_launch_us'],'us/launch')
+for r in d.get('rooflines',[]): print('  ', r['kind'], r['frac'], r.get('algorithmic_tflops', r.get('achieved')),r['unit'], r['kernel_ms_per_step'],'ms/step', r['avg_launch_us'],'us/launch')
 for name in ('f16', 'fp32_exact'):
     f=d.get(name)
     if f:
         print(name, f['value'],'fps', f['ms_per_step'],'ms', 'parity', (f.get('parity_vs_cpu_oracle') or {}).get('max_abs_diff'), f.get('composite_vs_headline'))
-        for r in f.get('rooflines',[]): print('  ', r['kind'], r['frac'], r['algorithmic_tflops'],'TF alg', r['kernel_ms_per_step'],'ms/step')
+        for r in f.get('rooflines',[]): print('  ', r['kind'], r['frac'], r.get('algorithmic_tflops', r.get('achieved')),r['unit'], r['kernel_ms_per_step'],'ms/step')
 " || tail -5 gpurun_out/bench.log
 fi
 if has pmc; then
   echo "== PMC HBM traffic of the MFMA kernels over bench.py (tiles pre-seeded: only clip-pass launches in the trace)"
   for c in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmcb_$c" -o pmc -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-prof --no-fp32-exact --no-f16 > "$R/gpurun_out/pmcb_$c.log" 2>&1)
+    (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmcb_$c" -o pmc -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-prof --no-fp32-exact --no-f16 --no-c4 > "$R/gpurun_out/pmcb_$c.log" 2>&1)
     echo "pmc $c exit $?"
   done
   python tools/pmc_traffic.py gpurun_out/pmcb_FETCH_SIZE gpurun_out/pmcb_WRITE_SIZE bf16x3 gpurun_out/kernel_traffic.json
@@ -47,15 +47,15 @@ fi
 if has pmc16; then
   echo "== PMC HBM traffic of the MFMA kernels, f16 mode (needs gpurun_out/tuning.json from the bench stage of this visit)"
   for c in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmcf_$c" -o pmc -- python "$R/bench.py" --precision f16 --steps 1 --warmup 0 --no-cpu-baseline --no-prof --no-fp32-exact > "$R/gpurun_out/pmcf_$c.log" 2>&1)
+    (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmcf_$c" -o pmc -- python "$R/bench.py" --precision f16 --steps 1 --warmup 0 --no-cpu-baseline --no-prof --no-fp32-exact --no-c4 > "$R/gpurun_out/pmcf_$c.log" 2>&1)
     echo "pmc f16 $c exit $?"
   done
-  python tools/pmc_traffic.py gpurun_out/pmcf_FETCH_SIZE gpurun_out/pmcf_WRITE_SIZE f16 gpurun_out/kernel_traffic.json "bench.py --precision f16 --steps 1 --warmup 0 --no-prof --no-cpu-baseline --no-fp32-exact (prepare pass + 1 step, tiles pre-seeded)"
+  python tools/pmc_traffic.py gpurun_out/pmcf_FETCH_SIZE gpurun_out/pmcf_WRITE_SIZE f16 gpurun_out/kernel_traffic.json "bench.py --precision f16 --steps 1 --warmup 0 --no-prof --no-cpu-baseline --no-fp32-exact --no-c4 (prepare pass + 1 step, tiles pre-seeded)"
 fi
 if has stats; then
   echo "== rocprofv3 kernel stats (same command as the bench headline)"
   rm -rf gpurun_out/prof
-  (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o fgt -- python "$R/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --no-prof --no-fp32-exact --no-f16 > "$R/gpurun_out/rocprof.log" 2>&1)
+  (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o fgt -- python "$R/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --no-prof --no-fp32-exact --no-f16 --no-c4 > "$R/gpurun_out/rocprof.log" 2>&1)
   echo "rocprof exit: $?"
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" gpurun_out/kernel_stats.csv && cut -c1-170 "$f" | head -22
@@ -82,11 +82,11 @@ if has c5; then
   grep '^{' gpurun_out/bench_c5_1gpu.log | python -c "
 import sys,json; d=json.loads(sys.stdin.read())
 print(d['value'],'fps', d['ms_per_step'],'ms')
-for r in d.get('rooflines',[]): print('  ', r['kind'], r['frac'], r['algorithmic_tflops'],'TF alg', r['kernel_ms_per_step'],'ms/step')
+for r in d.get('rooflines',[]): print('  ', r['kind'], r['frac'], r.get('algorithmic_tflops', r.get('achieved')),r['unit'], r['kernel_ms_per_step'],'ms/step')
 f=d.get('f16')
 if f:
     print('f16', f['value'],'fps', f['ms_per_step'],'ms', f.get('composite_vs_headline'))
-    for r in f.get('rooflines',[]): print('  ', r['kind'], r['frac'], r['algorithmic_tflops'],'TF alg', r['kernel_ms_per_step'],'ms/step')
+    for r in f.get('rooflines',[]): print('  ', r['kind'], r['frac'], r.get('algorithmic_tflops', r.get('achieved')),r['unit'], r['kernel_ms_per_step'],'ms/step')
 "
 fi
 if has flow; then

@@ -45,7 +45,7 @@ def collect(d, counter):
 
 def main():
     fd, wd, prec, out = sys.argv[1:5]
-    note = sys.argv[5] if len(sys.argv) > 5 else "bench.py --steps 1 --warmup 0 --no-prof --no-cpu-baseline --no-fp32-exact (prepare pass + 1 step, tiles pre-seeded)"
+    note = sys.argv[5] if len(sys.argv) > 5 else "bench.py --steps 1 --warmup 0 --no-prof --no-cpu-baseline --no-fp32-exact --no-f16 --no-c4 (prepare pass + 1 step, tiles pre-seeded)"
     F, W = collect(fd, "FETCH_SIZE"), collect(wd, "WRITE_SIZE")
     kinds = defaultdict(lambda: {"launches": 0, "fetch_KiB": 0.0, "write_KiB": 0.0})
     templates = {}
