@@ -61,7 +61,7 @@ if has stats; then
   [ -n "$f" ] && cp "$f" gpurun_out/kernel_stats.csv && cut -c1-170 "$f" | head -22
   echo "== rocprofv3 kernel stats, f16 mode"
   rm -rf gpurun_out/prof_f16
-  (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_f16" -o fgt -- python "$R/bench.py" --precision f16 --steps 2 --warmup 0 --no-cpu-baseline --no-prof --no-fp32-exact > "$R/gpurun_out/rocprof_f16.log" 2>&1)
+  (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_f16" -o fgt -- python "$R/bench.py" --precision f16 --steps 2 --warmup 0 --no-cpu-baseline --no-prof --no-c4 --no-fp32-exact > "$R/gpurun_out/rocprof_f16.log" 2>&1)
   echo "rocprof f16 exit: $?"
   f=$(find gpurun_out/prof_f16 -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" gpurun_out/kernel_stats_f16.csv && cut -c1-170 "$f" | head -12
