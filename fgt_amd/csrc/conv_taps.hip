@@ -81,8 +81,11 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     // mode (p.tr_li != 0: k x 1 convolutions, RAFT's vertical GRU pass): the reused taps are the ky taps and the tile's rows walk the image
     // in (n, x, y) order — row m' = (n, x, y) is pixel n*H*W + y*W + x; every LDS-DMA lane carries its own address, so a column strip costs
     // what a row strip costs, and the epilogue maps m' back to the pixel (conv_out_row).  "inner" = the reused axis, "outer" = the other one.
+    // NEAREST x2 UPSAMPLING (desc.upsample, normal mode only): the tile walks the 2H x 2W output grid, LDS row = output-grid pixel; its source
+    // is input pixel ((y' + dy) >> 1, x' >> 1): adjacent LDS rows fetch the same 64 bytes twice, the taps shift in the output grid as always.
     const bool tr = p.tr_li != 0;
-    const int W = d.W, H = d.H;
+    const int ush = d.upsample ? 1 : 0;
+    const int W = d.W << ush, H = d.H << ush;               // the grid the tile walks (= the output map)
     const int HW = H * W;
     const int Li = tr ? H : W, Lo = tr ? W : H;             // extents
     const int Si = tr ? W : 1, So = tr ? 1 : W;             // pixel strides
@@ -122,6 +125,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     const int lrow = lane >> 2;
     const int kc = (lane & 3) ^ ((lane >> 4) & 3);       // swizzle on the source side
     int a_q[APW], a_y[APW];                              // flattened input pixel of the row for ky*dh - ph = 0, and its y (far negative: never fetched)
+    int a_nb[APW], a_xs[APW];                            // upsampling: image base n*Hin*Win and source column x' >> 1 (a_y is the OUTPUT-grid row)
 #pragma unroll
     for (int it = 0; it < APW; ++it) {
         const int j = wave + it * NW;
@@ -131,13 +135,16 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
         const int co = rem / Li, ci = rem - co * Li;                // outer / inner coordinate
         a_q[it] = valid ? (int)(q - rem) + co * So + ci * Si : 0;   // its pixel
         a_y[it] = valid ? co : -(1 << 30);
+        a_nb[it] = (int)((q - rem) >> (2 * ush));
+        a_xs[it] = ci >> 1;
     }
     const char* const zp = reinterpret_cast<const char*>(p.zero_page);
     auto issue_A = [&](int it, int ab) {
         const int j = wave + it * NW;
         if (j >= NPA) return;                             // (wave-uniform)
         const int plane = j / GA, grp = j % GA;
-        const char* ptr = (plane ? a_lo : a_hi) + 2 * ((long)(a_q[it] + a_dyW) * a_ld + kc * 8);
+        const int pix = ush ? a_nb[it] + ((a_y[it] + a_dy) >> 1) * d.W + a_xs[it] : a_q[it] + a_dyW;
+        const char* ptr = (plane ? a_lo : a_hi) + 2 * ((long)pix * a_ld + kc * 8);
         const bool ok = (unsigned)(a_y[it] + a_dy) < (unsigned)Lo;
         glds16(ok ? ptr : zp, Abuf + ab * A_BYTES + plane * APL + grp * 1024);
     };
@@ -294,7 +301,7 @@ int launch_kw(const ConvP& p, hipStream_t s) {
 template <int BM, int BN, int WM, int WN, int MINW>
 int launch(const ConvP& p, hipStream_t s) {
     ConvP q = p;
-    q.tr_li = p.d.kw == 1 ? p.d.H : 0;                    // k x 1: transposed mode
+    q.tr_li = p.d.kw == 1 ? p.d.H : 0;                    // k x 1: transposed mode (never with upsampling: fgt_conv_taps_eligible)
     switch (q.tr_li ? p.d.kh : p.d.kw) {
         case 3: return launch_kw<BM, BN, WM, WN, MINW, 3>(q, s);
         case 5: return launch_kw<BM, BN, WM, WN, MINW, 5>(q, s);
@@ -306,11 +313,11 @@ int launch(const ConvP& p, hipStream_t s) {
 }  // namespace
 
 // Geometry this kernel serves (decided by the layer alone, never by tuning): bf16x3 on split inputs (planes or interleaved) with interleaved weights,
-// stride 1, no upsample, zero padding, output map = input map ("same"), kw in {3, 5, 7}, (kw - 1) * dw <= 16, Cin/groups a multiple of 32 per source.
+// stride 1, zero padding, output map = input map ("same") or its nearest x2 upsampling, kw in {3, 5, 7}, (kw - 1) * dw <= 16, Cin/groups a multiple of 32 per source.
 bool fgt_conv_taps_eligible(const ConvP& p) {
     const fgt_conv_desc& d = p.d;
-    return d.precision == FGT_PREC_BF16X3 && (d.in_split == 1 || d.in_split == 2) && (d.w_il == 1 || d.w_il == 2) && d.sh == 1 && d.sw == 1 && !d.upsample && d.pad_mode == 0 &&
-           d.in_relu == 0 && d.Ho == d.H && d.Wo == d.W && p.Cg0 % 32 == 0 && p.Cg1 % 32 == 0 &&
+    return d.precision == FGT_PREC_BF16X3 && (d.in_split == 1 || d.in_split == 2) && (d.w_il == 1 || d.w_il == 2) && d.sh == 1 && d.sw == 1 && d.pad_mode == 0 &&
+           d.in_relu == 0 && d.Ho == (d.H << (d.upsample ? 1 : 0)) && d.Wo == (d.W << (d.upsample ? 1 : 0)) && (!d.upsample || d.kw > 1) && p.Cg0 % 32 == 0 && p.Cg1 % 32 == 0 &&
            (((d.kw == 3 || d.kw == 5 || d.kw == 7) && (d.kw - 1) * d.dw <= HALO) ||                        // kx taps reused
             (d.kw == 1 && (d.kh == 3 || d.kh == 5 || d.kh == 7) && (d.kh - 1) * d.dh <= HALO)) &&           // k x 1: ky taps reused (transposed tile order)
            d.Kpad == p.K && p.Cout_g > 4;

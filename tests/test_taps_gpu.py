@@ -125,6 +125,36 @@ def test_taps_epilogues_and_split_outputs(dev):
     assert torch.equal(wide.data[:, :, 128:], full.data.view(2, rows, 128)) and float(wide.data[:, :, :128].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("il", [False, True], ids=["planes", "interleaved"])
+def test_taps_nearest_upsampling(il, dev):
+    """desc.upsample (nearest x2 ahead of the conv: FGT's decoder, LAFC's decoder): the tile walks the output grid, LDS rows fetch input
+    pixel ((y' + dy) >> 1, x' >> 1).  Two sources (LAFC concatenates the skip), odd sizes, an image boundary inside a tile."""
+    from fgt_amd import ops
+    for (N, H, W, C0, C1, Cout) in ((3, 9, 13, 64, 0, 64), (2, 15, 27, 96, 96, 48), (1, 30, 54, 128, 0, 200)):
+        x = _rand(N, H, W, C0, seed=1).to(dev)
+        x1 = _rand(N, H, W, C1, seed=2).to(dev) if C1 else None
+        w, b = _rand(Cout, C0 + C1, 3, 3, seed=3, scale=1.0 / math.sqrt(9 * (C0 + C1))), _rand(Cout, seed=4)
+        pc = ops.PackedConv(w.to(dev), b.to(dev))
+        xs, x1s = ops.split(x, interleave=il), (ops.split(x1, interleave=il) if C1 else None)
+        xd = xs.float().double() if C1 == 0 else torch.cat([xs.float().double(), x1s.float().double()], -1)
+        up = F.interpolate(xd.permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+        wh = w.to(dev).to(torch.bfloat16)
+        wd = (wh.float() + (w.to(dev) - wh.float()).to(torch.bfloat16).float()).double()
+        ref = F.leaky_relu(F.conv2d(up, wd, b.to(dev).double(), 1, 1), 0.2).permute(0, 2, 3, 1)
+        other = ops.conv2d(xs, pc, x1=x1s, pad=1, upsample=True, act="lrelu", tile="128x128", precision="bf16x3")
+        e_other, scale = (other.double() - ref).abs().max().item(), ref.abs().max().item()
+        first = None
+        for t in [t for t in TAPS if not t.endswith("r")]:
+            got = ops.conv2d(xs, pc, x1=x1s, pad=1, upsample=True, act="lrelu", tile=t, precision="bf16x3")
+            torch.cuda.synchronize()
+            e = (got.double() - ref).abs().max().item()
+            assert e <= max(2.0 * e_other, 2e-6 * scale) and e <= 2e-5 * scale, f"{t}: {e:.3e} vs other kernels {e_other:.3e} (scale {scale:.2e})"
+            first = got if first is None else first
+            assert torch.equal(got, first), t
+        assert torch.equal(ops.conv2d(xs, pc, x1=x1s, pad=1, upsample=True, act="lrelu", precision="bf16x3"), first)      # tile = auto: routed
+        print(f"[parity] conv_taps upsample x2 {N}x{H}x{W} {C0}+{C1}->{Cout} ({'interleaved' if il else 'planes'}): max |taps - fp64| {e:.2e}, |conv_split - fp64| {e_other:.2e}")
+
+
 def test_taps_routing_is_geometry_only(dev):
     from fgt_amd import ops
     xf = _rand(1, 16, 20, 64, seed=1).to(dev)
@@ -132,9 +162,9 @@ def test_taps_routing_is_geometry_only(dev):
     pc = ops.PackedConv(_rand(64, 64, 3, 3, seed=2, scale=0.05).to(dev), None)
     base = ops.conv2d(x, pc, pad=1, precision="bf16x3")                               # tile = auto on an eligible layer: the tap kernel
     assert torch.equal(base, ops.conv2d(x, pc, pad=1, precision="bf16x3", tile="128x128x8t"))
-    # not served: stride 2, upsample, replicate padding, "valid" padding, Cin / groups not a multiple of 32, fp32 inputs — all run on the
+    # not served: stride 2, replicate padding, "valid" padding, Cin / groups not a multiple of 32, fp32 inputs — all run on the
     # other kernels, bit-identical to the register-staged bf16x3 kernel on fp32 inputs
-    for kw in (dict(stride=2, pad=1), dict(pad=1, upsample=True), dict(pad=1, pad_mode="replicate"), dict(pad=0)):
+    for kw in (dict(stride=2, pad=1), dict(pad=1, pad_mode="replicate"), dict(pad=0)):
         a = ops.conv2d(x, pc, precision="bf16x3", **kw)
         assert torch.equal(a, ops.conv2d(xf, pc, precision="bf16x3", tile="128x128", **kw)), kw
     x40 = _rand(1, 16, 20, 40, seed=3).to(dev)

@@ -18,6 +18,7 @@ LAYERS = {  # name: (N, H, W, C0, C1, Cout, groups, k, stride, pad)
     "enc8  256->384 3x3": (17, 60, 108, 256, 0, 384, 1, 3, 1, 1),
     "enc10 640->512 g2": (17, 60, 108, 256, 384, 512, 2, 3, 1, 1),
     "enc12 640->256 g8": (17, 60, 108, 256, 384, 256, 8, 3, 1, 1),
+    "e20 enc11 768->384 g4": (20, 60, 108, 256, 512, 384, 4, 3, 1, 1),
     "enc4  64->128 s2": (17, 120, 216, 64, 0, 128, 1, 3, 2, 1),
     "dec   128->128 120x216": (17, 120, 216, 128, 0, 128, 1, 3, 1, 1),
     "dec   64->64 240x432/2": (8, 240, 432, 64, 0, 64, 1, 3, 1, 1),
@@ -52,6 +53,11 @@ LAYERS = {  # name: (N, H, W, C0, C1, Cout, groups, k, stride, pad)
     # LAFC, 8 pivots x 3 flows
     "lafc 96->96 3x3 120x216": (24, 120, 216, 96, 0, 96, 1, 3, 1, 1),
     "lafc 192->192 3x3 60x108": (24, 60, 108, 192, 0, 192, 1, 3, 1, 1),
+    # nearest x2 upsampling ahead of the conv (" up" in the name): FGT decoder, LAFC decoder
+    "dec up 128->128 60x108": (20, 60, 108, 128, 0, 128, 1, 3, 1, 1),
+    "dec up 64->64 120x216": (8, 120, 216, 64, 0, 64, 1, 3, 1, 1),
+    "lafc up 96+96->48 120x216": (8, 120, 216, 96, 96, 48, 1, 3, 1, 1),
+    "lafc up 192+192->96 60x108": (8, 60, 108, 192, 192, 96, 1, 3, 1, 1),
     # LAFC P3D temporal convs: 3 x 1 over (T = 3, H*W)
     "lafc p3d 96 3x1 T": (8, 3, 25920, 96, 0, 96, 1, (3, 1), 1, (1, 0)),
     "lafc p3d 192 3x1 T": (8, 3, 6480, 192, 0, 192, 1, (3, 1), 1, (1, 0)),
@@ -88,6 +94,7 @@ def main():
     for name, (N, H, W, C0, C1, Cout, g, k, s, p) in LAYERS.items():
         if a.layers and not any(x in name for x in a.layers.split(",")):
             continue
+        up = " up " in name
         x = torch.randn(N, H, W, C0, device=dev)
         x1 = torch.randn(N, H, W, C1, device=dev) if C1 else None
         kh_, kw_ = (k, k) if isinstance(k, int) else k
@@ -96,23 +103,23 @@ def main():
         xs, x1s = ops.split(x), (ops.split(x1) if C1 else None)
         can_il = (C0 // g) % 32 == 0 and (C1 // g) % 32 == 0
         xi, x1i = (ops.split(x, interleave=True), (ops.split(x1, interleave=True) if C1 else None)) if can_il else (None, None)
-        out = ops.conv2d(x, pc, x1=x1, stride=s, pad=p, act="lrelu", tile="128x128", precision="bf16x3")
+        out = ops.conv2d(x, pc, x1=x1, stride=s, pad=p, upsample=up, act="lrelu", tile="128x128", precision="bf16x3")
         fl = 2.0 * (out.numel() // Cout) * (Cout // g) * pc.K * g
         cells = []
         for t in TILES:
             o1, o2 = torch.empty_like(out), torch.empty_like(out)
             if t.endswith(("s3", "s4", "pp", "il", "p8", "p8n", "p8l", "ea", "lw", "xy", "w", "t")) or t.startswith("x2") or a.split_only:        # split inputs only
-                ops.conv2d(x, pc, x1=x1, stride=s, pad=p, act="lrelu", tile="128x128", precision="bf16x3", out=o1)
+                ops.conv2d(x, pc, x1=x1, stride=s, pad=p, upsample=up, act="lrelu", tile="128x128", precision="bf16x3", out=o1)
                 ms_a = float("inf")
             else:
-                ms_a = bench(lambda: ops.conv2d(x, pc, x1=x1, stride=s, pad=p, act="lrelu", tile=t, precision="bf16x3", out=o1), a.reps)
+                ms_a = bench(lambda: ops.conv2d(x, pc, x1=x1, stride=s, pad=p, upsample=up, act="lrelu", tile=t, precision="bf16x3", out=o1), a.reps)
             wide = t.endswith("w")                 # wide LDS image (csrc/conv_wide.hip): interleaved inputs only
             if wide:
                 ms_b = float("inf")
                 o2.copy_(o1)
             else:
                 try:
-                    ms_b = bench(lambda: ops.conv2d(xs, pc, x1=x1s, stride=s, pad=p, act="lrelu", tile=t, precision="bf16x3", out=o2), a.reps)
+                    ms_b = bench(lambda: ops.conv2d(xs, pc, x1=x1s, stride=s, pad=p, upsample=up, act="lrelu", tile=t, precision="bf16x3", out=o2), a.reps)
                 except RuntimeError as e:                                              # e.g. a tap-reusing tile on a layer that kernel does not serve
                     if "does not serve" not in str(e):
                         raise
@@ -121,7 +128,7 @@ def main():
             ms_c = float("inf")
             if can_il and (wide or not a.split_only):
                 o3 = torch.empty_like(out)
-                ms_c = bench(lambda: ops.conv2d(xi, pc, x1=x1i, stride=s, pad=p, act="lrelu", tile=t, precision="bf16x3", out=o3), a.reps)
+                ms_c = bench(lambda: ops.conv2d(xi, pc, x1=x1i, stride=s, pad=p, upsample=up, act="lrelu", tile=t, precision="bf16x3", out=o3), a.reps)
                 o2 = o2 if torch.equal(o2, o3) else o2 + 1
             if torch.equal(o1, o2) and torch.equal(o1, out):
                 eq = ""
