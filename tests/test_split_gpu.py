@@ -371,8 +371,8 @@ def test_fgt_forward_bit_equal_with_interleaved_split_tensors(dev, monkeypatch):
     real = ops.conv2d
 
     def forced(x, pc, *a, **kw):
-        # (3x3 / stride-1 layers are routed to the tap-reusing kernel by geometry in both layouts: not forced)
-        tap_routed = pc.kw >= 3 and kw.get("stride", 1) == 1 and not kw.get("upsample") and kw.get("pad_mode", "zeros") == "zeros"
+        # (3x3 / stride-1 layers, with or without nearest upsampling, are routed to the tap-reusing kernel by geometry in both layouts: not forced)
+        tap_routed = pc.kw >= 3 and kw.get("stride", 1) == 1 and kw.get("pad_mode", "zeros") == "zeros"
         if isinstance(x, ops.Split) and x.il and kw.get("tile") is None and pc.Cout // pc.groups > 4 and not tap_routed:
             kw["tile"] = "128x128x8eaw"
         return real(x, pc, *a, **kw)
