@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     const int lrow = lane >> 2;
     const int kc = (lane & 3) ^ ((lane >> 4) & 3);       // swizzle on the source side
     int a_q[APW], a_y[APW];                              // flattened input pixel of the row for ky*dh - ph = 0, and its y (far negative: never fetched)
-    int a_nb[APW], a_xs[APW];                            // upsampling: image base n*Hin*Win and source column x' >> 1 (a_y is the OUTPUT-grid row)
+    // (upsampling: a_q = n*Hin*Win + (x' >> 1), the source pixel of output-grid row 0 of that column; a_y is the OUTPUT-grid row)
 #pragma unroll
     for (int it = 0; it < APW; ++it) {
         const int j = wave + it * NW;
@@ -133,17 +133,15 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
         const bool valid = j < NPA && q >= 0 && q < (long)d.N * HW;
         const int rem = valid ? (int)(q % HW) : 0;
         const int co = rem / Li, ci = rem - co * Li;                // outer / inner coordinate
-        a_q[it] = valid ? (int)(q - rem) + co * So + ci * Si : 0;   // its pixel
+        a_q[it] = !valid ? 0 : ush ? (int)((q - rem) >> 2) + (ci >> 1) : (int)(q - rem) + co * So + ci * Si;   // its pixel
         a_y[it] = valid ? co : -(1 << 30);
-        a_nb[it] = (int)((q - rem) >> (2 * ush));
-        a_xs[it] = ci >> 1;
     }
     const char* const zp = reinterpret_cast<const char*>(p.zero_page);
     auto issue_A = [&](int it, int ab) {
         const int j = wave + it * NW;
         if (j >= NPA) return;                             // (wave-uniform)
         const int plane = j / GA, grp = j % GA;
-        const int pix = ush ? a_nb[it] + ((a_y[it] + a_dy) >> 1) * d.W + a_xs[it] : a_q[it] + a_dyW;
+        const int pix = a_q[it] + (ush ? ((a_y[it] + a_dy) >> 1) * d.W : a_dyW);
         const char* ptr = (plane ? a_lo : a_hi) + 2 * ((long)pix * a_ld + kc * 8);
         const bool ok = (unsigned)(a_y[it] + a_dy) < (unsigned)Lo;
         glds16(ok ? ptr : zp, Abuf + ab * A_BYTES + plane * APL + grp * 1024);

@@ -112,12 +112,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         constexpr int AUX = decltype(auxc)::value;
         // loads of UN row groups in flight together (the 128-accumulator-register tiles have little room: 2 at a time)
         // (two aux operands, each held for two groups: 2 rows at a time as well)
-        constexpr int UN = (TM * TN >= 8 || AUX == 2) ? 2 : ITER;
+        constexpr int UN = (TM * TN >= 8 || TM * TN == 1 || AUX == 2) ? 2 : ITER;      // (one accumulator tile per wavefront: the <= 85-register tiles)
         constexpr int GPB = ITER / UN, NG = TM * GPB;                  // row groups per 32-row block, per wavefront
         // Aux operands are requested ONE GROUP AHEAD, in front of the previous group's stores: the wait for a group's operands then covers
         // the loads older than those stores, not the stores (same counter, in order) — otherwise every group would wait for the write
         // acknowledgements of the group before it.
-        float4 ax1[2][UN], ax2[2][UN];
+        // (not in the one-accumulator-tile kernels, which run at <= 85 registers: there a group's operands are requested right before use)
+        constexpr bool AHEAD = TM * TN > 1;
+        float4 ax1[AHEAD ? 2 : 1][UN], ax2[AHEAD ? 2 : 1][UN];
         auto load_aux = [&](auto gc, float4 (&a1)[UN], float4 (&a2)[UN]) {
             constexpr int gi = decltype(gc)::value, i = gi / GPB, c0 = (gi % GPB) * UN;
 #pragma unroll
@@ -130,7 +132,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 if constexpr (AUX >= 2) a2[u0] = *reinterpret_cast<const float4*>(okk ? p.aux2 + (long)m * d.ld_aux2 + co : p.zero_page);
             }
         };
-        if constexpr (AUX >= 1) load_aux(std::integral_constant<int, 0>{}, ax1[0], ax2[0]);
+        if constexpr (AUX >= 1 && AHEAD) load_aux(std::integral_constant<int, 0>{}, ax1[0], ax2[0]);
         static_for<NG>([&](auto gc) {
             constexpr int gi = decltype(gc)::value, i = gi / GPB, c0 = (gi % GPB) * UN;
             if constexpr (gi % GPB == 0) {
@@ -141,7 +143,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 __builtin_amdgcn_wave_barrier();                       // the patch is exchanged between lanes of this wavefront only
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            if constexpr (AUX >= 1 && gi + 1 < NG) load_aux(std::integral_constant<int, gi + 1>{}, ax1[(gi + 1) & 1], ax2[(gi + 1) & 1]);
+            if constexpr (AUX >= 1 && AHEAD && gi + 1 < NG) load_aux(std::integral_constant<int, gi + 1>{}, ax1[(gi + 1) & 1], ax2[(gi + 1) & 1]);
+            if constexpr (AUX >= 1 && !AHEAD) load_aux(gc, ax1[0], ax2[0]);
+            constexpr int ab = AHEAD ? (gi & 1) : 0;
             const int mrow = bm0 + wm * WTM + i * 32 + r0;
             float4 cv[UN];
             bool ok[UN];
@@ -156,8 +160,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 const int m = conv_out_row(p, mrow + (c0 + u0) * RPI);
                 float v[4] = {cv[u0].x * sc.x + bi.x, cv[u0].y * sc.y + bi.y, cv[u0].z * sc.z + bi.z, cv[u0].w * sc.w + bi.w};
                 float x1[4] = {0.f, 0.f, 0.f, 0.f}, x2[4] = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (AUX >= 1) { const float4 t = ax1[gi & 1][u0]; x1[0] = t.x; x1[1] = t.y; x1[2] = t.z; x1[3] = t.w; }
-                if constexpr (AUX >= 2) { const float4 t = ax2[gi & 1][u0]; x2[0] = t.x; x2[1] = t.y; x2[2] = t.z; x2[3] = t.w; }
+                if constexpr (AUX >= 1) { const float4 t = ax1[ab][u0]; x1[0] = t.x; x1[1] = t.y; x1[2] = t.z; x1[3] = t.w; }
+                if constexpr (AUX >= 2) { const float4 t = ax2[ab][u0]; x2[0] = t.x; x2[1] = t.y; x2[2] = t.z; x2[3] = t.w; }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     float x = fgt_act(v[u], d.act, d.slope) * d.out_scale;

@@ -409,8 +409,10 @@ int fgt_conv_wide_launch(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_128x128x8_EA: return launch<128, 128, 2, 4, 4, 1>(p, s);
         case FGT_TILE_256x128x16_EA: return launch<256, 128, 4, 4, 4, 1>(p, s);
         case FGT_TILE_256x64x8_EA: return launch<256, 64, 4, 2, 2, 1>(p, s);
+#ifdef FGT_DIAG      // the 8-phase schedule: measured = the early-release tiles on long-K layers, slower on K = 512 GEMMs; never selected by the autotuner
         case FGT_TILE_256x256_P8: return launch<256, 256, 2, 4, 2, 2>(p, s);       // one workgroup per CU (128 KB of stages)
         case FGT_TILE_256x128_P8: return launch<256, 128, 4, 2, 2, 2>(p, s);
+#endif
         default: fgt_set_error("fgt_conv2d: tile %d is not built for the wide (interleaved) bf16x3 kernel", tile + 100); return FGT_EINVAL;
     }
 }

@@ -29,9 +29,7 @@ TILE_CANDIDATES = ("128x128", "64x64", "128x64", "256x128", "128x32", "128x128x8
                    "128x128ea", "64x64ea", "128x64ea", "128x128x8ea", "256x128x16ea", "256x64x8ea",
                    # fp16 kernel only (csrc/conv_f16.hip): one more early-release tile, and every tile on the wide LDS image
                    "256x128ea", "128x128w", "64x64w", "128x64w", "256x128w", "128x32w", "128x128x8w", "256x128x16w", "256x64x8w",
-                   "128x128eaw", "64x64eaw", "128x64eaw", "128x128x8eaw", "256x128x16eaw", "256x64x8eaw", "256x128eaw",
-                   # bf16x3 on interleaved inputs only (csrc/conv_wide.hip): the 8-phase schedule on 256-row tiles
-                   "256x256p8w", "256x128p8w")
+                   "128x128eaw", "64x64eaw", "128x64eaw", "128x128x8eaw", "256x128x16eaw", "256x64x8eaw", "256x128eaw")
 # Layers that fgt_conv2d routes to the tap-reusing kernel (csrc/conv_taps.hip; decided by geometry: fgt_conv_taps_route) are tuned among ITS
 # tiles only — they are bit-identical to each other, so results never depend on tuning.
 TAPS_CANDIDATES = ("128x128x8t", "128x128t", "128x64t", "128x64x8t", "64x64t")

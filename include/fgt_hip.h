@@ -142,7 +142,7 @@ typedef struct fgt_conv_desc {
 #define FGT_TILE_128x128x8_PP 14  /* split inputs only: 128x128, 4-stage ring, ping-pong */
 /* 15: retired (256x256 on 8 wavefronts of 128x64 with the interleaved schedule: 220 VGPRs, +0...5 % on N >= 512 GEMMs, slower epilogue) */
 #define FGT_TILE_256x128x8_IL 16  /* split inputs only: 256x128 on 8 wavefronts of 64x64, interleaved schedule */
-#define FGT_TILE_256x256_P8 17    /* split inputs only: 256x256 on 8 wavefronts of 128x64, 8-phase schedule: two staggered wavefront
+#define FGT_TILE_256x256_P8 17    /* DIAGNOSTIC BUILDS ONLY; split inputs only: 256x256 on 8 wavefronts of 128x64, 8-phase schedule: two staggered wavefront
                                    * groups (one loads / issues LDS-DMA while the other owns the matrix pipe), counted vmcnt, s_setprio */
 #define FGT_TILE_256x128_P8 18    /* split inputs only: the same schedule on a 256x128 tile (8 wavefronts of 64x64) */
 #define FGT_TILE_128x128_EA 26    /* split inputs only: tiles 1, 2, 3, 6, 7, 8 with EARLY STAGE RELEASE — an extra barrier after the fragment reads frees */

@@ -214,8 +214,11 @@ def test_conv_interleaved_two_source_and_out_il(dev):
 
 
 # ---- wide LDS image (csrc/conv_wide.hip): interleaved inputs + interleaved weights, 8-row x 128-byte LDS-DMA pieces, 8-phase tiles
+from fgt_amd import _lib as _fgt_lib
+
+P8_TILES = ["256x256p8w", "256x128p8w"] if "diag" in _fgt_lib.LIB_PATH else []      # the 8-phase schedule exists in diagnostic builds only
 WIDE_TILES = ["128x128w", "128x64w", "64x64w", "128x32w", "256x128w", "128x128x8w", "256x128x16w", "256x64x8w", "128x128eaw", "128x64eaw", "64x64eaw",
-              "128x128x8eaw", "256x128x16eaw", "256x64x8eaw", "256x128eaw", "256x256p8w", "256x128p8w"]
+              "128x128x8eaw", "256x128x16eaw", "256x64x8eaw", "256x128eaw"] + P8_TILES
 WIDE_CASES = IL_CASES + [
     ("3x3_cin256_cout384", 1, 20, 36, 256, 384, 3, 1, 1, 1, 1),      # several K-steps per tap, N tile past Npad for the 256-wide tiles
     ("1x1_k768_rows_not_tile_multiple", 1, 1, 1111, 768, 512, 1, 1, 0, 1, 1),
@@ -249,7 +252,7 @@ def test_conv_wide_two_source_upsample_replicate_out_il(dev):
         w, b = _rand(cout, 640 // g, 3, 3, seed=3, scale=0.05), _rand(cout, seed=4)
         pc = ops.PackedConv(w.to(dev), b.to(dev), groups=g)
         ref = ops.conv2d(x0, pc, x1=o, stride=1, pad=1, act="lrelu", precision="bf16x3")
-        for tile in ("128x128x8eaw", "64x64w", "256x256p8w", "256x128p8w", "128x128w"):
+        for tile in ["128x128x8eaw", "64x64w", "128x128w"] + P8_TILES:
             r32, rs = ops.conv2d(ops.split(x0, interleave=True), pc, x1=ops.split(o, interleave=True), stride=1, pad=1, act="lrelu",
                                  precision="bf16x3", tile=tile, out_split="both", out_il=True)
             assert torch.equal(r32, ref), (g, tile)
@@ -259,7 +262,7 @@ def test_conv_wide_two_source_upsample_replicate_out_il(dev):
     pc2 = ops.PackedConv(w2.to(dev), b2.to(dev))
     for kw in (dict(upsample=True, pad=1), dict(pad=2, pad_mode="replicate", dil=2), dict(stride=2, pad=1)):
         ref = ops.conv2d(x, pc2, precision="bf16x3", **kw)
-        for tile in ("64x64eaw", "128x64w", "256x128p8w"):
+        for tile in ["64x64eaw", "128x64w"] + P8_TILES[1:]:
             assert torch.equal(ops.conv2d(ops.split(x, interleave=True), pc2, precision="bf16x3", tile=tile, **kw), ref), (kw, tile)
     with pytest.raises(RuntimeError, match="not built|unknown tile|wide"):
         ops.conv2d(ops.split(x), pc2, pad=1, precision="bf16x3", tile="128x128w")         # planes input on a wide tile
