@@ -252,7 +252,9 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
             const bool more = kt + 2 < p.nk;
             if (more) issue_tile(slot);
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);                // (the MFMA block ahead of the other wavefronts' address arithmetic: +1...2 %, same-box A/B)
             mfmas(ah, al, bh, bl);
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (more) wait_vmcnt<DPT>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();

@@ -251,6 +251,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
             const bool more = !crosses || !last;
             if (more) { issue_B(bs); advance_B((kx + 2) % KW == KW - 1); }
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);                // (the MFMA block ahead of the other wavefronts' address arithmetic: +1...2 %, same-box A/B)
             // same products as conv_split.hip (lo*hi, hi*lo, hi*hi per k-half)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -267,6 +268,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             // everything older than this step's B pieces has landed: the B tile of the next step and (requested ahead of them) this step's A rows
             if (more) wait_vmcnt<B_IT>(); else wait_vmcnt<0>();
