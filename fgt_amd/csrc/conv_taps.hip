@@ -45,6 +45,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <int BASE, int MAXA> __device__ __forceinline__ void wait_vmcnt_plus(int na) {     // vmcnt(BASE + na), na wave-uniform in [0, MAXA]
+    if constexpr (MAXA == 0) wait_vmcnt<BASE>();
+    else {
+        if (na == MAXA) wait_vmcnt<BASE + MAXA>();
+        else wait_vmcnt_plus<BASE, MAXA - 1>(na);
+    }
+}
+
 constexpr int HALO = 16;          // extra A rows per (ky, chunk): (kw - 1) * dw <= 16
 
 template <int BM, int BN, int WM, int WN, int MINW, int KW>
@@ -61,6 +69,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     constexpr int STAGE = LDS_BYTES / 8;                 // floats in half of the LDS (the epilogue's view of its scratch)
     constexpr int APW = (NPA + NW - 1) / NW;             // A pieces a wavefront owns per (ky, chunk)
     constexpr int ASTEPS = KW - 1;                       // they go out in steps 0 .. KW-2 of the previous super-step (piece it in step it % ASTEPS)
+    constexpr bool A_LATE = NW >= 8;                     // A pieces behind the B pieces of their step, waited for one step later
     static_assert(AR % 16 == 0 && (2 * GB) % NW == 0 && B_IT >= 1 && TM >= 1 && TN >= 1 && BN <= 128 && KW >= 3, "tile / wavefront geometry");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -139,12 +148,13 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     const char* const zp = reinterpret_cast<const char*>(p.zero_page);
     auto issue_A = [&](int it, int ab) {
         const int j = wave + it * NW;
-        if (j >= NPA) return;                             // (wave-uniform)
+        if (j >= NPA) return 0;                           // (wave-uniform)
         const int plane = j / GA, grp = j % GA;
         const int pix = a_q[it] + (ush ? ((a_y[it] + a_dy) >> 1) * d.W : a_dyW);
         const char* ptr = (plane ? a_lo : a_hi) + 2 * ((long)pix * a_ld + kc * 8);
         const bool ok = (unsigned)(a_y[it] + a_dy) < (unsigned)Lo;
         glds16(ok ? ptr : zp, Abuf + ab * A_BYTES + plane * APL + grp * 1024);
+        return 1;
     };
 
     // ---- weights: interleaved rows [Kpad/32][hi 32 | lo 32] (128 bytes per K-step of 32 channels); running pointers, K-step order
@@ -240,16 +250,23 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();                 // every wavefront holds its fragments: the B stage can be refilled
+            constexpr bool crosses = kx + 2 >= KW;        // the step two ahead belongs to the next super-step
+            const bool more = !crosses || !last;
+            // Request order.  8-wavefront tiles: B first, then the A pieces, which may stay in flight across this step's end (two steps to
+            // land: they come from the Infinity Cache / HBM, the weights from L2); 4-wavefront tiles: A pieces first, landed with this step
+            // (same-box A/B: +3 % on the 128x128 tile on 8 wavefronts, -2 % on the 128x64 tile on 4).
+            int na = 0;
+            if constexpr (A_LATE)
+                if (more) { issue_B(bs); advance_B((kx + 2) % KW == KW - 1); }
             if constexpr (kx < ASTEPS) {
                 if (!last) {
 #pragma unroll
                     for (int it = 0; it < APW; ++it)
-                        if (it % ASTEPS == kx) issue_A(it, (ss + 1) & 1);
+                        if (it % ASTEPS == kx) na += issue_A(it, (ss + 1) & 1);
                 }
             }
-            constexpr bool crosses = kx + 2 >= KW;        // the step two ahead belongs to the next super-step
-            const bool more = !crosses || !last;
-            if (more) { issue_B(bs); advance_B((kx + 2) % KW == KW - 1); }
+            if constexpr (!A_LATE)
+                if (more) { issue_B(bs); advance_B((kx + 2) % KW == KW - 1); }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);                // (the MFMA block ahead of the other wavefronts' address arithmetic: +1...2 %, same-box A/B)
             // same products as conv_split.hip (lo*hi, hi*lo, hi*hi per k-half)
@@ -270,8 +287,13 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            // everything older than this step's B pieces has landed: the B tile of the next step and (requested ahead of them) this step's A rows
-            if (more) wait_vmcnt<B_IT>(); else wait_vmcnt<0>();
+            if constexpr (A_LATE) {
+                // everything older than this step's requests has landed (the A pieces of the step before, the next step's B tile)
+                constexpr int MAXA = kx < ASTEPS ? (APW + ASTEPS - 1 - kx) / ASTEPS : 0;
+                if (more) wait_vmcnt_plus<B_IT, MAXA>(na); else wait_vmcnt_plus<0, MAXA>(na);
+            } else {
+                if (more) wait_vmcnt<B_IT>(); else wait_vmcnt<0>();
+            }
             __builtin_amdgcn_s_barrier();
             bs ^= 1;
         });
