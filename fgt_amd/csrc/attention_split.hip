@@ -47,6 +47,7 @@ struct AttnS {
     long psq, psk, psv, psgk, psgv;
     int n_q, n_k, zh, zw, gh, gw, n_loc;
     float scale_log2e;
+    int gx, gy, per_xcd;                  // work grid (query blocks x problems) and, with the XCD-aware order, work items per XCD (else 0)
 };
 
 
@@ -139,9 +140,19 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
 
+    // Work item of this workgroup.  Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2); with the XCD-aware order every
+    // XCD walks a CONTIGUOUS range of (problem, query block) items, so the query blocks of a problem — which stream the same K / V tiles at about
+    // the same time — share one L2 instead of fetching the tiles into all eight.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.per_xcd) {
+        const int w = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+        if (w >= p.gx * p.gy) return;
+        by = w / p.gx;
+        bx = w - by * p.gx;
+    }
     Prob pr;
     {
-        int y = blockIdx.y;
+        int y = by;
         pr.hd = y % d.heads; y /= d.heads;
         if (d.mode == 0) {
             pr.zj = y % d.group; y /= d.group;
@@ -236,7 +247,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     };
 
     // ---- Q rows into registers, already split: step s holds d = 16s + 8h + (0..7) of the hi and the lo plane
-    const int qi = blockIdx.x * (NW * 32) + wave * 32 + l31;
+    const int qi = bx * (NW * 32) + wave * 32 + l31;
     const int qpix = local_pix(p, pr, min(qi, p.n_q - 1));
     bf16x8 qh[8], ql[H ? 1 : 8];
     {
@@ -491,6 +502,14 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     }
 }
 
+// FGT_ATTN_XCD=0: plain (query block, problem) grid (A/B measurements)
+dim3 attn_grid(AttnS& q, int gx, int gy) {
+    static const int xcd = [] { const char* e = getenv("FGT_ATTN_XCD"); return e ? atoi(e) : 1; }();
+    q.gx = gx; q.gy = gy;
+    q.per_xcd = (xcd && gx > 1) ? cdiv(gx * gy, 8) : 0;
+    return q.per_xcd ? dim3(8 * q.per_xcd) : dim3(gx, gy);
+}
+
 template <int NW, bool H, bool TEMPORAL>
 int launch_mode(const AttnS& p, int problems, hipStream_t s) {
     constexpr int NS = NW == 8 ? 4 : 2;          // long zones (one workgroup per CU): four stages = three tiles in flight
@@ -498,8 +517,9 @@ int launch_mode(const AttnS& p, int problems, hipStream_t s) {
     static_assert(smem <= 160 * 1024, "LDS ring does not fit");
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<NW, H, TEMPORAL, NS>), smem, lds_set, "attn_split")) return rc;
-    dim3 grid(cdiv(p.n_q, NW * 32), problems);
-    hipLaunchKernelGGL((attn_split_kernel<NW, H, TEMPORAL, NS>), grid, dim3(NW * 64), smem, s, p);
+    AttnS q = p;
+    const dim3 grid = attn_grid(q, cdiv(p.n_q, NW * 32), problems);
+    hipLaunchKernelGGL((attn_split_kernel<NW, H, TEMPORAL, NS>), grid, dim3(NW * 64), smem, s, q);
     return fgt_check_launch("attn_split_kernel");
 }
 
@@ -508,8 +528,9 @@ int launch_prefetch(const AttnS& p, int problems, hipStream_t s) {
     constexpr int smem = 4 * 2 * PLANE;
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<8, true, true, 4, true>), smem, lds_set, "attn_split")) return rc;
-    dim3 grid(cdiv(p.n_q, 8 * 32), problems);
-    hipLaunchKernelGGL((attn_split_kernel<8, true, true, 4, true>), grid, dim3(8 * 64), smem, s, p);
+    AttnS q = p;
+    const dim3 grid = attn_grid(q, cdiv(p.n_q, 8 * 32), problems);
+    hipLaunchKernelGGL((attn_split_kernel<8, true, true, 4, true>), grid, dim3(8 * 64), smem, s, q);
     return fgt_check_launch("attn_split_kernel");
 }
 
