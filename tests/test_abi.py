@@ -87,6 +87,22 @@ def test_autotune_alias_guard():
     assert ops._aliases(c, None, d)
 
 
+def test_tile_tables_agree_with_the_header():
+    """Every tile name the autotuner may pick maps to a code the header defines (FGT_TILE_* [+ 100 wide, + 200 tap-reusing]); the tap-reusing
+    kernel's candidates are its own family only — its accumulation order differs, so tuning must never cross families."""
+    import re
+    from fgt_amd import _lib, ops
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "fgt_hip.h")).read()
+    base = {int(v) for v in re.findall(r"#define FGT_TILE_\w+ (\d+)\b", hdr)}
+    for name in ops.TILE_CANDIDATES:
+        code = _lib.TILE[name]
+        assert code < 200 and (code % 100) in base, name
+    for name in ops.TAPS_CANDIDATES:
+        code = _lib.TILE[name]
+        assert 200 <= code < 300 and (code - 200) in base and name.endswith("t"), name
+    assert not set(ops.TILE_CANDIDATES) & set(ops.TAPS_CANDIDATES)
+
+
 def test_entry_build_runs_here():
     """__graft_entry__.build(): what the driver runs on the CPU box every round (compile for gfx950, import, ABI version)."""
     import subprocess
