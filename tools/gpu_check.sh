@@ -73,7 +73,7 @@ fi
 if has rehearse; then
   echo "== 2-rank rehearsal of bench.py on this single GPU (gloo, collectives staged through the host): strong headline + weak side object"
   FGT_BENCH_SHARE_GPU=1 FGT_BENCH_BACKEND=gloo FGT_TUNING_FILE="$PWD/gpurun_out/tuning.json" timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
-    --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --no-prof > gpurun_out/bench_2rank_rehearsal.log 2>&1
+    --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-c4 --no-f16 --no-fp32-exact > gpurun_out/bench_2rank_rehearsal.log 2>&1
   echo "rehearsal exit: $?"; grep '^{' gpurun_out/bench_2rank_rehearsal.log | cut -c1-1500
 fi
 if has c5; then
