@@ -32,6 +32,8 @@ CASES = [
     ("5x1_gru_vertical", 2, 15, 27, 128, 256, 128, (5, 1), (2, 0), 1, 1),           # RAFT SepConvGRU vertical pass: ky taps reused, tile rows in (n, x, y) order
     ("3x1_h_smaller_than_halo", 2, 5, 33, 32, 0, 32, (3, 1), (1, 0), 1, 1),
     ("7x1_dil2_cout_200", 1, 40, 21, 64, 0, 200, (7, 1), (6, 0), 2, 1),
+    ("5x1_cout_50_general_epilogue", 2, 20, 19, 64, 0, 50, (5, 1), (2, 0), 1, 1),   # Cout % 4 != 0: workgroup-wide epilogue, rows mapped back from (n, x, y)
+    ("3x3_cout_50_general_epilogue", 2, 11, 23, 32, 32, 50, (3, 3), (1, 1), 1, 1),
     ("1x1_not_served", 1, 15, 27, 64, 0, 64, (1, 1), (0, 0), 1, 1),                 # no taps to reuse: the other kernels
     ("3x3_dil2", 1, 30, 27, 96, 0, 96, (3, 3), (2, 2), 2, 1),
     ("3x3_dil8", 1, 40, 44, 192, 0, 192, (3, 3), (8, 8), 8, 1),                     # LAFC middle: (kw - 1) * dw = 16 = the halo
@@ -130,7 +132,7 @@ def test_taps_nearest_upsampling(il, dev):
     """desc.upsample (nearest x2 ahead of the conv: FGT's decoder, LAFC's decoder): the tile walks the output grid, LDS rows fetch input
     pixel ((y' + dy) >> 1, x' >> 1).  Two sources (LAFC concatenates the skip), odd sizes, an image boundary inside a tile."""
     from fgt_amd import ops
-    for (N, H, W, C0, C1, Cout) in ((3, 9, 13, 64, 0, 64), (2, 15, 27, 96, 96, 48), (1, 30, 54, 128, 0, 200)):
+    for (N, H, W, C0, C1, Cout) in ((3, 9, 13, 64, 0, 64), (2, 15, 27, 96, 96, 48), (1, 30, 54, 128, 0, 200), (2, 7, 10, 32, 0, 50)):
         x = _rand(N, H, W, C0, seed=1).to(dev)
         x1 = _rand(N, H, W, C1, seed=2).to(dev) if C1 else None
         w, b = _rand(Cout, C0 + C1, 3, 3, seed=3, scale=1.0 / math.sqrt(9 * (C0 + C1))), _rand(Cout, seed=4)
