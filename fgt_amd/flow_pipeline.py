@@ -13,9 +13,10 @@ import torch
 from . import ops
 
 
-RAFT_PAIR_BATCH = 32         # pairs per RAFT refinement batch (forward and backward pairs mixed): the per-iteration convs have 1 620 (432x240) /
+RAFT_PAIR_BATCH = 64         # pairs per RAFT refinement batch (forward and backward pairs mixed): the per-iteration convs have 1 620 (432x240) /
 #                              6 480 (864x480) output pixels per pair — 8 pairs left 1.6 rounds of tiles on 256 CUs.  Measured (profiles/r03_run2_raft_batch.txt):
-#                              8 -> 32 pairs: 1.88 -> 1.16 ms per pair at 432x240, 4.34 -> 3.93 at 864x480, bit-identical flows, 10.6 GB peak
+#                              8 -> 32 pairs: 1.88 -> 1.16 ms per pair at 432x240, 4.34 -> 3.93 at 864x480, bit-identical flows, 10.6 GB peak;
+#                              32 -> 64 (end of round 3, tap-reusing convs): 1.02 -> 0.95 and 3.35 -> 3.27, bit-identical, 22 GB peak
 LAFC_PIVOT_BATCH = 16        # pivots per LAFC call (tools/lafc_batch.py: 8 -> 0.718, 16 -> 0.69, 32 -> 0.688 ms per flow at 432x240, bit-equal; 2.9 GB peak at 16)
 FILL_ITERS = 1000            # iteration cap of the diffusion fill's conjugate gradients (a map stops at tol * |r0|)
 
