@@ -16,10 +16,12 @@ exchanged as uint8 in one all-gather, identical composite on every rank (DESIGN.
 per rank, no data-path collective) is timed first and reported beside it as `weak_scaling_clip_per_rank`; if the sharded
 section fails or times out the weak number becomes the headline and the line says so (`scaling`, `strong_error`).
 
-Prints ONE JSON line on rank 0 (contract in the task statement).  `roofline` is the kernel with the largest share of the step
-(per-launch HIP events on the launch stream over the timed region); `rooflines` lists all three MFMA kernels of the path
-(conv/GEMM, temporal attention, spatial attention); `cpu_baseline` is the oracle (PyTorch CPU restatement of the reference)
-timed on the host cores on a bounded sample, median of 3 runs.
+Prints ONE compact JSON line (< 6 KB, `compact_line`) as the LAST stdout line on rank 0 (contract in the task statement); the full
+record (per-mode roofline lists, traffic sources, solver details, notes) goes to gpurun_out/bench_detail.json.  `roofline` is the
+kernel with the largest share of the step (per-launch HIP events on the launch stream over the timed region); `rooflines` lists the
+MFMA kernels of the path (conv/GEMM, temporal attention, spatial attention) and the HBM-bound ones; `cpu_baseline` is the reference
+module itself when /root/reference is mounted (kind "reference"), else the oracle (PyTorch CPU restatement, kind "port"), timed on the
+host cores on a bounded sample, median of 3 runs.
 """
 import argparse
 import json
@@ -37,7 +39,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured with a float4 copy)
-KERNELS = {"conv": "conv_split_kernel (bf16x3) / conv_f16_kernel (f16) / conv_igemm_kernel (fp32 inputs): implicit-GEMM conv + every Linear; all fgt_conv2d MFMA launches",
+KERNELS = {"conv": "conv_{taps,wide,split}_kernel (bf16x3) / conv_igemm_kernel (fp32 inputs) / conv_f16_kernel (f16): implicit-GEMM conv + every Linear; all fgt_conv2d MFMA launches",
            "attn_temporal": "attn_split_kernel<8|4, H> (bf16x3: split q/k/v; f16: H = true) / attn_kernel<4> (fp32): temporal zone attention, fgt_attention mode 0",
            "attn_spatial": "attn_split_kernel<2, H> (bf16x3 / f16) / attn_kernel<2> (fp32): spatial window + global-token attention, fgt_attention mode 1"}
 # HBM-bound kernels of the step (fgt_prof kinds 3..9): algorithmic bytes (every input / output byte once) over HIP-event time
@@ -73,22 +75,34 @@ def kernel_traffic(prec):
 
 
 def cpu_baseline(cfg, sd, frames, flows, masks, sched, model=None, runs=3):
-    """Oracle (PyTorch-CPU port of the reference path) on a bounded sample of the same workload: the first window
-    (t = 13) of the schedule, `runs` timed runs (median) after choosing the intra-op thread count that runs a 2-frame probe
-    fastest (a 256-thread pool on a 256-core host is ~8x slower than 32 threads for these conv sizes)."""
+    """CPU path on a bounded sample of the same workload: the first window (t = 13) of the schedule, `runs` timed runs (median)
+    after choosing the intra-op thread count that runs a 2-frame probe fastest (a 256-thread pool on a 256-core host is ~8x slower
+    than 32 threads for these conv sizes).  The timed function is the REFERENCE module itself (FGT.models.model.Model loaded
+    through oracle/reference_loader.py, kind "reference") when /root/reference is mounted — the authoring container; it does not
+    exist on the GPU box — and the oracle (PyTorch-CPU restatement pinned to it, kind "port") otherwise.  Parity is always taken
+    against the oracle's output (identical to the reference's within fp32 rounding: tests/test_oracle_pinned.py)."""
     from oracle import fgt_oracle as O
+    from oracle import reference_loader as RL
     nb, ref = sched[0]
     ids = nb + ref
     m = masks[:, ids].cpu()
     mf = (frames[:, ids].cpu() * 2 - 1) * (1 - m)
     fl = flows[:, ids].cpu()
+    kind, run = "port", (lambda a, b, c: O.fgt_forward(sd, cfg, a, b, c))
+    if RL.available():
+        try:
+            refm = RL.fgt_model(dict(cfg))
+            refm.load_state_dict({k: v.cpu() for k, v in sd.items()}, strict=True)
+            kind, run = "reference", (lambda a, b, c: refm(a, b, c))
+        except Exception:  # noqa: BLE001 - fall back to the port, the line says which one ran
+            kind = "port"
     ncpu = os.cpu_count() or 1
     best, best_dt = 1, None
     for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
         torch.set_num_threads(th)
-        O.fgt_forward(sd, cfg, mf[:, :1], fl[:, :1], m[:, :1])
+        run(mf[:, :1], fl[:, :1], m[:, :1])
         t0 = time.perf_counter()
-        O.fgt_forward(sd, cfg, mf[:, :2], fl[:, :2], m[:, :2])
+        run(mf[:, :2], fl[:, :2], m[:, :2])
         dt = time.perf_counter() - t0
         if best_dt is None or dt < best_dt:
             best, best_dt = th, dt
@@ -96,11 +110,13 @@ def cpu_baseline(cfg, sd, frames, flows, masks, sched, model=None, runs=3):
     times = []
     for _ in range(runs):
         t0 = time.perf_counter()
-        ref = O.fgt_forward(sd, cfg, mf, fl, m)
+        run(mf, fl, m)
         times.append(time.perf_counter() - t0)
+    ref = O.fgt_forward(sd, cfg, mf, fl, m)
     dt = statistics.median(times)
     total = sum(fgt_flops(len(a) + len(b)) for a, b in sched)
     est_clip_s = dt * total / fgt_flops(len(ids))
+
     def parity_of(model, what="headline precision"):
         """"PSNR vs ref" of the metric: the same window through the HIP path (in the arithmetic mode selected right now) vs the oracle's output"""
         dev = frames.device
@@ -111,11 +127,134 @@ def cpu_baseline(cfg, sd, frames, flows, masks, sched, model=None, runs=3):
                 "note": f"HIP path ({what}) vs CPU oracle on window 0; PSNR per FGT/metrics/psnr.py:5-9 on clip((x+1)/2*255) uint8 frames (100 = identical)"}
 
     parity = parity_of(model) if model is not None else None
+    who = "reference FGT.models.model.Model.forward" if kind == "reference" else "oracle fgt_forward (CPU restatement of the reference)"
     return parity, parity_of, {"value": round(frames.shape[1] / est_clip_s, 4), "unit": "frames/s", "cores": best, "host_cores": ncpu,
-                    "kind": "port", "runs_s": [round(x, 3) for x in times],
-                    "sample": f"oracle fgt_forward on window 0 (t={len(ids)}) at {frames.shape[-1]}x{frames.shape[-2]}: median of {runs} runs = {dt:.2f} s "
+                    "kind": kind, "runs_s": [round(x, 3) for x in times],
+                    "sample": f"{who} on window 0 (t={len(ids)}) at {frames.shape[-1]}x{frames.shape[-2]}: median of {runs} runs = {dt:.2f} s "
                               f"with {best} threads (fastest of a 2-frame probe); clip time extrapolated by F(t)=147.03t+1.0618t^2 GFLOP over the "
                               f"{len(sched)}-window reference schedule ({total / 1e12:.1f} TFLOP)"}
+
+
+LINE_LIMIT = 6000       # bytes: the driver parses the LAST stdout line; round 3's 26 KB line did not parse
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[: n - 1] + "…"
+
+
+def _b(bound):
+    return "hbm" if str(bound).startswith("hbm") else "mfma"
+
+
+def compact_line(full, detail_path=None):
+    """The ONE JSON line of the bench contract, derived from the full record `full` (which goes to `detail_path`): contract keys,
+    `roofline` of the dominant kernel, compact `rooflines` (kind / bound / frac / ms), `cpu_baseline`, `parity_vs_cpu_oracle`,
+    `fp32_exact` {value, ms_per_step, roofline_frac}, `c4` {per stage: ms + hardware / effective fractions, pipeline frames/s}.
+    Always < LINE_LIMIT bytes (tests/test_bench_line.py); optional blocks are dropped from the tail if a future field overflows it."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "data")
+    line = {k: full[k] for k in keep if k in full}
+    line["dtype"] = _short(full.get("dtype", ""), 120)
+    cfg = full.get("config", {})
+    line["config"] = {k: (_short(v, 200) if isinstance(v, str) else v) for k, v in cfg.items()}
+    for k in ("effective_tflops", "host_enqueue_ms_per_step", "output_checksum", "output_sane", "strong_error"):
+        if k in full:
+            line[k] = full[k]
+    r = full.get("roofline")
+    if r:
+        rr = {k: r.get(k) for k in ("bound", "kind", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_tflops", "mfma_passes_per_product",
+                                    "launches", "avg_launch_us", "kernel_ms_per_step", "share_of_step") if k in r}
+        rr["bound"] = _b(rr.get("bound", ""))
+        rr["kernel"] = _short(r.get("kernel", ""), 90)
+        hb = r.get("hbm") or {}
+        if "bytes_per_launch" in hb:
+            rr["algorithmic_bytes_per_launch"] = hb["bytes_per_launch"]
+        if rr.get("traffic") and hb.get("bytes_per_launch"):
+            rr["traffic_over_algorithmic"] = round(rr["traffic"] / hb["bytes_per_launch"], 3)
+        ts = r.get("traffic_source") or {}
+        if ts:
+            rr["traffic_source"] = {"file": ts.get("file"), "git_head": ts.get("git_head")}
+        su = r.get("sustained") or {}
+        if su:
+            rr["sustained"] = {k: su.get(k) for k in ("peak", "clock_ghz", "frac") if k in su}
+        line["roofline"] = rr
+    if full.get("rooflines"):
+        line["rooflines"] = [{"kind": x["kind"], "bound": _b(x["bound"]), "frac": x["frac"], "achieved": x["achieved"], "unit": x["unit"],
+                              "ms": x["kernel_ms_per_step"]} for x in full["rooflines"]]
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: (_short(v, 260) if k == "sample" else v) for k, v in cb.items() if k in ("value", "unit", "cores", "host_cores", "kind", "sample")}
+    pv = full.get("parity_vs_cpu_oracle")
+    if pv:
+        line["parity_vs_cpu_oracle"] = {k: pv[k] for k in ("window", "frames", "max_abs_diff", "ref_max_abs", "psnr_db_uint8") if k in pv}
+    for name in ("fp32_exact", "f16"):
+        f = full.get(name)
+        if f:
+            line[name] = {"value": f["value"], "ms_per_step": f["ms_per_step"], "roofline_frac": (f.get("roofline") or {}).get("frac"),
+                          "roofline_kind": (f.get("roofline") or {}).get("kind"), "composite_vs_headline": f.get("composite_vs_headline")}
+    c4 = full.get("c4")
+    if c4:
+        if "error" in c4:
+            line["c4"] = {"error": _short(c4["error"], 300)}
+        else:
+            st = {}
+            for k, v in c4.get("stages", {}).items():
+                e = {kk: vv for kk, vv in v.items() if kk.startswith("ms_per_")}
+                rl = v.get("roofline") or {}
+                if rl:
+                    e["bound"] = _b(rl.get("bound", ""))
+                    # MFMA stages: `frac_effective` = reference FLOP count (incl. encoder passes the pipeline no longer executes) x MFMA passes
+                    # over the stage time; `frac_hardware` = the executed conv launches' event-timed rate (c4.rooflines).  HBM stages: `frac`.
+                    if rl.get("bound") == "mfma":
+                        e["frac_effective"] = rl.get("frac")
+                        if "frac_hardware" in rl:
+                            e["frac_hardware"] = rl["frac_hardware"]
+                    else:
+                        e["frac"] = rl.get("frac")
+                st[k] = e
+            cc = {"stages": st, "pipeline_frames_per_s": (c4.get("pipeline_frames_per_s") or {}).get("value"),
+                  "pipeline_ms_per_clip": (c4.get("pipeline_frames_per_s") or {}).get("ms_per_clip"),
+                  "rooflines": [{"kind": _short(x["kind"], 40), "bound": x["bound"], "frac": x["frac"], "achieved": x["achieved"], "unit": x["unit"]}
+                                for x in c4.get("rooflines", [])]}
+            cpu = c4.get("cpu_baseline") or {}
+            if cpu:
+                cc["cpu_baseline"] = {"cores": cpu.get("cores"), "kind": cpu.get("kind"),
+                                      "gpu_speedup": {k: v.get("gpu_speedup") for k, v in cpu.items() if isinstance(v, dict)}}
+            if "sharded" in c4:
+                cc["sharded"] = c4["sharded"]
+            line["c4"] = cc
+    for k in ("phases_ms", "weak_scaling_clip_per_rank", "strong_scaling_same_clip", "strong_scaling_ideal", "pipeline_sharded", "feature_exchange"):
+        if k in full:
+            v = full[k]
+            if k == "strong_scaling_ideal":
+                v = {kk: vv for kk, vv in v.items() if kk != "note"}
+            line[k] = v
+    if detail_path:
+        line["detail"] = detail_path
+    # safety net: never exceed the limit — drop optional blocks from the least important end
+    for k in ("phases_ms", "f16", "rooflines", "strong_scaling_ideal", "c4", "fp32_exact", "parity_vs_cpu_oracle"):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        if k in line:
+            line.pop(k)
+            line.setdefault("dropped", []).append(k)
+    return line
+
+
+def emit(full):
+    """Write the full record to gpurun_out/bench_detail.json (scratch dir of a GPU visit; created if missing) and print the compact line LAST."""
+    rel = os.path.join("gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, rel), "w") as f:
+            json.dump(full, f, indent=1)
+    except OSError:
+        rel = None
+    if os.environ.get("FGT_BENCH_DETAIL_STDOUT") == "1":
+        print("BENCH_DETAIL " + json.dumps(full), flush=True)       # a line BEFORE the last one
+    line = compact_line(full, rel)
+    print(json.dumps(line), flush=True)
+    return line
 
 
 def main():
@@ -133,7 +272,8 @@ def main():
                          "product and fp32 accumulation (FGT max |diff| vs reference 1.6e-6, bar 1e-3); or f16: GEMM / attention operands "
                          "rounded once to fp16 by their producer, one fp16 MFMA per product, fp32 accumulation (~1e-4, bar 1e-3)")
     ap.add_argument("--no-fp32-exact", action="store_true", help="N = 1: do not also time the exact-fp32 mode (the `fp32_exact` object)")
-    ap.add_argument("--no-f16", action="store_true", help="N = 1: do not also time the f16 mode (the `f16` object)")
+    ap.add_argument("--f16", action="store_true", help="N = 1: also time the f16 mode (the `f16` object; lower precision than the reference, never the headline)")
+    ap.add_argument("--no-f16", action="store_true", help="(default since round 4; kept so that older command lines still parse)")
     ap.add_argument("--no-c4", action="store_true", help="N = 1: skip the `c4` object (BASELINE config C4 + tool stages: RAFT, diffusion fill, LAFC, "
                                                          "gradient propagation, Poisson blend, pipeline frames/s)")
     ap.add_argument("--no-cache", action="store_true", help="recompute the per-frame encoders in every window like the reference")
@@ -357,8 +497,7 @@ def main():
     if world > 1:
         def give_up():
             if rank == 0:
-                line = assemble(weak_res, weak=True, strong_error="sharded section timed out after 300 s")
-                print(json.dumps(line), flush=True)
+                emit(assemble(weak_res, weak=True, strong_error="sharded section timed out after 300 s"))
             os._exit(0)
 
         dog = threading.Timer(300.0, give_up)
@@ -397,7 +536,7 @@ def main():
         if not args.no_cpu_baseline:      # CPU baseline: rank 0 at N = 1 only (headline precision still selected)
             ops.DEFAULT_CONV_PRECISION = ops.DEFAULT_ATTN_PRECISION = prec
             out["parity_vs_cpu_oracle"], parity_of, out["cpu_baseline"] = cpu_baseline(cfg, sd, frames, flows, masks, runner.sched, model)
-        if prec != "f16" and not args.no_f16:
+        if prec != "f16" and args.f16 and not args.no_f16:
             # the third arithmetic mode in the same invocation: operands rounded once to fp16 by their producer, one MFMA per product
             dt16, host16, comp16, kinds16 = timed(runner, "f16", prof=not args.no_prof)
             rl = rooflines(kinds16, "f16", dt16)
@@ -434,7 +573,7 @@ def main():
             ops.save_tuning(os.path.join(ROOT, "gpurun_out", "tuning.json"))
 
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
         assert out["output_sane"], "composited clip has NaN/inf or out-of-range values"
     if world > 1:
         dist.barrier()

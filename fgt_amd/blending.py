@@ -16,10 +16,23 @@ from . import ops
 BLEND_ITERS = 2000           # iteration cap of the conjugate gradients (a problem stops at tol * |r0|)
 
 
-def poisson_blend_clip(target, gradient_x, gradient_y, hole, gradient_mask, iters=BLEND_ITERS, tol=1e-7):
+def poisson_blend_clip(target, gradient_x, gradient_y, hole, gradient_mask, iters=BLEND_ITERS, tol=1e-7, rank=0, world=1, group=None, bounds=None):
     """target, gradient_x, gradient_y [N,H,W,3] fp32 device tensors (gradient_x[..., x, :] = I[x+1] - I[x]); hole, gradient_mask
-    [N,H,W].  Returns (blend [N,H,W,3], UnfilledMask [N,H,W] bool)."""
-    return ops.poisson_blend(target, gradient_x, gradient_y, hole, gradient_mask, iters, tol)
+    [N,H,W].  Returns (blend [N,H,W,3], UnfilledMask [N,H,W] bool).  world > 1: frames are independent problems
+    (tool/video_inpainting.py:644-682 loops over them): block-sharded, one all-gather of the blended frames + unfilled masks.
+    `bounds` = ops.hole_bounds(hole) of the clip (no host sync in this call)."""
+    if world == 1:
+        return ops.poisson_blend(target, gradient_x, gradient_y, hole, gradient_mask, iters, tol, bounds=bounds)
+    from .flow_pipeline import gather_blocks, shard_range
+    N, H, W, _ = target.shape
+    lo, hi = shard_range(N, rank, world)
+    if hi > lo:
+        bl, unf = ops.poisson_blend(target[lo:hi], gradient_x[lo:hi], gradient_y[lo:hi], hole[lo:hi], gradient_mask[lo:hi], iters, tol, bounds=bounds)
+        loc = torch.cat([bl, unf.float()[..., None]], -1)                       # [cnt, H, W, 4]: one collective for both outputs
+    else:
+        loc = torch.zeros(0, H, W, 4, dtype=torch.float32, device=target.device)
+    full = gather_blocks(loc, N, rank, world, group)
+    return full[..., :3].contiguous(), full[..., 3] != 0
 
 
 def Poisson_blend_img(imgTrg, imgSrc_gx, imgSrc_gy, holeMask, gradientMask=None, edge=None, device="cuda", iters=BLEND_ITERS, tol=1e-7):

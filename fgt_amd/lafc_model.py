@@ -132,8 +132,8 @@ class P3DNet(nn.Module):
         return tgt
 
     # ---- split chains (vanilla convs, bf16x3 arithmetic): a conv whose output only feeds other convs writes it PRE-SPLIT (ops.Split, bf16 hi /
-    # lo pair) and the consumer's im2col tiles become plain LDS-DMA copies (csrc/conv_split.hip) — bit-identical to handing fp32 tensors to
-    # the bf16x3 kernel.  `want`: "s" = split only, "both" = (fp32, split) for outputs that are ALSO an epilogue operand (residuals) or
+    # lo pair) and the consumer's im2col tiles become plain LDS-DMA copies (csrc/conv_split.hip) — the same products as handing fp32 tensors to
+    # the bf16x3 kernel (tap-routed layers sum them in another order, csrc/conv_taps.hip: equal to fp32 rounding, not bit for bit).  `want`: "s" = split only, "both" = (fp32, split) for outputs that are ALSO an epilogue operand (residuals) or
     # feed a Cout <= 4 VALU conv, "f32" = fp32 only.  Without split chains (exact-fp32 mode, gated convs) every form is the fp32 tensor.
     def _sc(self):
         return (not self.gated) and ops.DEFAULT_CONV_PRECISION != "fp32"

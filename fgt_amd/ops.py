@@ -21,8 +21,11 @@ DEFAULT_CONV_PRECISION = os.environ.get("FGT_CONV_PRECISION", "fp32")
 DEFAULT_ATTN_PRECISION = os.environ.get("FGT_ATTN_PRECISION", "fp32")
 
 # Per-shape tile autotuning of fgt_conv2d: the first call of a new (shape, precision) times every tile candidate with HIP
-# events and caches the fastest.  Tiles only change the work decomposition: results are bit-identical across tiles
-# (the k order of every accumulation is the same), so tuning never changes numerics.
+# events and caches the fastest.  Tiles only change the work decomposition: within ONE kernel family (tap-reusing kernel / the
+# others) results are bit-identical across tiles (the k order of every accumulation is the same), and which family a layer gets is
+# decided by its geometry (fgt_conv_taps_route), never by tuning — so tuning never changes numerics.  (The two families accumulate in
+# different orders — (ky, chunk, kx) vs (ky, kx, chunk) — so a split-input layer routed to the tap kernel differs in the last bits from
+# the same layer fed fp32 tensors; same products, different summation order.)
 AUTOTUNE = os.environ.get("FGT_AUTOTUNE", "1") != "0"
 TILE_CANDIDATES = ("128x128", "64x64", "128x64", "256x128", "128x32", "128x128x8", "256x128x16", "256x64x8",
                    # split inputs only (rejected, hence skipped, for fp32 inputs): the same tiles with early stage release
@@ -34,6 +37,7 @@ TILE_CANDIDATES = ("128x128", "64x64", "128x64", "256x128", "128x32", "128x128x8
 # tiles only — they are bit-identical to each other, so results never depend on tuning.
 TAPS_CANDIDATES = ("128x128x8t", "128x128t", "128x64t", "128x64x8t", "64x64t")
 _tile_cache = {}
+_tile_validated = set()      # keys whose cached tile has been checked against the geometry's kernel family (conv2d)
 
 
 def mode_key():
@@ -386,12 +390,31 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
         key = (N, H, W, C0, C1, pc.Cout, pc.groups, pc.kh, pc.kw, sh, sw, ph, pw, dh, dw, d.upsample, d.epi, d.out_nchw, d.precision,
                d.in_split, d.out_split, d.w_il, int(bool(osp) and out_s.il) + 2 * int(bool(osp) and out_s.h), d.pad_mode, d.in_relu)
         best = _tile_cache.get(key)
+        if best is not None and key not in _tile_validated:
+            # A cached / loaded tile must belong to the kernel family the GEOMETRY routes this layer to (taps-routed layers: codes 200-299,
+            # everything else below 200; diagnostic codes >= 300 never come from the autotuner): a table saved under FGT_CONV_TAPS=0 or from a
+            # diagnostic build would otherwise select another accumulation order — or a tile the product library does not have.
+            taps = bool(_lib.lib().fgt_conv_taps_route(C.byref(d)))
+            if (200 <= best < 300) != taps or best >= 300 or best < 0:
+                best = None
+                _tile_cache.pop(key, None)
+            else:
+                _tile_validated.add(key)
         if best is None and not torch.cuda.is_current_stream_capturing() and not _aliases(out, out_s, x, x1, aux1, aux2):
             # (tuning re-launches the kernel into the caller's buffers and synchronises: illegal under stream capture, and it would
             #  corrupt an output that aliases an input / aux operand — such calls run on the static tile and are not cached)
             taps = bool(_lib.lib().fgt_conv_taps_route(C.byref(d)))
             best = _tile_cache[key] = _autotune(d, args, TAPS_CANDIDATES if taps else TILE_CANDIDATES)
+            _tile_validated.add(key)
         d.tile = best or 0
+        if best:
+            rc = _lib.lib().fgt_conv2d(*args, _stream())
+            if rc != 0:                      # e.g. a table from a diagnostic build names a tile this library does not have: forget it, static tile
+                _tile_cache.pop(key, None)
+                _tile_validated.discard(key)
+                d.tile = 0
+                check(_lib.lib().fgt_conv2d(*args, _stream()), "fgt_conv2d")
+            return {0: out, 1: out_s, 2: (out, out_s)}[osp]
     check(_lib.lib().fgt_conv2d(*args, _stream()), "fgt_conv2d")
     return {0: out, 1: out_s, 2: (out, out_s)}[osp]
 
@@ -836,9 +859,44 @@ def _onchip_bounds(bb):
     return rows, cols
 
 
-def laplace_fill(maps, masks, iters=1000, tol=1e-6, solver=None):
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def hole_bounds(masks):
+    """(max rows, max cols) of the holes' bounding boxes of uint8 / bool masks [n, H, W], or None when a box does not fit one workgroup.
+    ONE blocking read-back: a clip's masks are fixed, so callers compute this once per clip and pass it as `bounds=` to laplace_fill /
+    poisson_blend (both directions of the diffusion fill and the Poisson blend use the same holes) instead of paying a device-to-host
+    sync per call."""
+    m8 = (masks != 0).to(torch.uint8).contiguous()
+    return _onchip_bounds(mask_bbox(m8))
+
+
+def solver_report(name):
+    """What the last `laplace_fill` / `poisson_blend` call did, read back from the device: solver, problems, iterations (mean / max), the
+    number of problems that hit the iteration cap and the number the device NaN-filled because their box exceeded the promised bounds
+    (status 1; cannot happen with bounds from `hole_bounds` of the same masks).  FGT_SOLVER_CHECK=1 makes the two entry points assert
+    the latter is zero after every call (a blocking read-back: debugging only)."""
+    st = last_solver.get(name, {})
+    if st.get("solver") != "onchip":
+        return {"solver": st.get("solver", "none")}
+    s = st["status"].cpu().long()
+    it = s >> 1
+    return {"solver": "onchip", "problems": int(s.numel()), "iterations_mean": float(it.float().mean()), "iterations_max": int(it.max()),
+            "cap_hits": int((it >= st.get("iters", 1 << 30)).sum()), "nan_filled": int((s == 1).sum()), "bbox": st.get("bbox")}
+
+
+def _solver_check(name):
+    if os.environ.get("FGT_SOLVER_CHECK") == "1" and not _capturing():
+        rep = solver_report(name)
+        assert rep.get("nan_filled", 0) == 0, f"{name}: {rep['nan_filled']} problems exceeded the promised bounding box (NaN-filled)"
+
+
+def laplace_fill(maps, masks, iters=1000, tol=1e-6, solver=None, bounds=None):
     """fgt_laplace_fill[_onchip]: maps [B, H, W] fp32, masks [n_masks, H, W] (non-zero = hole; map b uses mask b % n_masks) -> filled [B, H, W].
-    tool/utils/region_fill.py:7-63 for every map at once by conjugate gradients (`iters` = iteration cap, a map stops at tol * |r0|)."""
+    tool/utils/region_fill.py:7-63 for every map at once by conjugate gradients (`iters` = iteration cap, a map stops at tol * |r0|).
+    `bounds` = hole_bounds(masks) computed earlier (no host sync in this call, legal under stream capture); without it the on-chip path
+    reads the boxes back once (skipped while a stream is capturing: the multi-launch kernels run then)."""
     _require_dev(maps)
     assert maps.dim() == 3 and masks.dim() == 3 and masks.shape[1:] == maps.shape[1:] and masks.is_cuda
     maps = maps.contiguous()
@@ -846,14 +904,16 @@ def laplace_fill(maps, masks, iters=1000, tol=1e-6, solver=None):
     B, H, W = maps.shape
     out = torch.empty_like(maps)
     solver = solver or SOLVER
-    if solver != "multilaunch" and W % 4 == 0:
+    if solver != "multilaunch" and W % 4 == 0 and (bounds is not None or not _capturing()):
         bb = mask_bbox(m8)
-        bounds = _onchip_bounds(bb)
+        if bounds is None:
+            bounds = _onchip_bounds(bb)
         if bounds is not None:
             status = torch.empty(B, dtype=torch.int32, device=maps.device)
             check(_lib.lib().fgt_laplace_fill_onchip(_ptr(maps), C.c_void_p(m8.data_ptr()), C.c_void_p(bb.data_ptr()), B, m8.shape[0], H, W, _ptr(out),
                                                      bounds[0], bounds[1], int(iters), float(tol), C.c_void_p(status.data_ptr()), _stream()), "fgt_laplace_fill_onchip")
-            last_solver["laplace_fill"] = {"solver": "onchip", "status": status, "bbox": bounds}
+            last_solver["laplace_fill"] = {"solver": "onchip", "status": status, "bbox": bounds, "iters": int(iters)}
+            _solver_check("laplace_fill")
             return out
         if solver == "onchip":
             raise RuntimeError("laplace_fill(solver='onchip'): a hole's bounding box does not fit one workgroup")
@@ -884,7 +944,7 @@ def flow_propagate(gx, gy, mask, flow_f, flow_b, consistency_thres=5.0, alpha=0.
     return ox, oy, fill.bool()
 
 
-def poisson_blend(target, gx, gy, hole, gmask, iters=2000, tol=1e-7, solver=None):
+def poisson_blend(target, gx, gy, hole, gmask, iters=2000, tol=1e-7, solver=None, bounds=None):
     """fgt_poisson_blend[_onchip]: target, gx, gy [N,H,W,3] fp32; hole, gmask [N,H,W] (non-zero = hole / gradient unknown) ->
     (blend [N,H,W,3], unfilled [N,H,W] bool).  tool/utils/Poisson_blend_img.py:19-244 for the whole clip."""
     _require_dev(target, gx, gy)
@@ -896,15 +956,17 @@ def poisson_blend(target, gx, gy, hole, gmask, iters=2000, tol=1e-7, solver=None
     unf = torch.empty(N, H, W, dtype=torch.uint8, device=target.device)
     ws = torch.empty(_lib.lib().fgt_poisson_blend_workspace(N, H, W), dtype=torch.uint8, device=target.device)
     solver = solver or SOLVER
-    if solver != "multilaunch" and W % 4 == 0:
+    if solver != "multilaunch" and W % 4 == 0 and (bounds is not None or not _capturing()):
         bb = mask_bbox(h8)
-        bounds = _onchip_bounds(bb)
+        if bounds is None:
+            bounds = _onchip_bounds(bb)
         if bounds is not None:
             status = torch.empty(3 * N, dtype=torch.int32, device=target.device)
             check(_lib.lib().fgt_poisson_blend_onchip(_ptr(target), _ptr(gx), _ptr(gy), C.c_void_p(h8.data_ptr()), C.c_void_p(g8.data_ptr()), C.c_void_p(bb.data_ptr()),
                                                       N, H, W, bounds[0], bounds[1], int(iters), float(tol), _ptr(out), C.c_void_p(unf.data_ptr()),
                                                       C.c_void_p(status.data_ptr()), C.c_void_p(ws.data_ptr()), _stream()), "fgt_poisson_blend_onchip")
-            last_solver["poisson_blend"] = {"solver": "onchip", "status": status, "bbox": bounds}
+            last_solver["poisson_blend"] = {"solver": "onchip", "status": status, "bbox": bounds, "iters": int(iters)}
+            _solver_check("poisson_blend")
             return out, unf.bool()
         if solver == "onchip":
             raise RuntimeError("poisson_blend(solver='onchip'): a hole's bounding box does not fit one workgroup")

@@ -249,8 +249,10 @@ class RAFT(nn.Module):
         E, G = P["enc"], P["gru"]
         m4 = lambda t2: t2.view(B, h8, w8, t2.shape[1]) if t2.is_contiguous() else t2.unflatten(0, (B, h8, w8))
         # bf16x3 arithmetic: the conv -> conv chains of the update block hand their activations over PRE-SPLIT (ops.Split, bf16 hi / lo pairs:
-        # the consumer's im2col tiles are plain LDS-DMA copies, csrc/conv_split.hip) — the same arithmetic as feeding fp32 tensors to the
-        # bf16x3 kernel, bit for bit.  Under the 'f16' mode RAFT stays in bf16x3 (h = False: bf16 pairs, never fp16 planes).
+        # the consumer's im2col tiles are plain LDS-DMA copies, csrc/conv_split.hip) — the same PRODUCTS as feeding fp32 tensors to the
+        # bf16x3 kernel; layers that the geometry routes to the tap-reusing kernel (3x3, 1x5, 5x1 'same' convs on split inputs, csrc/conv_taps.hip)
+        # sum them in (ky, chunk, kx) order instead of (ky, kx, chunk), so the two input forms agree to fp32 rounding, not bit for bit
+        # (bit-identity holds within one input form: across tiles, batch sizes, ranks).  Under the 'f16' mode RAFT stays in bf16x3 (h = False: bf16 pairs, never fp16 planes).
         sc = ops.DEFAULT_CONV_PRECISION != "fp32"
         rows = B * n
         S = lambda ch: ops.Split.empty((rows, ch), dev, h=False)

@@ -217,7 +217,23 @@ class ClipRunner:
             self.n_chunks, self.ck = -(-self.n // self.encode_chunk), self.encode_chunk
         self._row_of = list(range(self.n))
         self.rows = self.n
-        if world > 1:
+        import os
+        # FGT_EXCHANGE=allgather: replace the needed-rows all-to-all by a plain all_gather_into_tensor of every chunk (equal-sized
+        # contributions, the most ordinary collective there is) — the degraded mode for a first RCCL run in which the uneven / zero-length
+        # all_to_all_single misbehaves.  Same composite (tests/test_scheduler.py), ~2.7x the bytes on the wire at 8 ranks.
+        self.exchange = "none" if world == 1 else os.environ.get("FGT_EXCHANGE", "a2a").lower()
+        if self.exchange not in ("none", "a2a", "allgather"):
+            raise ValueError(f"FGT_EXCHANGE={self.exchange!r}: expected 'a2a' or 'allgather'")
+        if self.exchange == "allgather":
+            # chunk j's gathered block = rows [j*world*ck, (j+1)*world*ck): rank r's frames of the chunk at offset r*ck
+            self._plan = None
+            self.rows = self.n_chunks * world * self.ck
+            self._row_of = [-1] * self.n
+            for f in range(self.n):
+                r, o = divmod(f, self.per)
+                j, i = divmod(o, self.ck)
+                self._row_of[f] = j * world * self.ck + r * self.ck + i
+        elif world > 1:
             need = [sorted({f for wi in self.assign[q] for f in self.sched[wi][0] + self.sched[wi][1]}) for q in range(world)]
             self.need = need
             chunk_of = lambda r, j: range(min(self.n, r * self.per + j * self.ck), min(self.n, r * self.per + (j + 1) * self.ck, (r + 1) * self.per))
@@ -253,7 +269,6 @@ class ClipRunner:
             self._group_tq.append(tq if self.prune_last else None)
             self._group_keep_q.append(torch.tensor([j * tq + i for j, wi in enumerate(ws) for i in range(len(self.sched[wi][0]))],
                                                    dtype=torch.int32, device=self.dev))
-        import os
         # window groups on `n_streams` concurrent HIP streams (default 1; FGT_STREAMS): +1.8 % clip throughput with 2 on the bench
         # clip, bit-identical composite — off by default because overlapped launches make the per-launch event timings of
         # bench.py's roofline blocks meaningless
@@ -293,7 +308,9 @@ class ClipRunner:
             new = lambda rows, *s: torch.zeros(rows, *s, dtype=torch.float32, device=self.dev)
             full = (new(self.rows, Hf, Wf, C), new(self.rows, th * tw, c), new(self.rows, th * tw, cf))
             local = send = None
-            if self.world > 1:
+            if self.exchange == "allgather":
+                local = tuple(new(self.n_chunks * self.ck, *b.shape[1:]) for b in full)      # chunk j at rows [j*ck, (j+1)*ck), zero rows past the clip
+            elif self.world > 1:
                 # this rank's block as encoded, and one send buffer per chunk (rows ordered by destination rank; a frame that several
                 # ranks need appears once per destination)
                 local = tuple(new(max(self.per, 1), *b.shape[1:]) for b in full)
@@ -331,6 +348,20 @@ class ClipRunner:
             return full + (th, tw)
         lo = self.rank * self.per
         works = []
+        if self.exchange == "allgather":
+            W, ck = self.world, self.ck
+            for j in range(self.n_chunks):
+                s0 = min(self.n, lo + j * ck)
+                s1 = min(self.n, lo + (j + 1) * ck, lo + self.per)
+                if s1 > s0:
+                    self._encode_chunk(s0, s1, tuple(l[j * ck:j * ck + s1 - s0] for l in local))
+                for b, l in zip(full, local):
+                    works.append(all_gather(b[j * W * ck:(j + 1) * W * ck], l[j * ck:(j + 1) * ck], self.group, async_op=True))
+            self._t("encode")
+            for w in works:
+                w.wait()
+            self._t("gather_wait")
+            return full + (th, tw)
         for j, (ids, in_rows, out_rows, r0) in enumerate(self._plan):
             s0 = min(self.n, lo + j * self.ck)
             s1 = min(self.n, lo + (j + 1) * self.ck, lo + self.per)

@@ -340,7 +340,7 @@ def _sample(img, coords):
     return F.grid_sample(img, torch.cat([2 * xg / (W - 1) - 1, 2 * yg / (H - 1) - 1], dim=-1), align_corners=True)
 
 
-def laplace_fill(maps, masks, iters=1000, tol=1e-6):
+def laplace_fill(maps, masks, iters=1000, tol=1e-6, solver=None, bounds=None):
     """fgt_laplace_fill contract: the exact solution of the masked Laplace system (the kernel iterates to tol; the spec is the solve)."""
     import numpy as np
     from oracle import fill_oracle as FO

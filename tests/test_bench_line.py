@@ -1,0 +1,68 @@
+"""The bench contract's LAST stdout line must stay parseable by the driver: round 3's 26 KB line was not (BENCH_r03.parsed = null).
+`bench.compact_line` derives the line from the full record; here it is fed canned records (the round-3 full line committed under
+profiles/, and a synthetic worst case with every optional block present and long strings) and must stay under bench.LINE_LIMIT."""
+import copy
+import json
+import os
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
+
+
+def _canned():
+    return json.load(open(os.path.join(ROOT, "profiles", "r03_run22_bench_full.json")))
+
+
+def test_round3_record_compacts_under_limit():
+    full = _canned()
+    assert len(json.dumps(full)) > 20000            # the record that broke the driver's parser
+    line = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    s = json.dumps(line)
+    assert len(s) < bench.LINE_LIMIT, len(s)
+    back = json.loads(s)
+    for k in CONTRACT:
+        assert k in back, k
+    assert back["config"]["workload"].startswith("full FGT forward")
+    r = back["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel_ms_per_step", "sustained"):
+        assert k in r, k
+    assert r["bound"] in ("mfma", "hbm") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    cb = back["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert {x["kind"] for x in back["rooflines"]} >= {"conv", "attn_temporal", "attn_spatial", "layernorm", "fold"}
+    assert set(back["fp32_exact"]) >= {"value", "ms_per_step", "roofline_frac"}
+    c4 = back["c4"]
+    assert c4["pipeline_frames_per_s"] > 0 and "raft_864x480" in c4["stages"] and "ms_per_pair" in c4["stages"]["raft_864x480"]
+    assert "dropped" not in back
+
+
+def test_worst_case_record_still_under_limit():
+    full = _canned()
+    full["metric"] = full["metric"] + " " + "x" * 200
+    full["config"]["sharding"] = "y" * 2000
+    full["cpu_baseline"]["sample"] = "z" * 5000
+    full["strong_error"] = "e" * 300
+    full["weak_scaling_clip_per_rank"] = {"value": 1.0, "unit": "frames/s", "ms_per_step": 1.0, "scaling": "weak", "output_checksum": 1.0}
+    full["strong_scaling_ideal"] = {"window_phase_speedup_bound": 7.1, "frame_phase_speedup_bound": 8.0, "note": "n" * 1000}
+    full["phases_ms"] = {f"rank{i}": {"encode": 1.0, "gather_wait": 1.0, "windows": 1.0, "exchange": 1.0, "blend": 1.0} for i in range(8)}
+    big = copy.deepcopy(full["rooflines"])
+    full["rooflines"] = big + big                     # twice as many kernels as today
+    line = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    s = json.dumps(line)
+    assert len(s) < bench.LINE_LIMIT, len(s)
+    back = json.loads(s)
+    for k in CONTRACT + ("roofline", "cpu_baseline"):
+        assert k in back, k
+
+
+def test_c4_error_and_missing_blocks():
+    full = _canned()
+    full["c4"] = {"error": "RuntimeError: " + "q" * 1000, "trace": "t" * 1200}
+    for k in ("fp32_exact", "f16", "parity_vs_cpu_oracle", "cpu_baseline", "rooflines", "roofline"):
+        full.pop(k, None)
+    line = bench.compact_line(full)
+    assert len(json.dumps(line)) < bench.LINE_LIMIT
+    assert "error" in line["c4"] and "detail" not in line

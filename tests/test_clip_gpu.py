@@ -137,6 +137,9 @@ def test_cliprunner_model_without_mask_channel(dev):
 
 
 # ------------------------------------------------------------------------------------------------ the bench clip itself
+_BENCH_COMP = {}
+
+
 @pytest.fixture(scope="module")
 def clip80(dev):
     """The 432x240x80 clip bench.py times (synth_clip seed 1234, trained 20x36 token grid, 16 windows of t = 13 / 17 / 18) through the CPU
@@ -149,8 +152,8 @@ def clip80(dev):
     return m, (fr.to(dev), fl.to(dev), ms.to(dev)), ref
 
 
-@pytest.mark.parametrize("prec,max_rate", [("fp32", 3e-4), ("bf16x3", 2e-2)])
-def test_bench_clip_432x240x80_full_geometry_matches_oracle_clip(prec, max_rate, clip80, monkeypatch):
+@pytest.mark.parametrize("prec,max_rate,chunk", [("fp32", 3e-4, 20), ("bf16x3", 2e-2, 40), ("bf16x3", 2e-2, 20)])
+def test_bench_clip_432x240x80_full_geometry_matches_oracle_clip(prec, max_rate, chunk, clip80, monkeypatch):
     """`ClipRunner(cache, batch 8, pruned last pair)` — exactly the runner and clip of the bench headline — against `oracle.fgt_clip`:
     batch-8 groups of t = 17 / 18 windows on the trained grid, the composite of all 16 windows.  Every difference <= 1 uint8 step
     (a value on an integer boundary of (x+1)/2*255 flips with a 1e-7 change), the rate of differing values bounded by the arithmetic."""
@@ -159,9 +162,14 @@ def test_bench_clip_432x240x80_full_geometry_matches_oracle_clip(prec, max_rate,
     monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", prec)
     monkeypatch.setattr(ops, "DEFAULT_ATTN_PRECISION", prec)
     m, (fr, fl, ms), ref = clip80
-    r = ClipRunner(m, fr, fl, ms, cache_features=True, window_batch=8)
+    # encode_chunk = 40 is bench.py's default (--encode-chunk), 20 the library's: both host configurations are held to the oracle, and
+    # (below) to each other bit for bit
+    r = ClipRunner(m, fr, fl, ms, cache_features=True, window_batch=8, encode_chunk=chunk)
     assert sorted(len(g) for g in r.groups) == [1, 7, 8] and all(tq is not None for tq in r._group_tq)
     got = r.run().cpu()
+    if prec == "bf16x3":
+        prev = _BENCH_COMP.setdefault(prec, got)
+        assert torch.equal(prev, got), "encode_chunk changes the composite"
     d = (got - ref).abs()
     rate = (d > 0).float().mean().item()
     print(f"[parity] bench clip 432x240x80 ClipRunner(cache, batch 8, pruned, {prec}) vs oracle.fgt_clip: max diff {d.max().item()} uint8 steps, "

@@ -194,3 +194,46 @@ def test_raft_864x480_twenty_iterations_contractive_regime_abs_1e3(prec, dev, mo
           f"(flows up to {ref[1].abs().max().item():.1f} px; bar 1e-3 px)")
     assert ref[1].abs().max().item() > 2.0            # the loop does move the flow: not a trivially small signal
     assert e_lo < 1e-3 and e_up < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ the bench's batch sizes
+@pytest.mark.parametrize("prec", ["bf16x3"])
+def test_flow_stages_at_bench_batch_sizes_equal_small_batches(prec, dev, monkeypatch):
+    """bench_stages runs RAFT at 64 pairs per refinement batch and LAFC at 16 pivots per call (flow_pipeline.raft_pair_batch /
+    lafc_pivot_batch at 432x240); the other flow tests run batches of 3-4.  Per-row results of every kernel are independent of how many
+    rows a launch carries, so the fields must be IDENTICAL: asserted here on a 432x240 clip of 34 frames (66 pairs: one full batch of 64 +
+    a ragged one) instead of claimed from A/B runs."""
+    from fgt_amd import flow_pipeline, ops
+    monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", prec)
+    monkeypatch.setattr(ops, "DEFAULT_ATTN_PRECISION", prec)
+    H, W, N = 240, 432, 34
+    assert flow_pipeline.raft_pair_batch(H, W) == 64 and flow_pipeline.lafc_pivot_batch(H, W) == 16
+    raft = raft_model.RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).eval()
+    raft.load_state_dict(_sd("raft_state_keys.json"), strict=True)
+    raft = raft.to(dev)
+    lafc = lafc_model.Model(dict(lafc_model.DEFAULT_CONFIG)).eval()
+    lafc.load_state_dict(_sd("lafc_vanilla_state_keys.json"), strict=True)
+    lafc = lafc.to(dev)
+    g = torch.Generator().manual_seed(21)
+    base = F.avg_pool2d(torch.rand(1, 3, H + 16, W + 2 * N + 16, generator=g), 7, 1, 3)
+    frames = torch.cat([base[:, :, 8:8 + H, 8 + 2 * i:8 + 2 * i + W] for i in range(N)], 0).contiguous().to(dev) * 255.0
+    fw64, bw64 = flow_pipeline.compute_flows(raft, frames, iters=4)                      # the bench's batch (64) and encoder batch (16)
+    fw4, bw4 = flow_pipeline.compute_flows(raft, frames, iters=4, batch=4, enc_batch=3)
+    assert torch.isfinite(fw64).all() and fw64.abs().max() > 0
+    assert torch.equal(fw64, fw4) and torch.equal(bw64, bw4)
+    flows = fw64.permute(1, 0, 2, 3)[None].contiguous()
+    masks = torch.zeros(1, 1, N - 1, H, W, device=dev)
+    for i in range(N - 1):
+        masks[0, 0, i, 60 + i:150 + i, 100 + 2 * i:260 + 2 * i] = 1
+    dif = flow_pipeline.diffusion(flows, masks)
+    c16 = flow_pipeline.complete_flows(lafc, flows, masks, dif)                          # 16 pivots per call
+    c4 = flow_pipeline.complete_flows(lafc, flows, masks, dif, batch=4)
+    assert torch.isfinite(c16).all()
+    assert torch.equal(c16, c4)
+    # the precomputed-bounds path of the fill (no host read-back in the call) == the default path
+    b = ops.hole_bounds(masks[0, 0])
+    assert b is not None
+    assert torch.equal(flow_pipeline.diffusion(flows, masks, bounds=b), dif)
+    rep = ops.solver_report("laplace_fill")
+    print(f"[parity] RAFT batch 64 == batch 4 and LAFC 16 == 4 pivots at {W}x{H} ({prec}): identical; fill {rep}")
+    assert rep["solver"] == "onchip" and rep["nan_filled"] == 0

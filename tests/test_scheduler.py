@@ -221,3 +221,34 @@ def test_eight_ranks_needed_rows_exchange_matches_single_rank(n, what):
         assert rows == len(need) and rows <= 0.45 * n, f"rank {r} holds {rows} feature rows of {n} frames"
         assert nch == max(2, -(-(-(-n // world)) // 4))               # chunk count follows encode_chunk (= 4 here), at least two
         assert phases == ["blend", "encode", "exchange", "gather_wait", "windows"]
+
+
+def _worker_ag(rank, world, port, n, H, W, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FGT_EXCHANGE="allgather")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    fr, fl, ms = clip(n, H, W)
+    r = ClipRunner(_StubModel(), fr, fl, ms, rank=rank, world=world, cache_features=True, encode_chunk=4)
+    got = r.run()
+    q.put((rank, got.numpy(), r.rows, r.exchange))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world", [(80, 8), (23, 3), (5, 8)])
+def test_allgather_exchange_mode_matches_single_rank(n, world):
+    """FGT_EXCHANGE=allgather (the degraded mode for a first RCCL run: plain equal-sized all_gather_into_tensor per chunk instead of the
+    needed-rows all-to-all): same composite as one rank, also with ragged blocks (23 frames / 3 ranks) and ranks past the clip (5 / 8)."""
+    port, H, W = 35500 + (os.getpid() % 2000), 32, 48
+    fr, fl, ms = clip(n, H, W)
+    want = ClipRunner(_StubModel(), fr, fl, ms, cache_features=True).run()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_ag, args=(r, world, port, n, H, W, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = {r: (torch.from_numpy(a), rows, ex) for r, a, rows, ex in (q.get(timeout=300) for _ in range(world))}
+    [p.join(timeout=60) for p in procs]
+    for r in range(world):
+        got, rows, ex = res[r]
+        assert ex == "allgather" and rows >= n
+        assert torch.equal(got, want), f"rank {r} differs from the single-rank composite"
