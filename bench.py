@@ -511,10 +511,33 @@ def main():
             strong_err = f"{type(e).__name__}: {e}"[:300]
         dog.cancel()
 
+    # ---------------------------------------------------------------- N > 1: the flow stages of the covered chain, sharded (watchdog-guarded too)
+    pipe_sharded = None
+    if world > 1 and not args.no_c4:
+        def pipe_give_up():
+            if rank == 0:
+                hw = args.scaling == "weak" or strong_res is None
+                emit(dict(assemble(weak_res if hw else strong_res, weak=hw, strong_error=strong_err), pipeline_sharded={"error": "timed out after 300 s"}))
+            os._exit(0)
+
+        dog2 = threading.Timer(300.0, pipe_give_up)
+        dog2.daemon = True
+        dog2.start()
+        try:
+            import bench_stages
+            pipe_sharded = bench_stages.run_sharded(dev, prec, rank, world, frames=args.frames, H=args.height, W=args.width,
+                                                    fgt_ms=(1e3 * strong_res["dt"] / args.steps) if strong_res is not None else None, backend=backend)
+        except Exception as e:  # noqa: BLE001 - the side object must not take the headline down
+            pipe_sharded = {"error": f"{type(e).__name__}: {e}"[:300]}
+        dog2.cancel()
+
     if rank == 0:
         headline_weak = world == 1 or args.scaling == "weak" or strong_res is None
         out = assemble(weak_res if headline_weak else strong_res, weak=headline_weak, strong_error=strong_err)
+        if pipe_sharded is not None:
+            out["pipeline_sharded"] = pipe_sharded
         if world > 1:
+            out["feature_exchange"] = getattr(strong_res["runner"], "exchange", None) if strong_res is not None else None
             bound = ideal_speedup(n_sched, world)
             per = -(-args.frames // world)
             side = lambda res, weak: {"value": round(args.frames * args.steps / res["dt"] * (world if weak else 1), 3), "unit": "frames/s",

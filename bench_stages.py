@@ -327,3 +327,67 @@ def _cpu_legs(inp, lsd, rsd, N, H, W, comp_f, comp_b, st):
     cpu["poisson_blend"] = {"ms_per_frame": round(dt * 1e3, 1), "sample": "oracle poisson_blend (scipy LSQR at the reference's tolerances) on one frame (3 channels)",
                             "ms_per_clip_extrapolated": round(dt * 1e3 * N, 0), "gpu_speedup": round(dt * 1e3 * N / st["poisson_blend"]["ms_per_clip"], 1)}
     return cpu
+
+
+def run_sharded(dev, prec, rank, world, group=None, frames=80, H=240, W=432, fgt_ms=None, backend="nccl"):
+    """N > 1: the covered chain with every stage's units block-sharded over the ranks (fgt_amd.flow_pipeline / blending: RAFT pairs, fill
+    maps, LAFC pivots, Poisson frames; one all-gather per stage; the latency-bound gradient propagation is replicated on every rank) —
+    one warm pass (weight packing, tile tuning), then one timed pass per stage between barriers, max over ranks.  Returns on every rank
+    {stage: ms, ..., "pipeline_frames_per_s"} (strong scaling of the same 80-frame clip as `c4`)."""
+    import torch.distributed as dist
+    from fgt_amd import blending, flow_pipeline, ops, propagation
+    torch.set_grad_enabled(False)
+    saved = (ops.DEFAULT_CONV_PRECISION, ops.DEFAULT_ATTN_PRECISION)
+    ops.DEFAULT_CONV_PRECISION = ops.DEFAULT_ATTN_PRECISION = prec
+    N = frames
+    inp = stage_inputs(N, H, W)
+    lafc, lsd, raft, rsd = _models(dev)
+    kw = dict(rank=rank, world=world, group=group)
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier(group=group)
+        torch.cuda.synchronize()
+
+    def timed(fn):
+        fn()                                    # warm pass
+        barrier()
+        t0 = time.perf_counter()
+        out = fn()
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
+        return tt.item() * 1e3, out
+
+    ms = {}
+    video = inp["video"].to(dev)
+    v2 = torch.nn.functional.interpolate(video, size=(2 * H, 2 * W), mode="bilinear", align_corners=False)
+    ms[f"raft_{2 * W}x{2 * H}"], _ = timed(lambda: flow_pipeline.compute_flows(raft, v2, iters=20, **kw))
+    del v2
+    hole = inp["hole"].to(dev)
+    ffl = inp["flow_f"].to(dev).permute(1, 0, 2, 3)[None].contiguous()
+    fbl = inp["flow_b"].to(dev).permute(1, 0, 2, 3)[None].contiguous()
+    mk_f, mk_b = hole[:-1].float()[None, None], hole[1:].float()[None, None]
+    bounds = ops.hole_bounds(hole)                                           # one read-back per clip: both fills and the blend use these holes
+    t1, dif_f = timed(lambda: flow_pipeline.diffusion(ffl, mk_f, bounds=bounds, **kw))
+    t2, dif_b = timed(lambda: flow_pipeline.diffusion(fbl, mk_b, bounds=bounds, **kw))
+    ms["diffusion_fill"] = t1 + t2
+    t1, comp_f = timed(lambda: flow_pipeline.complete_flows(lafc, ffl, mk_f, dif_f, **kw))
+    t2, comp_b = timed(lambda: flow_pipeline.complete_flows(lafc, fbl, mk_b, dif_b, **kw))
+    ms["lafc"] = t1 + t2
+    gx, gy = inp["gx"].to(dev), inp["gy"].to(dev)
+    flf, flb = comp_f.permute(0, 2, 3, 1).contiguous(), comp_b.permute(0, 2, 3, 1).contiguous()
+    ms["gradient_propagation"], (pgx, pgy, tofill) = timed(lambda: propagation.propagate_gradients(gx, gy, hole, flf, flb))
+    img = inp["img"].to(dev)
+    trg = img * (~hole)[..., None]
+    ms["poisson_blend"], (blend, unf) = timed(lambda: blending.poisson_blend_clip(trg, pgx, pgy, hole, tofill, bounds=bounds, **kw))
+    out = {"stages_ms": {k: round(v, 2) for k, v in ms.items()}, "n_gpus": world,
+           "checksum": round(float(blend.double().mean()) + float(comp_f.double().abs().mean()), 6)}
+    total = sum(ms.values())
+    if fgt_ms is not None:
+        out["stages_ms"]["fgt"] = round(fgt_ms, 2)
+        total += fgt_ms
+    out["ms_per_clip"] = round(total, 1)
+    out["pipeline_frames_per_s"] = round(N / (total * 1e-3), 2)
+    ops.DEFAULT_CONV_PRECISION, ops.DEFAULT_ATTN_PRECISION = saved
+    return out

@@ -25,9 +25,13 @@ fi
 if has bench; then
   echo "== bench (default: bf16x3 headline + fp32_exact + cpu baseline)"
   timeout 900 python bench.py --steps 5 --warmup 1 > gpurun_out/bench.log 2>&1; echo "bench exit: $?" | tee -a gpurun_out/bench.log
-  grep '^{' gpurun_out/bench.log | python -c "
-import sys,json; d=json.loads(sys.stdin.read())
+  cp gpurun_out/bench_detail.json gpurun_out/bench_detail_default.json 2>/dev/null
+  tail -1 gpurun_out/bench.log | wc -c
+  python -c "
+import sys,json; d=json.load(open('gpurun_out/bench_detail.json'))
 print(d['value'],'fps', d['ms_per_step'],'ms; cpu', d.get('cpu_baseline',{}).get('value'), 'parity', d.get('parity_vs_cpu_oracle',{}).get('max_abs_diff'))
+c4=d.get('c4',{})
+print('c4', {k:{kk:vv for kk,vv in v.items() if kk.startswith('ms_per')} for k,v in c4.get('stages',{}).items()}, (c4.get('pipeline_frames_per_s') or {}).get('value'), c4.get('error'))
 for r in d.get('rooflines',[]): print('  ', r['kind'], r['frac'], r.get('algorithmic_tflops', r.get('achieved')),r['unit'], r['kernel_ms_per_step'],'ms/step', r['avg_launch_us'],'us/launch')
 for name in ('f16', 'fp32_exact'):
     f=d.get(name)
@@ -36,8 +40,10 @@ for name in ('f16', 'fp32_exact'):
         for r in f.get('rooflines',[]): print('  ', r['kind'], r['frac'], r.get('algorithmic_tflops', r.get('achieved')),r['unit'], r['kernel_ms_per_step'],'ms/step')
 " || tail -5 gpurun_out/bench.log
 fi
-if has pmc; then
-  echo "== PMC HBM traffic of the MFMA kernels over bench.py (tiles pre-seeded: only clip-pass launches in the trace)"
+if has pmc && grep -q dirty .git_head 2>/dev/null; then
+  echo "== PMC stage REFUSED: .git_head = $(cat .git_head) — profiles/kernel_traffic.json must come from a committed tree (commit, then tools/gpu.sh)"
+elif has pmc; then
+  echo "== PMC HBM traffic of the MFMA kernels over bench.py (tiles pre-seeded: only clip-pass launches in the trace; tree $(cat .git_head 2>/dev/null))"
   for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmcb_$c" -o pmc -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-prof --no-fp32-exact --no-f16 --no-c4 > "$R/gpurun_out/pmcb_$c.log" 2>&1)
     echo "pmc $c exit $?"
@@ -73,14 +79,14 @@ fi
 if has rehearse; then
   echo "== 2-rank rehearsal of bench.py on this single GPU (gloo, collectives staged through the host): strong headline + weak side object"
   FGT_BENCH_SHARE_GPU=1 FGT_BENCH_BACKEND=gloo FGT_TUNING_FILE="$PWD/gpurun_out/tuning.json" timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
-    --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-c4 --no-f16 --no-fp32-exact > gpurun_out/bench_2rank_rehearsal.log 2>&1
+    --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-fp32-exact > gpurun_out/bench_2rank_rehearsal.log 2>&1
   echo "rehearsal exit: $?"; grep '^{' gpurun_out/bench_2rank_rehearsal.log | cut -c1-1500
 fi
 if has c5; then
   echo "== BASELINE config #5 clip on one GPU (864x480x160)"
   timeout 900 python bench.py --frames 160 --height 480 --width 864 --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-exact --no-c4 > gpurun_out/bench_c5_1gpu.log 2>&1
-  grep '^{' gpurun_out/bench_c5_1gpu.log | python -c "
-import sys,json; d=json.loads(sys.stdin.read())
+  python -c "
+import sys,json; d=json.load(open('gpurun_out/bench_detail.json'))
 print(d['value'],'fps', d['ms_per_step'],'ms')
 for r in d.get('rooflines',[]): print('  ', r['kind'], r['frac'], r.get('algorithmic_tflops', r.get('achieved')),r['unit'], r['kernel_ms_per_step'],'ms/step')
 f=d.get('f16')
