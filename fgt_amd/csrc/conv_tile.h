@@ -108,7 +108,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         // paths with and without aux loads) — and on gfx9 that counter also holds the STORES until they are acknowledged: every group of
         // stores was waited for before the next one was issued, 13 k cycles for 64 KB per workgroup in the K = 512 GEMMs
         // (profiles/r02_run8_conv_trace_qkv_epilogue.txt).  AUX = 0 has no load behind its first store: the stores stream.
-        auto body = [&](auto auxc) {
+        auto body = [&](auto auxc) __attribute__((always_inline)) {
         constexpr int AUX = decltype(auxc)::value;
         // loads of UN row groups in flight together (the 128-accumulator-register tiles have little room: 2 at a time)
         // (two aux operands, each held for two groups: 2 rows at a time as well)
@@ -120,7 +120,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         // (not in the one-accumulator-tile kernels, which run at <= 85 registers: there a group's operands are requested right before use)
         constexpr bool AHEAD = TM * TN > 1;
         float4 ax1[AHEAD ? 2 : 1][UN], ax2[AHEAD ? 2 : 1][UN];
-        auto load_aux = [&](auto gc, float4 (&a1)[UN], float4 (&a2)[UN]) {
+        auto load_aux = [&](auto gc, float4 (&a1)[UN], float4 (&a2)[UN]) __attribute__((always_inline)) {
             constexpr int gi = decltype(gc)::value, i = gi / GPB, c0 = (gi % GPB) * UN;
 #pragma unroll
             for (int u0 = 0; u0 < UN; ++u0) {
