@@ -123,10 +123,18 @@ __device__ __forceinline__ void tr_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8&
 // default kernel in all four cases; 0...5 % SLOWER as first built (b = 8, t = 17: 1 142 -> 1 200 us), **8 % faster** once the timeline
 // (tools/attn_trace.py) had shown where a tile's cycles go and the LDS-DMA issue was moved behind its QK^T MFMAs (1 196 -> 1 095 us).  Off by
 // default: the full suite has not run on it; round 3 starts here.
-template <int NW, bool H, bool TEMPORAL, int NS, bool PF = false>
+// ST (round 4; bf16x3, 8 wavefronts, NS = 4): the two wavefronts of a SIMD run HALF A TILE OUT OF PHASE.  In the plain loop all eight wavefronts
+// cross one barrier per tile and then do the same thing at the same time: QK^T (24 MFMAs each), softmax (VALU, matrix pipe idle), PV (24 MFMAs);
+// the softmax of both wavefronts of a SIMD coincides, nobody feeds the pipe meanwhile.  With ST wavefronts 4-7 (one per SIMD) carry the PV
+// product of tile i-1 into the interval of tile i: G0: | QK(i) softmax(i) PV(i) |, G1: | PV(i-1) QK(i) softmax(i) | ("|" = the tile's barrier):
+// G0's softmax runs beside G1's QK^T, G1's beside G0's PV.  The values and their order per wavefront are unchanged (bit-identical); what
+// changes is the lifetime of a stage: tile i-1 is read during interval i, so the request issued in interval i is tile i+2 (two tiles in
+// flight on the four stages instead of three).
+template <int NW, bool H, bool TEMPORAL, int NS, bool PF = false, bool ST = false>
 __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     constexpr int NT = NW * 64;
     static_assert(NS >= 2 && NS <= 4, "stage ring depth");
+    static_assert(!ST || (!H && !PF && NW == 8 && NS == 4), "staggered schedule: the bf16x3 instance on 8 wavefronts and 4 stages");
     static_assert(!PF || (H && NS == 4), "fragment prefetch: fp16 instance on the 4-stage ring");
     constexpr int NPL = H ? 2 : 4;               // planes per stage
     constexpr int STAGE = NPL * PLANE;           // (shadows the namespace constant: this instance's stage)
@@ -268,7 +276,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
 
     const int ntiles = (p.n_k + KT - 1) / KT;
 #pragma unroll
-    for (int t = 0; t < NS - 1; ++t)
+    for (int t = 0; t < NS - 1 - (ST ? 1 : 0); ++t)
         if (t < ntiles) issue_tile(t);
     bf16x8 kf_pf[PF ? 8 : 1];                                               // PF: K fragments of the tile about to be multiplied
 
@@ -462,8 +470,109 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
         }
     };
     const int nfull = p.n_k / KT;                                           // tiles whose 32 keys all exist
+    if constexpr (ST) {
+        const bool g1 = wave >= 4;
+        f32x16 s;                                                           // scores, then P: G1 keeps P(i-1) across the barrier
+        auto qk_softmax = [&](const int it) __attribute__((always_inline)) {
+            const char* st = smem + (it % NS) * STAGE;
+            const int k0 = it * KT;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+            for (int sx = 0; sx < 8; ++sx) {
+                const int off = krow + (((2 * sx + lh) ^ (l31 & 15)) << 4);
+                const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(st + off);
+                const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(st + PLANE + off);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, qh[sx], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, ql[sx], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, qh[sx], s, 0, 0, 0);
+            }
+            if (it >= nfull) {                                // the last, partial tile (wave-uniform branch: full tiles carry no compare / select)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (k0 + (e & 3) + 8 * (e >> 2) + 4 * lh >= p.n_k) s[e] = -INFINITY;
+            }
+            float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+            for (int e = 2; e < 16; e += 2) mx = fmaxf(mx, fmaxf(s[e], s[e + 1]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float mc = m_new * p.scale_log2e;
+            const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, p.scale_log2e, -mc));
+            const f32x2 c2 = {p.scale_log2e, p.scale_log2e}, mc2 = {mc, mc};
+            f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 sv = {s[e], s[e + 1]};
+                const f32x2 x = __builtin_elementwise_fma(sv, c2, -mc2);
+                const f32x2 pe = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                s[e] = pe[0];
+                s[e + 1] = pe[1];
+                ps2 += pe;
+            }
+            l_run = l_run * alpha + (ps2[0] + ps2[1]);
+            m_run = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
+            }
+        };
+        auto pv = [&](const int it) __attribute__((always_inline)) {
+            const char* st = smem + (it % NS) * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+                split2(s[8 * ks + 0], s[8 * ks + 1], h0, l0); split2(s[8 * ks + 2], s[8 * ks + 3], h1, l1);
+                split2(s[8 * ks + 4], s[8 * ks + 5], h2, l2); split2(s[8 * ks + 6], s[8 * ks + 7], h3, l3);
+                const bf16x8 p_h = as_bf16x8(h0, h1, h2, h3), p_l = as_bf16x8(l0, l1, l2, l3);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int seg = (t * 2 + (gi & 1)) ^ (vrow_in << 1);
+                    const int r0 = 16 * ks + 4 * (gi >> 1) + vrow_in;
+                    const int a0 = r0 * 256 + seg * 32 + vword * 8, a1 = a0 + 8 * 256;
+                    bf16x8 v_h = tr_pair(st + VOFF + a0, st + VOFF + a1);
+                    bf16x8 v_l = tr_pair(st + VOFF + PLANE + a0, st + VOFF + PLANE + a1);
+                    tr_wait(v_h, v_l);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_l, p_h, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h, p_l, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h, p_h, o[t], 0, 0, 0);
+                }
+            }
+        };
+        // One code site each for QK^T + softmax and for PV: G0 runs  | QK(i) PV(i) |, G1 runs  QK(i) | PV(i)  with its barrier BETWEEN the
+        // two — i.e. | PV(i-1) QK(i) | per interval — and one barrier more in front (G0 passes its extra one behind the loop).  Requests: tile
+        // i+2 right behind barrier i (its stage held tile i-2: G0 left it in interval i-2, G1 in interval i-1); the two groups' request
+        // cursors advance in the same order, G1's one tile ahead of its QK^T.
+        if (g1) {
+            if (1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                     // barrier 0
+            if (2 < ntiles) issue_tile(2 % NS);
+        }
+        for (int it = 0; it < ntiles; ++it) {
+            if (!g1) {
+                // tile `it` has landed (this wavefront's pieces); tile it+1 may stay in flight across the barrier
+                if (it + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                 // barrier it
+                if (it + 2 < ntiles) issue_tile((it + 2) % NS);
+            }
+            qk_softmax(it);
+            if (g1) {
+                // tile it+1 has landed (tile it+2, requested behind barrier it, may stay in flight)
+                if (it + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                 // barrier it+1
+                if (it + 3 < ntiles) issue_tile((it + 3) % NS);
+            }
+            pv(it);
+        }
+        if (!g1) __builtin_amdgcn_s_barrier();                // (G1 passed barrier `ntiles`)
+    } else {
     for (int it = 0; it < nfull; ++it) tile_step(it, std::false_type{});
     if (nfull < ntiles) tile_step(nfull, std::true_type{});
+    }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / l_tot;
@@ -508,6 +617,25 @@ dim3 attn_grid(AttnS& q, int gx, int gy) {
     q.gx = gx; q.gy = gy;
     q.per_xcd = (xcd && gx > 1) ? cdiv(gx * gy, 8) : 0;
     return q.per_xcd ? dim3(8 * q.per_xcd) : dim3(gx, gy);
+}
+
+template <int NW, bool H, bool TEMPORAL>
+int launch_mode(const AttnS& p, int problems, hipStream_t s);
+
+// bf16x3, long zones: the staggered schedule (FGT_ATTN_STAGGER=0: the plain loop, A/B measurements); bit-identical
+int launch_staggered(const AttnS& p, int problems, hipStream_t s) {
+    constexpr int smem = 4 * 4 * PLANE;
+    static std::atomic<unsigned long long> lds_set[2];
+    AttnS q = p;
+    const dim3 grid = attn_grid(q, cdiv(p.n_q, 8 * 32), problems);
+    if (p.d.mode == 0) {
+        if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<8, false, true, 4, false, true>), smem, lds_set[0], "attn_split")) return rc;
+        hipLaunchKernelGGL((attn_split_kernel<8, false, true, 4, false, true>), grid, dim3(8 * 64), smem, s, q);
+    } else {
+        if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<8, false, false, 4, false, true>), smem, lds_set[1], "attn_split")) return rc;
+        hipLaunchKernelGGL((attn_split_kernel<8, false, false, 4, false, true>), grid, dim3(8 * 64), smem, s, q);
+    }
+    return fgt_check_launch("attn_split_kernel");
 }
 
 template <int NW, bool H, bool TEMPORAL>
@@ -574,6 +702,8 @@ int fgt_attention_split(const fgt_attn_desc* dd, const void* Q, const void* K, c
         return launch<4, true>(p, problems, s);
     }
     if (n_q <= 64) return launch<2, false>(p, problems, s);
+    static const int stagger = [] { const char* e = getenv("FGT_ATTN_STAGGER"); return e ? atoi(e) : 1; }();
+    if (big && stagger && n_k >= 3 * KT) return launch_staggered(p, problems, s);
     if (big) return launch<8, false>(p, problems, s);
     return launch<4, false>(p, problems, s);
 }

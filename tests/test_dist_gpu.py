@@ -78,7 +78,16 @@ def _flow_models(dev):
 def _flow_stages(rank, world):
     from fgt_amd import blending, flow_pipeline, ops
     torch.set_grad_enabled(False)
+    saved = (ops.DEFAULT_CONV_PRECISION, ops.DEFAULT_ATTN_PRECISION)
     ops.DEFAULT_CONV_PRECISION = ops.DEFAULT_ATTN_PRECISION = "bf16x3"
+    try:
+        return _flow_stages_body(rank, world)
+    finally:                      # (also runs in the pytest process for the single-rank reference: the mode must not leak into later tests)
+        ops.DEFAULT_CONV_PRECISION, ops.DEFAULT_ATTN_PRECISION = saved
+
+
+def _flow_stages_body(rank, world):
+    from fgt_amd import blending, flow_pipeline, ops
     dev = torch.device("cuda:0")
     raft, lafc = _flow_models(dev)
     g = torch.Generator().manual_seed(31)

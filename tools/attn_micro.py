@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--precision", default="bf16x3")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--spatial", action="store_true")
+    ap.add_argument("--b", type=int, default=1, help="windows per call (the bench batches 8 equal-length windows)")
     ap.add_argument("--split", action="store_true", help="pre-split inputs (csrc/attention_split.hip: LDS-DMA K / V tiles)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -28,12 +29,12 @@ def main():
         fn = lambda: ops.attention_spatial(q, k, v, kg, vg, bt, h, w, nh, nw, 4, 8, 60, precision=a.precision)
         flops = 4.0 * bt * 15 * 4 * 64 * 124 * 128
     else:
-        qkv = torch.randn(a.t * 720, 1536, device=dev)
+        qkv = torch.randn(a.b * a.t * 720, 1536, device=dev)
         if a.split:
             qkv = ops.split(qkv)
-        fn = lambda: ops.attention_temporal(qkv, 1, a.t, 20, 36, 4, 2, 512, precision=a.precision)
+        fn = lambda: ops.attention_temporal(qkv, a.b, a.t, 20, 36, 4, 2, 512, precision=a.precision)
         L = a.t * 180
-        flops = 4.0 * 16 * L * L * 128
+        flops = 4.0 * 16 * a.b * L * L * 128
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -44,7 +45,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
-    print(f"attention {'spatial' if a.spatial else 'temporal'} t={a.t} {a.precision}{' split-in' if a.split else ''}: {ms * 1e3:.1f} us, {flops / ms / 1e9:.1f} TFLOP/s algorithmic")
+    print(f"attention {'spatial' if a.spatial else 'temporal'} b={a.b} t={a.t} {a.precision}{' split-in' if a.split else ''}: {ms * 1e3:.1f} us, {flops / ms / 1e9:.1f} TFLOP/s algorithmic")
 
 
 if __name__ == "__main__":
