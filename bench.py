@@ -220,8 +220,12 @@ def compact_line(full, detail_path=None):
             if cpu:
                 cc["cpu_baseline"] = {"cores": cpu.get("cores"), "kind": cpu.get("kind"),
                                       "gpu_speedup": {k: v.get("gpu_speedup") for k, v in cpu.items() if isinstance(v, dict)}}
-            if "sharded" in c4:
-                cc["sharded"] = c4["sharded"]
+            c2 = c4.get("c2_spatial_mhsa")
+            if c2:
+                cc["c2_spatial_mhsa"] = {k: c2[k] for k in ("ms_per_module", "mfma_frac_module_wall", "mfma_frac_mfma_kernels_only", "mfma_frac_attention_kernel",
+                                                            "hbm_frac_attention_kernel", "linears_share_of_flops", "error") if k in c2}
+                if "fp32_exact" in c2:
+                    cc["c2_spatial_mhsa"]["fp32_exact_mfma_frac_module_wall"] = c2["fp32_exact"].get("mfma_frac_module_wall")
             line["c4"] = cc
     for k in ("phases_ms", "weak_scaling_clip_per_rank", "strong_scaling_same_clip", "strong_scaling_ideal", "pipeline_sharded", "feature_exchange"):
         if k in full:
@@ -588,7 +592,7 @@ def main():
             try:
                 import bench_stages
                 out["c4"] = bench_stages.run_stages(dev, prec, frames=args.frames, H=args.height, W=args.width, fgt_ms=out["ms_per_step"],
-                                                    with_cpu=not args.no_cpu_baseline)
+                                                    with_cpu=not args.no_cpu_baseline, fgt_model=model)
             except Exception as e:  # noqa: BLE001 - the side object must not take the headline down
                 import traceback
                 out["c4"] = {"error": f"{type(e).__name__}: {e}"[:400], "trace": traceback.format_exc()[-1200:]}

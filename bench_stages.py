@@ -107,7 +107,45 @@ def _hbm(ms, nbytes):
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM, "unit": "GB/s", "frac": round(gbs / PEAK_HBM, 4), "algorithmic_bytes": int(nbytes)}
 
 
-def run_stages(dev, prec="bf16x3", frames=80, H=240, W=432, fgt_ms=None, with_cpu=True, reps=2, fill_iters=None, blend_iters=None):
+def c2_spatial_mhsa(dev, model, prec, t=10, reps=5):
+    """BASELINE config C2: ONE spatial window MHSA module (SWMHSA: flow re-weighting Linear + sigmoid, three LayerNorms, global-token
+    depthwise pools, q / k / v Linears, window + global-token attention, output Linear; attention_flow.py:57-113) on synthetic tokens of a
+    432x240x10 clip (token grid 20x36, x, f ~ N(0,1)).  The north star's "MFMA utilisation in spatial MHSA" is a MODULE figure: 94 % of the
+    module's flops are in its Linears, so it is reported as (algorithmic flops of every MFMA launch of the module x MFMA passes) / (module
+    wall time) / peak — next to the same figure over the MFMA kernels' own time and the attention kernel's two rooflines."""
+    from fgt_amd import ops
+    saved = (ops.DEFAULT_CONV_PRECISION, ops.DEFAULT_ATTN_PRECISION)
+    ops.DEFAULT_CONV_PRECISION = ops.DEFAULT_ATTN_PRECISION = prec
+    net = model.net
+    P = net.packed()
+    th, tw = 20, 36
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(t * th * tw, 512, generator=g).to(dev)
+    f = torch.randn(t * th * tw, 256, generator=g).to(dev)
+    fn = lambda: net._spatial_attention(x, f, P["s0"], t, th, tw)
+    dt, _ = _timed(fn, reps=reps, warm=2)
+    ops.prof_collect("all")
+    ops.prof_enable(True)
+    fn()
+    _sync()
+    ops.prof_enable(False)
+    passes = 3 if prec == "bf16x3" else 1
+    peak = PEAK_FP32 if prec == "fp32" else PEAK_BF16
+    cms, cfl, cn, cby = ops.prof_collect("conv")
+    ams, afl, an, aby = ops.prof_collect("attn_spatial")
+    ops.prof_collect("all")
+    ops.DEFAULT_CONV_PRECISION, ops.DEFAULT_ATTN_PRECISION = saved
+    tf = lambda fl, ms: passes * fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return {"workload": f"one SWMHSA module, t = {t}, token grid {th}x{tw} (432x240x{t}), {prec}", "ms_per_module": round(dt * 1e3, 4),
+            "algorithmic_gflop": round((cfl + afl) / 1e9, 2), "linears_share_of_flops": round(cfl / max(cfl + afl, 1.0), 3),
+            "mfma_frac_module_wall": round(tf(cfl + afl, dt * 1e3) / peak, 4),
+            "mfma_frac_mfma_kernels_only": round(tf(cfl + afl, cms + ams) / peak, 4),
+            "mfma_frac_linears": round(tf(cfl, cms) / peak, 4), "mfma_frac_attention_kernel": round(tf(afl, ams) / peak, 4),
+            "hbm_frac_attention_kernel": round(aby / max(ams * 1e-3, 1e-12) / 1e9 / PEAK_HBM, 4),
+            "launches": {"linear_gemm": cn, "attention": an}, "peak_tflops": peak}
+
+
+def run_stages(dev, prec="bf16x3", frames=80, H=240, W=432, fgt_ms=None, with_cpu=True, reps=2, fill_iters=None, blend_iters=None, fgt_model=None):
     from fgt_amd import blending, flow_pipeline, ops, propagation
     torch.set_grad_enabled(False)
     saved = (ops.DEFAULT_CONV_PRECISION, ops.DEFAULT_ATTN_PRECISION)
@@ -116,6 +154,13 @@ def run_stages(dev, prec="bf16x3", frames=80, H=240, W=432, fgt_ms=None, with_cp
     inp = stage_inputs(N, H, W)
     lafc, lsd, raft, rsd = _models(dev)
     out = {"clip": f"{N} frames {W}x{H}", "precision": prec, "stages": {}}
+    if fgt_model is not None:
+        try:
+            out["c2_spatial_mhsa"] = c2_spatial_mhsa(dev, fgt_model, prec)
+            if prec != "fp32":
+                out["c2_spatial_mhsa"]["fp32_exact"] = {k: v for k, v in c2_spatial_mhsa(dev, fgt_model, "fp32").items() if k.startswith(("mfma_frac", "ms_per", "hbm_frac"))}
+        except Exception as e:  # noqa: BLE001
+            out["c2_spatial_mhsa"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     st = out["stages"]
     times_ms = {}
 

@@ -86,6 +86,51 @@ __global__ void __launch_bounds__(256) warp_kernel(const float* __restrict__ img
     }
 }
 
+// C = 2 (flow fields, the forward-backward check's operands): TWO adjacent pixels per work item — one 16-byte flow load, eight 8-byte tap
+// loads in flight together, one 16-byte store.  Same arithmetic per pixel as warp_kernel<2>.
+__global__ void __launch_bounds__(256) warp_c2x2_kernel(const float* __restrict__ img, const float* __restrict__ flow, int B, int H, int W,
+                                                        int align_corners, int absolute, float* __restrict__ out) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const long total = (long)B * H * W / 2;
+    for (long item = (long)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (long)gridDim.x * blockDim.x) {
+        const long pix = item * 2;
+        const int x = (int)(pix % W); const long r = pix / W;
+        const int y = (int)(r % H); const long b = r / H;
+        const f4 fl = __builtin_nontemporal_load(reinterpret_cast<const f4*>(flow + pix * 2));
+        const float* base = img + b * H * W * 2;
+        float2 tap[2][4];
+        float wgt[2][4];
+        bool val[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float ix, iy;
+            sample_coord(q ? fl.z : fl.x, q ? fl.w : fl.y, x + q, y, W, H, align_corners, absolute, ix, iy);
+            const Bilin bl = bilin(ix, iy);
+            const bool vx0 = bl.x0 >= 0 && bl.x0 < W, vx1 = bl.x0 + 1 >= 0 && bl.x0 + 1 < W;
+            const bool vy0 = bl.y0 >= 0 && bl.y0 < H, vy1 = bl.y0 + 1 >= 0 && bl.y0 + 1 < H;
+            const int cx0 = min(max(bl.x0, 0), W - 1), cx1 = min(max(bl.x0 + 1, 0), W - 1);
+            const int cy0 = min(max(bl.y0, 0), H - 1), cy1 = min(max(bl.y0 + 1, 0), H - 1);
+            tap[q][0] = *reinterpret_cast<const float2*>(base + ((long)cy0 * W + cx0) * 2);
+            tap[q][1] = *reinterpret_cast<const float2*>(base + ((long)cy0 * W + cx1) * 2);
+            tap[q][2] = *reinterpret_cast<const float2*>(base + ((long)cy1 * W + cx0) * 2);
+            tap[q][3] = *reinterpret_cast<const float2*>(base + ((long)cy1 * W + cx1) * 2);
+            wgt[q][0] = bl.wnw; wgt[q][1] = bl.wne; wgt[q][2] = bl.wsw; wgt[q][3] = bl.wse;
+            val[q][0] = vx0 && vy0; val[q][1] = vx1 && vy0; val[q][2] = vx0 && vy1; val[q][3] = vx1 && vy1;
+        }
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a += (val[q][k] ? (u ? tap[q][k].y : tap[q][k].x) : 0.f) * wgt[q][k];
+                o[q * 2 + u] = a;
+            }
+        __builtin_nontemporal_store(f4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f4*>(out + pix * 2));
+    }
+}
+
 __device__ __forceinline__ void warp2(const float* src, const float* flw, long b, int x, int y, int H, int W, float& ox, float& oy) {
     const long pix = (b * H + y) * W + x;
     float ix, iy;
@@ -306,6 +351,11 @@ extern "C" int fgt_warp(const float* img, int ldi, const float* flow, int B, int
     FgtProfScope prof(FGT_PROF_WARP, 0.0, 4.0 * (double)B * H * W * (2.0 * C + 2.0), stream);
     const auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
     FGT_REQUIRE(al(flow, 8), "fgt_warp: flow must be 8-byte aligned");
+    if (C == 2 && ldi == 2 && ldo == 2 && W % 2 == 0 && al(img, 8) && al(flow, 16) && al(out, 16)) {
+        hipLaunchKernelGGL(warp_c2x2_kernel, dim3(grid_for((long)B * H * W / 2)), dim3(256), 0, (hipStream_t)stream, img, flow, B, H, W, align_corners,
+                           absolute_coords, out);
+        return fgt_check_launch("warp");
+    }
     const int V = (C % 4 == 0 && ldi % 4 == 0 && ldo % 4 == 0 && al(img, 16) && al(out, 16)) ? 4
                 : (C % 2 == 0 && ldi % 2 == 0 && ldo % 2 == 0 && al(img, 8) && al(out, 8)) ? 2 : 1;
     const long items = (long)B * H * W * (C / V);

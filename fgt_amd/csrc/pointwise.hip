@@ -1,6 +1,7 @@
 // Bandwidth-bound kernels of the FGT path: LayerNorm, depthwise convs, fold (overlap-add gather),
 // layout packing, zero padding, axpby and the tool's compose/blend step.  All are HBM-bound:
 // float4 accesses along the channel dimension of channels-last tensors, one pass over the data.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -15,17 +16,28 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ps == -1: `out` is one fp16 plane (offsets in fp16 elements)
 // ps == 32: the INTERLEAVED split layout (fgt_conv_desc.in_split = 2): channel c of a row lives at element (c / 32) * 64 + c % 32 (hi) and 32
 // further (lo) — `off` is then row * ld + c with ld the row stride in elements (>= 2 * C) and c the LOGICAL channel, passed separately
+template <bool NT = false>
 __device__ __forceinline__ void store_f32_or_split(float* out, long off, long ps, const float4 v, int c = 0) {
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
     if (ps < 0) {
-        *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(out) + off) = fgt_half4(v);
+        const uint2 h = fgt_half4(v);
+        if constexpr (NT) __builtin_nontemporal_store(nt_u2{h.x, h.y}, reinterpret_cast<nt_u2*>(reinterpret_cast<__bf16*>(out) + off));
+        else *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(out) + off) = h;
     } else if (ps > 0) {
         uint2 hi, lo;
         fgt_split4(v, hi, lo);
         __bf16* o = reinterpret_cast<__bf16*>(out) + (ps == 32 ? off - c + ((c >> 5) << 6) + (c & 31) : off);
-        *reinterpret_cast<uint2*>(o) = hi;
-        *reinterpret_cast<uint2*>(o + ps) = lo;
+        if constexpr (NT) {
+            __builtin_nontemporal_store(nt_u2{hi.x, hi.y}, reinterpret_cast<nt_u2*>(o));
+            __builtin_nontemporal_store(nt_u2{lo.x, lo.y}, reinterpret_cast<nt_u2*>(o + ps));
+        } else {
+            *reinterpret_cast<uint2*>(o) = hi;
+            *reinterpret_cast<uint2*>(o + ps) = lo;
+        }
     } else {
-        *reinterpret_cast<float4*>(out + off) = v;
+        if constexpr (NT) __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f4*>(out + off));
+        else *reinterpret_cast<float4*>(out + off) = v;
     }
 }
 
@@ -34,6 +46,7 @@ __device__ __forceinline__ void store_f32_or_split(float* out, long off, long ps
 //  chip of one-row wavefronts holds 16 MB in flight, about what 8 TB/s x 2 us needs; per-row arithmetic is unchanged)
 constexpr int LN_MAXV = 4;  // float4 per lane -> C <= 1024
 constexpr int LN_R = 2;
+template <bool NT>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1,
                                                         long rows, float eps, const float* gA, const float* bA, float* outA,
                                                         int ldA, const float* gB, const float* bB, float* outB, int ldB,
@@ -52,8 +65,14 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* x0, int C0,
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = (lane + 64 * i) * 4;
             if (c < C) {
-                v[r][i] = c < C0 ? *reinterpret_cast<const float4*>(x0 + row * ld0 + c)
-                                 : *reinterpret_cast<const float4*>(x1 + row * ld1 + (c - C0));
+                typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                const float* src = c < C0 ? x0 + row * ld0 + c : x1 + row * ld1 + (c - C0);
+                if constexpr (NT) {
+                    const nt_f4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(src));
+                    v[r][i] = make_float4(t.x, t.y, t.z, t.w);
+                } else {
+                    v[r][i] = *reinterpret_cast<const float4*>(src);
+                }
             } else {
                 v[r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -83,10 +102,10 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* x0, int C0,
                 const float4 n = make_float4((v[r][i].x - mean) * rstd, (v[r][i].y - mean) * rstd, (v[r][i].z - mean) * rstd,
                                              (v[r][i].w - mean) * rstd);
                 const float4 g = *reinterpret_cast<const float4*>(gA + c), b = *reinterpret_cast<const float4*>(bA + c);
-                store_f32_or_split(outA, row * ldA + c, psA, make_float4(n.x * g.x + b.x, n.y * g.y + b.y, n.z * g.z + b.z, n.w * g.w + b.w), c);
+                store_f32_or_split<NT>(outA, row * ldA + c, psA, make_float4(n.x * g.x + b.x, n.y * g.y + b.y, n.z * g.z + b.z, n.w * g.w + b.w), c);
                 if (outB) {
                     const float4 g2 = *reinterpret_cast<const float4*>(gB + c), b2 = *reinterpret_cast<const float4*>(bB + c);
-                    store_f32_or_split(outB, row * ldB + c, psB, make_float4(n.x * g2.x + b2.x, n.y * g2.y + b2.y, n.z * g2.z + b2.z, n.w * g2.w + b2.w), c);
+                    store_f32_or_split<NT>(outB, row * ldB + c, psB, make_float4(n.x * g2.x + b2.x, n.y * g2.y + b2.y, n.z * g2.z + b2.z, n.w * g2.w + b2.w), c);
                 }
             }
         }
@@ -467,8 +486,14 @@ extern "C" int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, 
                 "fgt_layernorm: an interleaved output (ps = 32) needs C %% 32 == 0 and a row stride of at least 2 * C elements");
     const auto ob = [](long long ps) { return ps < 0 ? 2.0 : 4.0; };
     FgtProfScope prof(FGT_PROF_LAYERNORM, 0.0, (double)rows * ((C0 + C1) * 4.0 + (C0 + C1) * (ob(psA) + (outB ? ob(psB) : 0.0))), stream);
-    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4 * LN_R)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, rows,
-                       eps, gA, bA, outA, ldA, gB, bB, outB, ldB, (long)psA, (long)psB);
+    // FGT_LN_NT (default 1): non-temporal loads / stores — the rows are read once and the outputs are consumed by the NEXT kernel (A/B: =0)
+    static const int nt = [] { const char* e = getenv("FGT_LN_NT"); return e ? atoi(e) : 1; }();
+    if (nt)
+        hipLaunchKernelGGL(layernorm_kernel<true>, dim3(cdiv(rows, 4 * LN_R)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, rows,
+                           eps, gA, bA, outA, ldA, gB, bB, outB, ldB, (long)psA, (long)psB);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<false>, dim3(cdiv(rows, 4 * LN_R)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, rows,
+                           eps, gA, bA, outA, ldA, gB, bB, outB, ldB, (long)psA, (long)psB);
     return fgt_check_launch("layernorm");
 }
 

@@ -84,6 +84,25 @@ def test_warp_and_fb_consistency_match_reference_golden(dev):
     assert mism < 2e-3                       # thresholded output: only pixels within round-off of the threshold may flip
 
 
+@pytest.mark.parametrize("C,H,W", [(2, 24, 40), (2, 17, 33), (3, 24, 40), (4, 9, 14), (8, 16, 20), (6, 11, 13)])
+def test_warp_every_vector_width_matches_oracle(C, H, W, dev):
+    """fgt_warp picks its access width from C and the alignment (C = 2 with even W: two pixels per work item; C % 4 == 0: 16-byte accesses;
+    C % 2 == 0: 8-byte; else scalar): every path against the oracle's image_warp (LAFC/models/utils/fbConsistencyCheck.py:8-26), incl.
+    flows that leave the image (zeros padding) and a channel slice of a wider buffer."""
+    from fgt_amd import ops
+    g = torch.Generator().manual_seed(100 + C + W)
+    B = 3
+    img = torch.randn(B, C, H, W, generator=g)
+    flow = torch.randn(B, 2, H, W, generator=g) * 6.0
+    ref = RO.image_warp(img, flow)
+    nhwc = lambda x: x.permute(0, 2, 3, 1).contiguous().to(dev)
+    out = ops.warp(nhwc(img), nhwc(flow))
+    assert report(f"image_warp C={C} {W}x{H}", out.permute(0, 3, 1, 2), ref)[0] < 1e-5
+    wide = torch.zeros(B, H, W, C + 5, device=dev)
+    wide[..., 1:1 + C] = nhwc(img)
+    assert torch.equal(ops.warp(wide[..., 1:1 + C], nhwc(flow)), out)          # an unaligned channel slice: the scalar path, same values
+
+
 def test_raft_helper_kernels(dev):
     from fgt_amd import ops
     g = torch.Generator().manual_seed(3)
