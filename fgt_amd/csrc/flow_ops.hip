@@ -75,11 +75,11 @@ __global__ void __launch_bounds__(256) warp_kernel(const float* __restrict__ img
         vec v;
 #pragma unroll
         for (int u = 0; u < V; ++u) {
-            float a = 0.f;
-            a += ((vx0 && vy0) ? nw[u] : 0.f) * bl.wnw;
-            a += ((vx1 && vy0) ? ne[u] : 0.f) * bl.wne;
-            a += ((vx0 && vy1) ? sw[u] : 0.f) * bl.wsw;
-            a += ((vx1 && vy1) ? se[u] : 0.f) * bl.wse;
+            // (explicit fused multiply-adds: every access-width variant of this kernel rounds identically)
+            float a = __builtin_fmaf((vx0 && vy0) ? nw[u] : 0.f, bl.wnw, 0.f);
+            a = __builtin_fmaf((vx1 && vy0) ? ne[u] : 0.f, bl.wne, a);
+            a = __builtin_fmaf((vx0 && vy1) ? sw[u] : 0.f, bl.wsw, a);
+            a = __builtin_fmaf((vx1 && vy1) ? se[u] : 0.f, bl.wse, a);
             v[u] = a;
         }
         __builtin_nontemporal_store(v, reinterpret_cast<vec*>(out + pix * ldo + c));
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256) warp_c2x2_kernel(const float* __restrict_
             for (int u = 0; u < 2; ++u) {
                 float a = 0.f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) a += (val[q][k] ? (u ? tap[q][k].y : tap[q][k].x) : 0.f) * wgt[q][k];
+                for (int k = 0; k < 4; ++k) a = __builtin_fmaf(val[q][k] ? (u ? tap[q][k].y : tap[q][k].x) : 0.f, wgt[q][k], a);
                 o[q * 2 + u] = a;
             }
         __builtin_nontemporal_store(f4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f4*>(out + pix * 2));
