@@ -2,7 +2,7 @@
 # One GPU-box visit: parity tests, smoke, bench (headline + fp32_exact + cpu baseline in one line), PMC traffic of the MFMA
 # kernels with pre-seeded tiles, rocprofv3 kernel stats, attention micro-benchmarks, 2-rank rehearsal.  Everything lands in
 # gpurun_out/.   usage (from the repo root on the GPU box):  bash tools/gpu_check.sh [stages]
-#   stages: any of  test smoke bench pmc pmc16 stats attn rehearse c5 flow   (default: test smoke bench pmc stats attn rehearse)
+#   stages: any of  test smoke bench pmc pmc16 stats stats16 attn rehearse c5 flow   (default: test smoke bench pmc stats attn rehearse)
 set -u
 STAGES="${*:-test smoke bench pmc stats attn rehearse}"
 has() { [[ " $STAGES " == *" $1 "* ]]; }
@@ -65,6 +65,8 @@ if has stats; then
   echo "rocprof exit: $?"
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" gpurun_out/kernel_stats.csv && cut -c1-170 "$f" | head -22
+fi
+if has stats16; then
   echo "== rocprofv3 kernel stats, f16 mode"
   rm -rf gpurun_out/prof_f16
   (cd /tmp && FGT_TUNING_FILE="$R/gpurun_out/tuning.json" timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_f16" -o fgt -- python "$R/bench.py" --precision f16 --steps 2 --warmup 0 --no-cpu-baseline --no-prof --no-c4 --no-fp32-exact > "$R/gpurun_out/rocprof_f16.log" 2>&1)
