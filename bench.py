@@ -212,7 +212,7 @@ def compact_line(full, detail_path=None):
                     else:
                         e["frac"] = rl.get("frac")
                 st[k] = e
-            cc = {"stages": st, "pipeline_frames_per_s": (c4.get("pipeline_frames_per_s") or {}).get("value"),
+            cc = {"stages": st, "checksum": c4.get("checksum"), "pipeline_frames_per_s": (c4.get("pipeline_frames_per_s") or {}).get("value"),
                   "pipeline_ms_per_clip": (c4.get("pipeline_frames_per_s") or {}).get("ms_per_clip"),
                   "rooflines": [{"kind": _short(x["kind"], 40), "bound": x["bound"], "frac": x["frac"], "achieved": x["achieved"], "unit": x["unit"]}
                                 for x in c4.get("rooflines", [])]}

@@ -237,6 +237,8 @@ def run_stages(dev, prec="bf16x3", frames=80, H=240, W=432, fgt_ms=None, with_cp
     st["poisson_blend"] = {"ms_per_clip": round(dtb * 1e3, 2), "problems": 3 * N, "hole_px_per_frame": int(hole_px), "solver": blend_info,
                            "roofline": _hbm(dtb * 1e3, blend_bytes)}
     times_ms["poisson_blend"] = dtb * 1e3
+    # the same figure `run_sharded` prints at N > 1: equal checksums = the sharded chain reproduced this one
+    out["checksum"] = round(float(blend.double().mean()) + float(comp_f.double().abs().mean()), 6)
     if fgt_ms is not None:
         st["fgt"] = {"ms_per_clip": round(fgt_ms, 2), "note": "the headline of this line (one clip pass)"}
         times_ms["fgt"] = fgt_ms
