@@ -130,7 +130,11 @@ __device__ __forceinline__ void tr_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8&
 // G0's softmax runs beside G1's QK^T, G1's beside G0's PV.  The values and their order per wavefront are unchanged (bit-identical); what
 // changes is the lifetime of a stage: tile i-1 is read during interval i, so the request issued in interval i is tile i+2 (two tiles in
 // flight on the four stages instead of three).
-template <int NW, bool H, bool TEMPORAL, int NS, bool PF = false, bool ST = false>
+// VB (round 4; bf16x3): the V fragments of a k-half (4 d-blocks x hi / lo = 16 transposing reads) are requested TOGETHER and retired with
+// counted lgkmcnt waits (12 / 8 / 4 / 0: LDS returns in order) in front of each d-block's MFMA triple.  The round-2/3 loop requested one
+// d-block's four reads and waited lgkmcnt(0) right behind them: eight exposed LDS round trips per tile and wavefront — the PV segment of
+// the timeline (profiles/r02_run12_attn_trace.txt) took 1 824 cycles for 768 cycles of MFMAs.  Same values, same order per accumulator.
+template <int NW, bool H, bool TEMPORAL, int NS, bool PF = false, bool ST = false, bool VB = false>
 __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
     constexpr int NT = NW * 64;
     static_assert(NS >= 2 && NS <= 4, "stage ring depth");
@@ -450,8 +454,35 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_split_kernel(const AttnS p) {
                     o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vf[t]), __builtin_bit_cast(f16x8, p_h), o[t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (!H && VB) {
+                bf16x8 v_h[4], v_l[4];
 #pragma unroll
-            for (int t = 0; t < (H ? 0 : 4); ++t) {
+                for (int t = 0; t < 4; ++t) {
+                    const int seg = (t * 2 + (gi & 1)) ^ (vrow_in << 1);
+                    const int r0 = 16 * ks + 4 * (gi >> 1) + vrow_in;
+                    const int a0 = r0 * 256 + seg * 32 + vword * 8, a1 = a0 + 8 * 256;
+                    v_h[t] = tr_pair(st + VOFF + a0, st + VOFF + a1);
+                    v_l[t] = tr_pair(st + VOFF + PLANE + a0, st + VOFF + PLANE + a1);
+                }
+                asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(v_h[0]), "+v"(v_l[0]));
+                o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_l[0], p_h, o[0], 0, 0, 0);
+                o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h[0], p_l, o[0], 0, 0, 0);
+                o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h[0], p_h, o[0], 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(v_h[1]), "+v"(v_l[1]));
+                o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_l[1], p_h, o[1], 0, 0, 0);
+                o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h[1], p_l, o[1], 0, 0, 0);
+                o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h[1], p_h, o[1], 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(v_h[2]), "+v"(v_l[2]));
+                o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_l[2], p_h, o[2], 0, 0, 0);
+                o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h[2], p_l, o[2], 0, 0, 0);
+                o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h[2], p_h, o[2], 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v_h[3]), "+v"(v_l[3]));
+                o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_l[3], p_h, o[3], 0, 0, 0);
+                o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h[3], p_l, o[3], 0, 0, 0);
+                o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_h[3], p_h, o[3], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < ((H || VB) ? 0 : 4); ++t) {
                 // run 0: keys 16ks + 4lh + (0..3); run 1: + 8.  row & 3 = vrow_in for both (16ks, 4lh, 8 are multiples of 4)
                 const int seg = (t * 2 + (gi & 1)) ^ (vrow_in << 1);        // swizzled 32-byte segment of d block t*32 + 16 (gi & 1)
                 const int r0 = 16 * ks + 4 * (gi >> 1) + vrow_in;
@@ -643,10 +674,20 @@ int launch_mode(const AttnS& p, int problems, hipStream_t s) {
     constexpr int NS = NW == 8 ? 4 : 2;          // long zones (one workgroup per CU): four stages = three tiles in flight
     constexpr int smem = NS * (H ? 2 : 4) * PLANE;
     static_assert(smem <= 160 * 1024, "LDS ring does not fit");
-    static std::atomic<unsigned long long> lds_set{0};
-    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<NW, H, TEMPORAL, NS>), smem, lds_set, "attn_split")) return rc;
     AttnS q = p;
     const dim3 grid = attn_grid(q, cdiv(p.n_q, NW * 32), problems);
+    if constexpr (!H) {
+        // FGT_ATTN_VBATCH (default 1): V fragments of a k-half requested together, counted waits (bit-identical; A/B: =0)
+        static const int vb = [] { const char* e = getenv("FGT_ATTN_VBATCH"); return e ? atoi(e) : 1; }();
+        if (vb) {
+            static std::atomic<unsigned long long> lds_set_vb{0};
+            if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<NW, H, TEMPORAL, NS, false, false, true>), smem, lds_set_vb, "attn_split")) return rc;
+            hipLaunchKernelGGL((attn_split_kernel<NW, H, TEMPORAL, NS, false, false, true>), grid, dim3(NW * 64), smem, s, q);
+            return fgt_check_launch("attn_split_kernel");
+        }
+    }
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&attn_split_kernel<NW, H, TEMPORAL, NS>), smem, lds_set, "attn_split")) return rc;
     hipLaunchKernelGGL((attn_split_kernel<NW, H, TEMPORAL, NS>), grid, dim3(NW * 64), smem, s, q);
     return fgt_check_launch("attn_split_kernel");
 }

@@ -33,7 +33,7 @@ bool fgt_conv_taps_eligible(const ConvP& p);     // the kernel can run the layer
 bool fgt_conv_taps_preferred(const ConvP& p);    // ... and tile = 0 routes the layer to it
 int fgt_conv_taps_launch(int tile, const ConvP& p, hipStream_t s);
 // conv_taps_pp.hip: the same arithmetic on 256 x {128, 256} tiles with two ping-pong wavefront groups (tile codes 200 + FGT_TILE_256x128 / FGT_TILE_256x256_P8)
-int fgt_conv_taps_pp_launch(int bn, const ConvP& p, hipStream_t s);
+int fgt_conv_taps_pp_launch(int bn, int sched, const ConvP& p, hipStream_t s);     // sched 0: ping-pong groups, 1: interleaved requests
 // diag/conv_taps_breg.hip (diagnostic builds only): the same with the weight fragments loaded straight into registers (w_il = 2, tile code - 300)
 int fgt_conv_taps_breg_launch(int tile, const ConvP& p, hipStream_t s);
 

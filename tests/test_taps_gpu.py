@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 from fgt_amd import _lib
 
-TAPS = ["128x128x8t", "128x128t", "128x64t", "128x64x8t", "64x64t", "256x128pt", "256x256pt"]      # ...pt: conv_taps_pp.hip (256-row tiles, ping-pong wavefront groups)
-PP_ONLY_KX = ("256x128pt", "256x256pt")            # the ping-pong tiles serve the kx-reuse geometry only: no k x 1 (transposed) layers, no upsampling
+TAPS = ["128x128x8t", "128x128t", "128x64t", "128x64x8t", "64x64t", "256x128pt", "256x256pt", "256x128it", "256x256it"]      # ...pt: conv_taps_pp.hip (256-row tiles, ping-pong wavefront groups)
+PP_ONLY_KX = ("256x128pt", "256x256pt", "256x128it", "256x256it")            # the ping-pong tiles serve the kx-reuse geometry only: no k x 1 (transposed) layers, no upsampling
 if "diag" in _lib.LIB_PATH:        # diagnostic builds: the same kernel with register-fed weights (csrc/diag/conv_taps_breg.hip), bit-identical
     TAPS += ["128x128x8r", "128x128r", "128x64r", "64x64r"]
 
