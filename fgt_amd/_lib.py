@@ -22,7 +22,7 @@ TILE = {"auto": 0, None: 0, "128x128": 1, "128x64": 2, "64x64": 3, "128x32": 4, 
         "128x128w": 101, "128x64w": 102, "64x64w": 103, "128x32w": 104, "256x128w": 105, "128x128x8w": 106, "256x128x16w": 107, "256x64x8w": 108,
         "128x128eaw": 126, "128x64eaw": 127, "64x64eaw": 128, "128x128x8eaw": 129, "256x128x16eaw": 130, "256x64x8eaw": 131, "256x128eaw": 138,
         "256x256p8w": 117, "256x128p8w": 118,     # bf16x3 on interleaved inputs only (csrc/conv_wide.hip)
-        "128x128t": 201, "128x64t": 202, "64x64t": 203, "128x64x8t": 204, "128x128x8t": 206, "256x128pt": 205, "256x256pt": 217, "256x128it": 218, "256x256it": 219,     # FGT_TILE_* + 200: the tap-reusing kernel (csrc/conv_taps.hip)
+        "128x128t": 201, "128x64t": 202, "64x64t": 203, "128x64x8t": 204, "128x128x8t": 206, "256x128it": 205, "256x256it": 217, "128x128it": 226,     # FGT_TILE_* + 200: the tap-reusing kernel (csrc/conv_taps.hip)
         "128x128r": 301, "128x64r": 302, "64x64r": 303, "128x128x8r": 306,     # diagnostic builds only: the same with register-fed weights (w_il = 2)
         # only in builds with -DFGT_P8_ABLATIONS (A/B + timing-only instances):
         "256x256p8n": 19, "256x256p8l": 20, "x22nodma": 22, "x23nomma": 23, "x24reads": 24, "x25locknodma": 25}

@@ -32,8 +32,9 @@ int fgt_conv_wide_launch(int tile, const ConvP& p, hipStream_t s);
 bool fgt_conv_taps_eligible(const ConvP& p);     // the kernel can run the layer (explicit +200 tiles)
 bool fgt_conv_taps_preferred(const ConvP& p);    // ... and tile = 0 routes the layer to it
 int fgt_conv_taps_launch(int tile, const ConvP& p, hipStream_t s);
-// conv_taps_pp.hip: the same arithmetic on 256 x {128, 256} tiles with two ping-pong wavefront groups (tile codes 200 + FGT_TILE_256x128 / FGT_TILE_256x256_P8)
-int fgt_conv_taps_pp_launch(int bn, int sched, const ConvP& p, hipStream_t s);     // sched 0: ping-pong groups, 1: interleaved requests
+// conv_taps_il.hip: the same arithmetic with the LDS-DMA requests of a step interleaved into its MFMAs and asm-pipelined fragment reads
+// (tile codes 200 + FGT_TILE_128x128_EA / FGT_TILE_256x128 / FGT_TILE_256x256_P8 = "128x128it" / "256x128it" / "256x256it")
+int fgt_conv_taps_il_launch(int bm, int bn, const ConvP& p, hipStream_t s);
 // diag/conv_taps_breg.hip (diagnostic builds only): the same with the weight fragments loaded straight into registers (w_il = 2, tile code - 300)
 int fgt_conv_taps_breg_launch(int tile, const ConvP& p, hipStream_t s);
 

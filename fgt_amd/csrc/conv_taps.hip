@@ -359,10 +359,10 @@ int fgt_conv_taps_launch(int tile, const ConvP& p, hipStream_t s) {
         case FGT_TILE_128x64: return launch<128, 64, 2, 2, 2>(p, s);
         case FGT_TILE_64x64: return launch<64, 64, 2, 2, 2>(p, s);
         case FGT_TILE_128x32: return launch<128, 64, 4, 2, 6>(p, s);          // "128x64x8t": 128x64 on 8 wavefronts of 32x32, three workgroups per CU
-        case FGT_TILE_256x128: return fgt_conv_taps_pp_launch(128, 0, p, s);     // "256x128pt" / "256x256pt": 256-row tiles, two ping-pong wavefront groups
-        case FGT_TILE_256x256_P8: return fgt_conv_taps_pp_launch(256, 0, p, s);  //   (conv_taps_pp.hip; bit-identical to the tiles above)
-        case FGT_TILE_256x128_P8: return fgt_conv_taps_pp_launch(128, 1, p, s);  // "256x128it" / "256x256it": the same tiles, requests interleaved with the MFMAs
-        case FGT_TILE_256x256_P8N: return fgt_conv_taps_pp_launch(256, 1, p, s);
+        // "...it" tiles: the same arithmetic with the requests interleaved into the matrix work (conv_taps_il.hip; bit-identical to the tiles above)
+        case FGT_TILE_256x128: return fgt_conv_taps_il_launch(256, 128, p, s);      // "256x128it"
+        case FGT_TILE_256x256_P8: return fgt_conv_taps_il_launch(256, 256, p, s);   // "256x256it"
+        case FGT_TILE_128x128_EA: return fgt_conv_taps_il_launch(128, 128, p, s);   // "128x128it"
         default: fgt_set_error("fgt_conv2d: tile %d is not built for the tap-reusing kernel", tile + FGT_TILE_TAPS); return FGT_EINVAL;
     }
 }

@@ -1,0 +1,429 @@
+// Round 4.  The tap-reusing bf16x3 convolution (conv_taps.hip) with the requests of a step INTERLEAVED into its matrix work (gfx950).
+//
+// conv_taps.hip's step is a serial chain per wavefront — fragment reads | barrier | LDS-DMA issue | MFMAs | wait | barrier — that only OTHER
+// wavefronts fill (4 per SIMD at <= 128 registers: the matrix pipe ends 52-58 % busy).  What this round measured about the links of that chain
+// (NOTEBOOK §11.3; tools/pp_trace.py, tools/micro/dma_issue.hip):
+//   * hipcc, left to itself, hoists ALL fragment reads of a step above its first MFMA and waits lgkmcnt(0): 700 cycles of LDS round trips in
+//     front of 768 cycles of MFMAs.  Reads as inline assembly with hand-counted lgkmcnt, one sub-step (12 MFMAs) ahead, run UNDER the MFMAs:
+//     36 cycles per MFMA (32 = the pipe's rate).
+//   * an LDS-DMA instruction is accepted in ~24 cycles while <= 32 are outstanding on the CU and in 200-600 cycles when every wavefront
+//     issues its share at once behind a barrier (the queue is full; the CU retires one 16-row x 64-byte piece per ~37 cycles from L2).  Spread
+//     over the step — one piece per ~6-9 MFMAs of a wavefront — the queue never fills and the issue sits in the shadow of the MFMAs.
+//   * with the requests of step s+1 issued DURING step s (behind its first sub-steps) and waited for at its end, ONE barrier per step is
+//     enough on two stages: what a step reads was published by the barrier before it, what it requests is read after the barrier behind it.
+//   * what remains per step is the ~500-600 cycles from the barrier to the first MFMA (every wavefront's first 8 ds_read_b128 at once: 64 KB
+//     through the LDS) and ~300 cycles of tail + barrier.  Two workgroups per CU (the 128-row tile) fill these gaps for each other; the
+//     256-row tiles (one workgroup per CU, half the bytes per flop) do not.
+// The first design of this file split the 8 wavefronts of a 256-row tile into two ping-pong groups (one computes a whole step while the other
+// requests): six versions, all within -50 ... +3 % of conv_taps.hip — a wavefront that requests 10 pieces at once waits 2 000-3 000 cycles for
+// the queue whoever its partner is (profiles/r04_run5...12_pp_trace*.txt, git history).
+//
+// Tiles: BM x BN on BM / 32 wavefronts of 64 x 64 (BN = 128) or 128 x 64 (BN = 256):
+//   128 x 128, 4 wavefronts, 68 KB of LDS: two workgroups per CU        ("128x128it")
+//   256 x 128, 8 wavefronts, 100 KB; 256 x 256, 8 wavefronts, 132 KB: one workgroup per CU  ("256x128it", "256x256it")
+// Step (kx tap of a (ky, 32-channel chunk) super-step) of every wavefront:
+//   | first reads ... then per group of four MFMAs ONE request behind it: the B(s+1) pieces first, then this tap's A(ss+1) pieces; behind the
+//     last group the next step's fragment addresses; vmcnt(this step's A pieces) | barrier
+// Normal mode only (the reused taps are the kx taps of a stride-1 "same" convolution): the transposed k x 1 mode and the nearest-x2 upsampling
+// stay on conv_taps.hip's tiles (fgt_conv_taps_il_launch declines them).  The request path is written for few live scalars: its first version
+// kept conv_taps.hip's generality and executed ~200 v_readlane reloads of spilled SGPRs per step.
+//
+// Numerics: the products and the accumulation order of conv_taps.hip ((ky, chunk, kx); per accumulator and k-half lo*hi, hi*lo, hi*hi):
+// BIT-IDENTICAL to its tiles (tests/test_taps_gpu.py), so the autotuner chooses among all of them (routing stays by geometry).
+// LDS: B stages [2][hi BN | lo BN] x 64-byte rows, A buffers [2][hi: BM + 16 rows + zero row | lo: ...].
+#include "conv_tile.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int MAXA> __device__ __forceinline__ void wait_vmcnt_upto(int na) {     // vmcnt(na), na wave-uniform in [0, MAXA]
+    if constexpr (MAXA == 0) wait_vmcnt<0>();
+    else {
+        if (na == MAXA) wait_vmcnt<MAXA>();
+        else wait_vmcnt_upto<MAXA - 1>(na);
+    }
+}
+
+constexpr int HALO = 16;          // extra A rows per (ky, chunk): (kw - 1) * dw <= 16
+
+#ifdef FGT_PP_TRACE
+// Diagnostic builds only (fgt_amd.build.build(variant="pptrace", extra_flags=["-DFGT_PP_TRACE"]), tools/pp_trace.py): s_memtime stamps of one
+// workgroup's wavefronts over the first PP_TR_STEPS steps: [wave][step][0: step top, 5: first MFMA about to issue, 6: last MFMA issued,
+// 3: requests waited for (before the barrier), 4: behind the barrier].  FGT_CONV_PIPE=2: no LDS-DMA in the loop (timing only).
+constexpr int PP_TR_STEPS = 24;
+__device__ unsigned long long fgt_pp_trace_buf[8 * PP_TR_STEPS * 10];
+#define PP_STAMP(slot)                                                                                       \
+    do {                                                                                                     \
+        if (blockIdx.x == 8 && blockIdx.y == 0 && tr_step < PP_TR_STEPS) {                                   \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                      \
+            if (lane == 0) fgt_pp_trace_buf[(wave * PP_TR_STEPS + tr_step) * 10 + (slot)] = t_;               \
+        }                                                                                                    \
+    } while (0)
+#else
+#define PP_STAMP(slot) do {} while (0)
+#endif
+
+template <int BM, int BN, int KW>
+__global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) {
+    constexpr int NW = BM / 32;                          // 8 (BM = 256) or 4 (BM = 128) wavefronts
+    constexpr int WN = BN / 64, WM = NW / WN;            // 256x256: 2 x 4 wavefronts of 128x64; 256x128: 4 x 2 of 64x64; 128x128: 2 x 2 of 64x64
+    constexpr int WTM = BM / WM, WTN = 64, TM = WTM / 32, TN = 2;
+    constexpr int NIH = TM / 2, NU = 2 * NIH;            // sub-steps per step: (k-half, pair of 32-row blocks)
+    constexpr int HPS = BN == 256 ? 1 : 3;               // request slots per sub-step: behind every 4 MFMAs, or (256x256: registers) every 12
+    constexpr int AR = BM + HALO;                        // A rows per plane filled by DMA; row AR is the zero row
+    constexpr int APL = (AR + 1) * 64;                   // bytes per A plane
+    constexpr int GB = BN / 16;                          // 16-row DMA groups per B plane
+    constexpr int A_BYTES = 2 * APL, B_BYTES = 2 * BN * 64;
+    constexpr int LDS_BYTES = 2 * B_BYTES + 2 * A_BYTES;
+    constexpr int STAGE = LDS_BYTES / 8;                 // floats in half of the LDS (the epilogue's view of its scratch)
+    constexpr int NGA = BM / 16 / NW;                    // A row groups (of both planes) a wavefront owns: 2
+    constexpr int APW = 2 * NGA + 1;                     // A pieces a wavefront may own per (ky, chunk): 2 groups x 2 planes + the halo group (last two waves)
+    constexpr int ASTEPS = KW - 1;                       // they go out in taps 0 .. KW-2 of the previous super-step (piece it in tap it % ASTEPS)
+    constexpr int MAXA = (APW + ASTEPS - 1) / ASTEPS;    // most A pieces a wavefront requests in one step
+    constexpr int BPP = GB / NW;                         // B pieces per plane and wavefront (256x256: 2, 256x128: 1, 128x128: 2)
+    static_assert((HPS == 3 || NU == 4) && (BM == 256 || BM == 128) && (BN == 128 || BN == 256) && NGA == 2 && BPP >= 1 && GB % NW == 0 && KW >= 3 && TM % 2 == 0 && WM * WN == NW,
+                  "tile / wavefront geometry");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const fgt_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int m_idx, n_idx;
+    if (!conv_tile_index(p, m_idx, n_idx)) return;
+    const int bm0 = m_idx * BM, bn0 = n_idx * BN, g = blockIdx.y;
+
+    char* const lds = reinterpret_cast<char*>(smem);
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)lds;     // LDS byte address of the dynamic segment
+    char* const Bst = lds;                               // [2][hi BN rows | lo BN rows]
+    char* const Abuf = lds + 2 * B_BYTES;                // [2][hi AR rows, zero row | lo AR rows, zero row]
+    if (tid < 64) reinterpret_cast<float*>(Abuf + (tid >> 5) * A_BYTES + ((tid >> 4) & 1) * APL + AR * 64)[tid & 15] = 0.f;
+
+    const int W = d.W, H = d.H, HW = H * W;
+    const int dwx = d.dw, p_i = d.pw;
+    const bool il = d.in_split == 2;
+    const int nch0 = p.Cg0 / 32, nch1 = p.Cg1 / 32, nchunk = nch0 + nch1;
+    const int nss = d.kh * nchunk;
+    const int cstride = il ? 128 : 64;                   // bytes from one 32-channel chunk of a pixel to the next
+
+    // ---- im2col source iterator (wave-uniform): the super-step whose A rows are requested next (conv_taps.hip, normal mode)
+    auto src_hi = [&](int s) {
+        const __bf16* x = reinterpret_cast<const __bf16*>(s ? p.x1 : p.x0);
+        const long c0 = s ? (long)d.off1 + (long)g * p.Cg1 : (long)d.off0 + (long)g * p.Cg0;
+        return reinterpret_cast<const char*>(x + (il ? 2 * c0 : c0));
+    };
+    auto src_lo_off = [&](int s) { return il ? 64l : 2 * (s ? p.ps1 : p.ps0); };
+    const char* a_hi = src_hi(0);
+    const char* a_lo = a_hi + src_lo_off(0);
+    int a_ld2 = 2 * d.ld0, a_left = nch0, a_src = 0;      // (a_ld2: bytes from one pixel of the source to the next)
+    int a_dy = -d.ph, a_dyW = -d.ph * W;                  // ky tap shift: in rows / in pixels
+    auto a_advance = [&]() {
+        a_hi += cstride; a_lo += cstride;
+        if (--a_left == 0) {
+            if (a_src == 0 && nch1 > 0) {
+                a_src = 1; a_left = nch1; a_ld2 = 2 * d.ld1;
+            } else {
+                a_src = 0; a_left = nch0; a_ld2 = 2 * d.ld0;
+                a_dy += d.dh; a_dyW += d.dh * W;
+            }
+            a_hi = src_hi(a_src);
+            a_lo = a_hi + src_lo_off(a_src);
+        }
+    };
+
+    // ---- A pieces (16 rows x 64 bytes of one plane): wavefront w owns, of BOTH planes, the row groups w and w + NW (pieces it = 0..3: plane
+    // it >> 1, group w + NW * (it & 1)) and — the last two wavefronts — the halo group BM / 16 of plane 0 / 1 (piece 4).  A lane fetches row
+    // (lane >> 2) of a group, 16-byte column kc (swizzled on the source side): three (pixel, image row) pairs per lane describe all five pieces.
+    const int lrow = lane >> 2;
+    const int kc16 = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
+    int a_q[3], a_y[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int grp = c < 2 ? wave + NW * c : BM / 16;
+        const long q = (long)bm0 - p_i + grp * 16 + lrow;           // flattened (n, y, x) index of the LDS row for the centre taps
+        const bool valid = q >= 0 && q < (long)d.N * HW;
+        const int rem = valid ? (int)(q % HW) : 0;
+        a_q[c] = valid ? (int)q : 0;
+        a_y[c] = valid ? rem / W : -(1 << 30);
+    }
+    const char* const zp = reinterpret_cast<const char*>(p.zero_page);
+#ifdef FGT_PP_TRACE
+    const int abl = p.pipe;
+    int tr_step = 0;
+#else
+    constexpr int abl = 1;
+#endif
+    auto issue_A = [&](auto IT, int ab) __attribute__((always_inline)) {
+        constexpr int it = decltype(IT)::value, c = it < 4 ? (it & 1) : 2;
+        if (abl == 2) return 0;
+        if constexpr (it == 4) { if (wave < NW - 2) return 0; }  // (wave-uniform)
+        const int plane = it < 4 ? it >> 1 : wave & 1;
+        const int grp = it < 4 ? wave + NW * (it & 1) : BM / 16;
+        const char* ptr = (plane ? a_lo : a_hi) + ((long)(a_q[c] + a_dyW) * a_ld2 + kc16);
+        const bool ok = (unsigned)(a_y[c] + a_dy) < (unsigned)H;
+        glds16(ok ? ptr : zp, Abuf + ab * A_BYTES + plane * APL + grp * 1024);
+        return 1;
+    };
+
+    // ---- weights: interleaved rows [Kpad/32][hi 32 | lo 32], K-step order as in conv_taps.hip: kstep(ky, c, kx) = (ky*KW + kx) * nchunk + c.
+    // One per-lane 64-bit base + a wave-uniform byte offset per piece; the K position is a scalar running offset (32 bits: it stays inside a row).
+    // A wavefront requests the 16-row groups BPP * wave .. BPP * wave + BPP - 1 of both planes.
+    const char* const w_lane = reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + bn0 + lrow) * (2 * d.Kpad)) + kc16;
+    const int w_row16 = 64 * d.Kpad;                      // bytes from one 16-row group of the weight image to the next
+    int w_k = 0;                                          // byte offset of the K-step the B stream is at
+    const int dkx = nchunk * 128, dss = 128 - (KW - 1) * dkx;      // to the next kx of a (ky, chunk) / from its last kx to the next chunk; to the next ky: + 128
+    int b_c = 0;                                          // chunk (within its ky) of the super-step the B stream is in
+    const int npad_rows = d.Npad - bn0;                   // weight rows of this tile that exist (the rest reads the zero page)
+    auto issue_B_plane = [&](int plane, int bs) __attribute__((always_inline)) {
+        if (abl == 2) return;
+#pragma unroll
+        for (int i = 0; i < BPP; ++i) {
+            const int grp = wave * BPP + i;
+            const bool ok = grp * 16 < npad_rows;         // (wave-uniform)
+            glds16(ok ? w_lane + ((long)grp * w_row16 + plane * 64 + w_k) : zp, Bst + bs * B_BYTES + plane * BN * 64 + grp * 1024);
+        }
+    };
+    auto advance_B = [&](bool last_kx) {                  // behind the B tile of a step with kx = KW-1 (last_kx) or kx < KW-1
+        int dlt = dkx;
+        if (last_kx) {
+            dlt = dss;
+            if (++b_c == nchunk) { b_c = 0; dlt = 128; }
+        }
+        w_k += dlt;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    int Rb[TM], oxp[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        Rb[i] = wm * WTM + i * 32 + l31;
+        oxp[i] = (bm0 + Rb[i]) % W - p_i;
+    }
+    const unsigned b_lane = (unsigned)((wn * WTN + l31) * 64);     // B fragment rows: wave-tile base (multiple of 32) + l31
+    const unsigned so0 = (unsigned)swz(l31, lh) * 2u, so1 = (unsigned)swz(l31, 2 + lh) * 2u;
+
+    // ---- prologue: A rows of super-step 0 and the B tile of step 0, landed and published
+    static_for<APW>([&](auto IT) __attribute__((always_inline)) { issue_A(IT, 0); });
+    a_advance();
+    issue_B_plane(0, 0);
+    issue_B_plane(1, 0);
+    advance_B(false);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- fragment addresses of a step (tap kx of A buffer Ab, B stage bs): computed for the NEXT step behind the current step's last MFMAs
+    unsigned fa_a0[TM], fa_bb = 0;
+    auto frag_addr = [&](int kx, unsigned Ab, int bs) __attribute__((always_inline)) {
+        // (opaque: the per-tap fragment addresses are recomputed per step, not hoisted and kept live across the loop)
+        int shv = kx * dwx;
+        asm volatile("" : "+v"(shv));
+        const int sh = __builtin_amdgcn_readfirstlane(shv);
+        static_for<TM>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            const bool xin = (unsigned)(oxp[i] + sh) < (unsigned)W;
+            const int R = xin ? Rb[i] + sh : AR;
+            fa_a0[i] = lds0 + Ab + (unsigned)R * 64u + (unsigned)(((R >> 2) & 3) ^ lh) * 16u;  // k-half 0: slot lh; k-half 1: slot 2 + lh (^ 32 bytes)
+        });
+        fa_bb = lds0 + (unsigned)(bs * B_BYTES) + b_lane;
+    };
+    auto rd = [&](bf16x8& dst, unsigned addr) __attribute__((always_inline)) {
+        u32x4 v;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+        dst = __builtin_bit_cast(bf16x8, v);
+    };
+    // ---- one step of one wavefront's matrix work: TM x TN x 6 MFMAs in sub-steps of 12 (k-half, pair of 32-row blocks), the NEXT sub-step's
+    // fragment reads in flight underneath (two register sets).  The wait carries the sub-step's fragments as "+v" operands, so no MFMA can be
+    // scheduled above it; LDS returns in order, so lgkmcnt(n) with n = the reads requested after them retires exactly this sub-step's (anything
+    // else in that queue only makes the wait stricter).  hook(u) runs behind sub-step u's MFMAs (pinned by the sched_barrier).
+    auto compute = [&](auto&& hook) __attribute__((always_inline)) {
+        unsigned a0[TM];
+        static_for<TM>([&](auto I) __attribute__((always_inline)) { a0[decltype(I)::value] = fa_a0[decltype(I)::value]; });
+        const unsigned bb = fa_bb;
+        bf16x8 Bh[2][TN], Bl[2][TN];                      // [k half][32-column block]
+        bf16x8 Ah[2][2], Al[2][2];                        // [register set][block of the pair]
+        auto loadB = [&](auto KS) __attribute__((always_inline)) {
+            constexpr int ks = decltype(KS)::value;
+            const unsigned so = ks ? so1 : so0;
+            static_for<TN>([&](auto J) __attribute__((always_inline)) {
+                constexpr int j = decltype(J)::value;
+                rd(Bh[ks][j], bb + so + j * 32 * 64);
+                rd(Bl[ks][j], bb + so + BN * 64 + j * 32 * 64);
+            });
+        };
+        auto loadA = [&](auto U) __attribute__((always_inline)) {
+            constexpr int u = decltype(U)::value, ks = u / NIH, ih = u % NIH, set = u & 1;
+            static_for<2>([&](auto II) __attribute__((always_inline)) {
+                constexpr int ii = decltype(II)::value;
+                const unsigned a = a0[2 * ih + ii] ^ (ks ? 32u : 0u);
+                rd(Ah[set][ii], a);
+                rd(Al[set][ii], a + APL);
+            });
+        };
+        loadB(std::integral_constant<int, 0>{});
+        loadA(std::integral_constant<int, 0>{});
+        static_for<NU>([&](auto U) __attribute__((always_inline)) {
+            constexpr int u = decltype(U)::value, ks = u / NIH, ih = u % NIH, set = u & 1;
+            constexpr bool more = u + 1 < NU, nextB = more && (u + 1) % NIH == 0;
+            if constexpr (nextB) loadB(std::integral_constant<int, (u + 1) / NIH>{});
+            if constexpr (more) loadA(std::integral_constant<int, u + 1>{});
+            constexpr int pending = more ? 4 + (nextB ? 2 * TN : 0) : 0;          // reads requested after this sub-step's
+            asm volatile("s_waitcnt lgkmcnt(%8)"
+                         : "+v"(Ah[set][0]), "+v"(Al[set][0]), "+v"(Ah[set][1]), "+v"(Al[set][1]), "+v"(Bh[ks][0]), "+v"(Bl[ks][0]), "+v"(Bh[ks][1]), "+v"(Bl[ks][1])
+                         : "n"(pending));
+            if constexpr (u == 0) PP_STAMP(5);
+            // same products as conv_taps.hip / conv_split.hip (lo*hi, hi*lo, hi*hi per accumulator and k-half)
+            static_for<3>([&](auto P) __attribute__((always_inline)) {
+                constexpr int prod = decltype(P)::value;
+                static_for<2>([&](auto II) __attribute__((always_inline)) {
+                    constexpr int ii = decltype(II)::value;
+                    static_for<TN>([&](auto J) __attribute__((always_inline)) {
+                        constexpr int j = decltype(J)::value;
+                        const bf16x8 av = prod == 0 ? Al[set][ii] : Ah[set][ii];
+                        const bf16x8 bv = prod == 1 ? Bl[ks][j] : Bh[ks][j];
+                        acc[2 * ih + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[2 * ih + ii][j], 0, 0, 0);
+                    });
+                });
+                if constexpr (HPS == 3 || prod == 2) {
+                    __builtin_amdgcn_sched_barrier(0);    // the hook's address arithmetic / LDS-DMA issue goes BEHIND these MFMAs
+                    hook(std::integral_constant<int, HPS == 3 ? u * 3 + prod : u>{});
+                }
+            });
+        });
+    };
+    constexpr int NHOOK = NU * HPS;                       // request slots per step
+    constexpr int NREQ = 2 * BPP + MAXA;                  // requests a wavefront may make per step: B pieces of both planes, then A pieces
+
+    int bs = 0;                                           // B stage of this step
+    frag_addr(0, (unsigned)(2 * B_BYTES), 0);
+    for (int ss = 0; ss < nss; ++ss) {
+        const bool last = ss + 1 == nss;
+        const unsigned Ab = (unsigned)(2 * B_BYTES + (ss & 1) * A_BYTES);          // byte offset of this super-step's A buffer in the LDS
+        static_for<KW>([&](auto KX) __attribute__((always_inline)) {
+            constexpr int kx = decltype(KX)::value;
+            const bool moreB = !(last && kx == KW - 1);
+            int na = 0;
+            // request slot h of this step: the B pieces of step s+1 first (they are read right behind the barrier), one per slot, then this
+            // wavefront's A pieces of super-step ss+1 that belong to tap kx (pieces it = kx, kx + ASTEPS, ...); the last slot also computes the
+            // next step's fragment addresses
+            auto hook = [&](auto Hh) __attribute__((always_inline)) {
+                constexpr int h = decltype(Hh)::value;
+                // HPS == 3: requests r with r * NHOOK / NREQ == h; HPS == 1 (four slots): B plane 0 | B plane 1 | the A pieces | addresses only
+                constexpr int r0 = HPS == 3 ? (h * NREQ + NHOOK - 1) / NHOOK : (h < 2 ? h * BPP : h == 2 ? 2 * BPP : NREQ);
+                constexpr int r1 = HPS == 3 ? ((h + 1) * NREQ + NHOOK - 1) / NHOOK : (h < 2 ? (h + 1) * BPP : NREQ);
+                static_for<r1 - r0>([&](auto RR) __attribute__((always_inline)) {
+                    constexpr int r = r0 + decltype(RR)::value;
+                    if constexpr (r < 2 * BPP) {
+                        if (moreB) {
+                            constexpr int plane = r / BPP, i = r % BPP;
+                            if (abl != 2) {
+                                const int grp = wave * BPP + i;
+                                const bool ok = grp * 16 < npad_rows;     // (wave-uniform)
+                                glds16(ok ? w_lane + ((long)grp * w_row16 + plane * 64 + w_k) : zp, Bst + (bs ^ 1) * B_BYTES + plane * BN * 64 + grp * 1024);
+                            }
+                        }
+                    } else {
+                        constexpr int it = kx + (r - 2 * BPP) * ASTEPS;
+                        if constexpr (kx < ASTEPS && it < APW) {
+                            if (!last) na += issue_A(std::integral_constant<int, it>{}, (ss + 1) & 1);
+                        }
+                    }
+                });
+                if constexpr (h == NHOOK - 1) {             // the next step's fragment addresses, under this step's last MFMAs
+                    constexpr int nkx = (kx + 1) % KW;
+                    const unsigned nAb = nkx == 0 ? (unsigned)(2 * B_BYTES + ((ss + 1) & 1) * A_BYTES) : Ab;
+                    frag_addr(nkx, nAb, bs ^ 1);
+                }
+            };
+            PP_STAMP(0);
+            compute(hook);
+            PP_STAMP(6);
+            if (moreB) advance_B((kx + 1) % KW == KW - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vmcnt_upto<MAXA>(na);                    // the next step's B tile (and every older A piece) has landed; this step's A pieces may fly on
+            PP_STAMP(3);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            PP_STAMP(4);
+            bs ^= 1;
+#ifdef FGT_PP_TRACE
+            ++tr_step;
+#endif
+        });
+        a_advance();
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
+}
+
+template <int BM, int BN, int KW>
+int launch_kw(const ConvP& p, hipStream_t s) {
+    constexpr size_t smem = (size_t)2 * (2 * BN * 64) + (size_t)2 * (2 * (BM + HALO + 1) * 64);
+    static_assert(smem <= 160 * 1024, "LDS buffers do not fit");
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_taps_il_kernel<BM, BN, KW>), (int)smem, lds_set, "conv_taps_il")) return rc;
+    ConvP q = p;
+    q.mtiles = cdiv(p.M, BM);
+    q.ntiles = cdiv(p.Cout_g, BN);
+    q.mchunk = cdiv(q.mtiles, 8);
+    dim3 grid(q.xcd_swizzle ? 8 * q.mchunk * q.ntiles : q.mtiles * q.ntiles, p.d.groups);
+    hipLaunchKernelGGL((conv_taps_il_kernel<BM, BN, KW>), grid, dim3(BM * 2), smem, s, q);
+    return fgt_check_launch("conv_taps_il");
+}
+
+template <int BM, int BN>
+int launch(const ConvP& p, hipStream_t s) {
+    ConvP q = p;
+    q.tr_li = 0;
+    if (p.d.kw == 1 || p.d.upsample) {                    // k x 1 (transposed tile order) and nearest-x2 upsampling: conv_taps.hip's tiles
+        fgt_set_error("fgt_conv2d: the interleaved-request tap tiles do not serve k x 1 or upsampling layers");
+        return FGT_EINVAL;
+    }
+    if constexpr (BN == 256) {                           // (kw = 5, 7 on the 256x256 tile need more than 256 registers: not built)
+        if (p.d.kw != 3) {
+            fgt_set_error("fgt_conv2d: the 256x256 interleaved-request tap tile does not serve kw = %d layers", p.d.kw);
+            return FGT_EINVAL;
+        }
+        return launch_kw<BM, BN, 3>(q, s);
+    } else {
+        switch (p.d.kw) {
+            case 3: return launch_kw<BM, BN, 3>(q, s);
+            case 5: return launch_kw<BM, BN, 5>(q, s);
+            case 7: return launch_kw<BM, BN, 7>(q, s);
+            default: fgt_set_error("fgt_conv2d: the tap-reusing kernel is built for 3, 5, 7 reused taps (got %d x %d)", p.d.kh, p.d.kw); return FGT_EINVAL;
+        }
+    }
+}
+
+}  // namespace
+
+#ifdef FGT_PP_TRACE
+extern "C" int fgt_debug_pp_trace(unsigned long long* host_out, int n) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(fgt_pp_trace_buf), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
+}
+#endif
+
+// called by fgt_conv_taps_launch (conv_taps.hip) for the "...it" tile codes; same eligibility as the other tap tiles minus k x 1 / upsampling
+int fgt_conv_taps_il_launch(int bm, int bn, const ConvP& p, hipStream_t s) {
+    if (bm == 128) return launch<128, 128>(p, s);
+    return bn == 256 ? launch<256, 256>(p, s) : launch<256, 128>(p, s);
+}

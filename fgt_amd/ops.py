@@ -35,7 +35,7 @@ TILE_CANDIDATES = ("128x128", "64x64", "128x64", "256x128", "128x32", "128x128x8
                    "128x128eaw", "64x64eaw", "128x64eaw", "128x128x8eaw", "256x128x16eaw", "256x64x8eaw", "256x128eaw")
 # Layers that fgt_conv2d routes to the tap-reusing kernel (csrc/conv_taps.hip; decided by geometry: fgt_conv_taps_route) are tuned among ITS
 # tiles only — they are bit-identical to each other, so results never depend on tuning.
-TAPS_CANDIDATES = ("128x128x8t", "128x128t", "128x64t", "128x64x8t", "64x64t", "256x256it", "256x128it")     # (...it: csrc/conv_taps_pp.hip, interleaved requests; declines k x 1 / upsampling layers)
+TAPS_CANDIDATES = ("128x128x8t", "128x128t", "128x64t", "128x64x8t", "64x64t", "128x128it", "256x128it", "256x256it")     # (...it: csrc/conv_taps_il.hip, interleaved requests; declines k x 1 / upsampling layers)
 _tile_cache = {}
 _tile_validated = set()      # keys whose cached tile has been checked against the geometry's kernel family (conv2d)
 

@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 from fgt_amd import _lib
 
-TAPS = ["128x128x8t", "128x128t", "128x64t", "128x64x8t", "64x64t", "256x128pt", "256x256pt", "256x128it", "256x256it"]      # ...pt: conv_taps_pp.hip (256-row tiles, ping-pong wavefront groups)
-PP_ONLY_KX = ("256x128pt", "256x256pt", "256x128it", "256x256it")            # the ping-pong tiles serve the kx-reuse geometry only: no k x 1 (transposed) layers, no upsampling
+TAPS = ["128x128x8t", "128x128t", "128x64t", "128x64x8t", "64x64t", "128x128it", "256x128it", "256x256it"]      # ...it: conv_taps_il.hip (requests interleaved into the matrix work)
+PP_ONLY_KX = ("128x128it", "256x128it", "256x256it")            # the interleaved tiles serve the kx-reuse geometry only: no k x 1 (transposed) layers, no upsampling
 if "diag" in _lib.LIB_PATH:        # diagnostic builds: the same kernel with register-fed weights (csrc/diag/conv_taps_breg.hip), bit-identical
     TAPS += ["128x128x8r", "128x128r", "128x64r", "64x64r"]
 
@@ -85,8 +85,8 @@ def test_taps_kernel_vs_fp64_and_other_kernels(case, il, dev):
     for t in TAPS:
         if kw == 1 and t.endswith("r"):
             continue                         # (the register-fed-weights experiment has no transposed mode)
-        if kw == 1 and t in PP_ONLY_KX:
-            with pytest.raises(RuntimeError, match="do not serve"):
+        if (kw == 1 and t in PP_ONLY_KX) or (t == "256x256it" and kw != 3):
+            with pytest.raises(RuntimeError, match="not serve"):
                 ops.conv2d(xs, pc, x1=x1s, pad=pad, dil=dil, act="lrelu", tile=t, precision="bf16x3")
             continue
         got = ops.conv2d(xs, pc, x1=x1s, pad=pad, dil=dil, act="lrelu", tile=t, precision="bf16x3")

@@ -1,11 +1,10 @@
 #!/usr/bin/env python
-"""Per-wavefront timeline of the ping-pong tap kernel (csrc/conv_taps_pp.hip; diagnostic build with -DFGT_PP_TRACE).
+"""Per-wavefront timeline of the interleaved-request tap kernel (csrc/conv_taps_il.hip; diagnostic build with -DFGT_PP_TRACE).
 
     python tools/pp_trace.py --build            # here (no GPU needed): lib/libfgt_hip_pptrace.so
-    python tools/pp_trace.py [--layer e20enc10] [--tile 256x128pt]      # on the MI355X
+    python tools/pp_trace.py [--layer e20enc10] [--tile 256x128it]      # on the MI355X
 
-Stamps per step (s_memtime cycles): 0 step top | 1 first half done (G0: MFMAs issued; G1: requests issued) | 2 after the barrier |
-3 second half done incl. waits (G0: requests (+ vmcnt at the last tap); G1: MFMAs issued + vmcnt(0)) | 4 after the closing barrier."""
+Stamps per step (s_memtime cycles): 0 step top | 5 first MFMA about to issue | 6 last MFMA issued | 3 requests waited for (vmcnt) | 4 behind the barrier."""
 import argparse
 import ctypes as C
 import os
@@ -22,7 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
     ap.add_argument("--layer", default="e20enc10")
-    ap.add_argument("--tile", default="256x128pt")
+    ap.add_argument("--tile", default="256x128it")
     a = ap.parse_args()
     if a.build:
         from fgt_amd import build
@@ -50,16 +49,17 @@ def main():
     t0 = t[:, 2:, :]                       # skip the first two steps (cold)
     base = t0[:, :, 0].min()
     print(f"{a.layer} {a.tile}: per wavefront, median cycles over steps 2..{STEPS - 1}")
-    print("wave | compute: to-1st-MFMA  MFMAs  tail(+vmcnt) | barrier | load: B-issue  A-issue  rest(+wait) | barrier |  step-period")
-    med = lambda a, b: np.median(t0[wv, :, b] - t0[wv, :, a])
+    print("wave | top -> first MFMA | MFMAs (+ interleaved requests) | tail + vmcnt | barrier | step period")
     for wv in range(8):
+        if t0[wv].max() == 0:
+            continue                                             # (4-wavefront tiles)
+        med = lambda a, b: np.median(t0[wv, :, b] - t0[wv, :, a])
         period = np.diff(t0[wv, :, 0])
-        post = np.median(t0[wv, 1:, 0] - t0[wv, :-1, 4])           # behind the barrier until the next step's top: G1's requests
-        print(f"{wv:4d} | {med(0, 5):20.0f} {med(5, 6):6.0f} {med(6, 1):13.0f} | {med(1, 2):7.0f} | {med(2, 7):13.0f} {med(7, 8):8.0f} {med(8, 3):12.0f} | {med(3, 4):7.0f} | {np.median(period):12.0f} | post-barrier {post:6.0f}")
+        print(f"{wv:4d} | {med(0, 5):19.0f} | {med(5, 6):30.0f} | {med(6, 3):12.0f} | {med(3, 4):7.0f} | {np.median(period):11.0f}")
     print("steps 2..9 of wave 0 (G0) and wave 4 (G1), stamps relative to the first:")
-    for wv in (0, 4):
+    for wv in (0, 3):
         for st in range(2, 10):
-            print(f"  wave {wv} step {st}: " + " ".join(f"{int(v - base):7d}" for v in t[wv, st, [0, 5, 6, 1, 2, 7, 8, 3, 4]]))
+            print(f"  wave {wv} step {st}: " + " ".join(f"{int(v - base):7d}" for v in t[wv, st, [0, 5, 6, 3, 4]]))
 
 
 if __name__ == "__main__":
