@@ -31,6 +31,17 @@
 // Numerics: the products and the accumulation order of conv_taps.hip ((ky, chunk, kx); per accumulator and k-half lo*hi, hi*lo, hi*hi):
 // BIT-IDENTICAL to its tiles (tests/test_taps_gpu.py), so the autotuner chooses among all of them (routing stays by geometry).
 // LDS: B stages [2][hi BN | lo BN] x 64-byte rows, A buffers [2][hi: BM + 16 rows + zero row | lo: ...].
+//
+// WIDE image (interleaved split inputs, in_split = 2 — what the bf16x3 pipeline produces for C % 32 == 0; weights are per-step interleaved lines
+// anyway): every LDS row is the full 128-byte line [hi 64 | lo 64] of a pixel's / an output channel's 32-channel chunk, requested as 8-row x
+// 128-byte pieces — the CU retires such a piece in 19 cycles against 37 for a 16-row x 64-byte one.  16-byte slots are XOR-swizzled by
+// (row >> 1) & 7 on the source side (a lane fetches the slot that belongs at its linear LDS position), which makes every ds_read_b128 lane
+// group hit 16 distinct slots of the 256-byte bank window for ANY tap shift.  Same values, same products: bit-identical to the plane image
+// (tests/test_taps_gpu.py runs both).  Measured +1 ... +13 % over the plane image (profiles/r04_run27_taps_il_wide_sweep.txt);
+// FGT_TAPS_WIDE=0 keeps interleaved inputs on the 64-byte image (A/B).
+// A GEMM mode of this kernel (KW = 1: 1 x 1 layers, A rows requested with the B tile of every step) was built, measured on the K = 512 / 768
+// linear layers of the transformer and dropped: 237-280 TFLOP/s against 253-309 of conv_split / conv_wide — with 16-24 steps per tile those
+// layers are bound by the tile's prologue and its 64 KB output, not by the step (NOTEBOOK §11).
 #include "conv_tile.h"
 
 namespace {
@@ -73,7 +84,7 @@ __device__ unsigned long long fgt_pp_trace_buf[8 * PP_TR_STEPS * 10];
 #define PP_STAMP(slot) do {} while (0)
 #endif
 
-template <int BM, int BN, int KW>
+template <int BM, int BN, int KW, bool WIDE>
 __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) {
     constexpr int NW = BM / 32;                          // 8 (BM = 256) or 4 (BM = 128) wavefronts
     constexpr int WN = BN / 64, WM = NW / WN;            // 256x256: 2 x 4 wavefronts of 128x64; 256x128: 4 x 2 of 64x64; 128x128: 2 x 2 of 64x64
@@ -87,7 +98,8 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     constexpr int LDS_BYTES = 2 * B_BYTES + 2 * A_BYTES;
     constexpr int STAGE = LDS_BYTES / 8;                 // floats in half of the LDS (the epilogue's view of its scratch)
     constexpr int NGA = BM / 16 / NW;                    // A row groups (of both planes) a wavefront owns: 2
-    constexpr int APW = 2 * NGA + 1;                     // A pieces a wavefront may own per (ky, chunk): 2 groups x 2 planes + the halo group (last two waves)
+    constexpr int APW = 2 * NGA + 1;                     // A pieces a wavefront may own per (ky, chunk): 2 groups x 2 planes + the halo group (last two waves);
+                                                         // WIDE: 4 groups of 8 full rows + a halo group (last two waves)
     constexpr int ASTEPS = KW - 1;                       // they go out in taps 0 .. KW-2 of the previous super-step (piece it in tap it % ASTEPS)
     constexpr int MAXA = (APW + ASTEPS - 1) / ASTEPS;    // most A pieces a wavefront requests in one step
     constexpr int BPP = GB / NW;                         // B pieces per plane and wavefront (256x256: 2, 256x128: 1, 128x128: 2)
@@ -107,7 +119,11 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)lds;     // LDS byte address of the dynamic segment
     char* const Bst = lds;                               // [2][hi BN rows | lo BN rows]
     char* const Abuf = lds + 2 * B_BYTES;                // [2][hi AR rows, zero row | lo AR rows, zero row]
-    if (tid < 64) reinterpret_cast<float*>(Abuf + (tid >> 5) * A_BYTES + ((tid >> 4) & 1) * APL + AR * 64)[tid & 15] = 0.f;
+    if constexpr (WIDE) {                                // [2][AR rows, zero row] x 128 bytes (hi 64 | lo 64, 16-byte slots swizzled by (row >> 1) & 7)
+        if (tid < 64) reinterpret_cast<float*>(Abuf + (tid >> 5) * A_BYTES + AR * 128)[tid & 31] = 0.f;
+    } else {
+        if (tid < 64) reinterpret_cast<float*>(Abuf + (tid >> 5) * A_BYTES + ((tid >> 4) & 1) * APL + AR * 64)[tid & 15] = 0.f;
+    }
 
     const int W = d.W, H = d.H, HW = H * W;
     const int dwx = d.dw, p_i = d.pw;
@@ -144,13 +160,20 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     // ---- A pieces (16 rows x 64 bytes of one plane): wavefront w owns, of BOTH planes, the row groups w and w + NW (pieces it = 0..3: plane
     // it >> 1, group w + NW * (it & 1)) and — the last two wavefronts — the halo group BM / 16 of plane 0 / 1 (piece 4).  A lane fetches row
     // (lane >> 2) of a group, 16-byte column kc (swizzled on the source side): three (pixel, image row) pairs per lane describe all five pieces.
-    const int lrow = lane >> 2;
-    const int kc16 = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
-    int a_q[3], a_y[3];
+    // WIDE (interleaved inputs: a pixel's 32-channel chunk is ONE 128-byte line [hi | lo]): pieces of 8 rows x 128 bytes — the CU retires
+    // such a piece in about half the time of a 16-row x 64-byte one (tools/micro/dma_issue.hip).  Wavefront w owns the 8-row groups w, w + NW,
+    // w + 2 NW, w + 3 NW (pieces 0..3) and — the last two wavefronts — the halo groups BM / 8 and BM / 8 + 1 (piece 4; the second one only when
+    // (kw - 1) * dw > 8).  A lane fetches row (lane >> 3), 16-byte slot (lane & 7) ^ ((LDS row >> 1) & 7): every group of one wavefront has
+    // the same parity, so the source-side swizzle is one per-lane constant.
+    constexpr int NPA = WIDE ? 5 : 3;                     // (pixel, image row) pairs per lane
+    const int lrow = WIDE ? lane >> 3 : lane >> 2;
+    const int kc16 = WIDE ? ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 16 : ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
+    const bool halo2 = (KW - 1) * dwx > 8;
+    int a_q[NPA], a_y[NPA];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int grp = c < 2 ? wave + NW * c : BM / 16;
-        const long q = (long)bm0 - p_i + grp * 16 + lrow;           // flattened (n, y, x) index of the LDS row for the centre taps
+    for (int c = 0; c < NPA; ++c) {
+        const int grp = WIDE ? (c < 4 ? wave + NW * c : BM / 8 + (wave - (NW - 2))) : (c < 2 ? wave + NW * c : BM / 16);
+        const long q = (long)bm0 - p_i + grp * (WIDE ? 8 : 16) + lrow;           // flattened (n, y, x) index of the LDS row for the centre taps
         const bool valid = q >= 0 && q < (long)d.N * HW;
         const int rem = valid ? (int)(q % HW) : 0;
         a_q[c] = valid ? (int)q : 0;
@@ -164,9 +187,17 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     constexpr int abl = 1;
 #endif
     auto issue_A = [&](auto IT, int ab) __attribute__((always_inline)) {
-        constexpr int it = decltype(IT)::value, c = it < 4 ? (it & 1) : 2;
+        constexpr int it = decltype(IT)::value, c = WIDE ? it : (it < 4 ? (it & 1) : 2);
         if (abl == 2) return 0;
         if constexpr (it == 4) { if (wave < NW - 2) return 0; }  // (wave-uniform)
+        if constexpr (WIDE) {
+            if constexpr (it == 4) { if (wave == NW - 1 && !halo2) return 0; }
+            const int grp = it < 4 ? wave + NW * it : BM / 8 + (wave - (NW - 2));
+            const char* ptr = a_hi + ((long)(a_q[c] + a_dyW) * a_ld2 + kc16);
+            const bool ok = (unsigned)(a_y[c] + a_dy) < (unsigned)H;
+            glds16(ok ? ptr : zp, Abuf + ab * A_BYTES + grp * 1024);
+            return 1;
+        }
         const int plane = it < 4 ? it >> 1 : wave & 1;
         const int grp = it < 4 ? wave + NW * (it & 1) : BM / 16;
         const char* ptr = (plane ? a_lo : a_hi) + ((long)(a_q[c] + a_dyW) * a_ld2 + kc16);
@@ -178,16 +209,25 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     // ---- weights: interleaved rows [Kpad/32][hi 32 | lo 32], K-step order as in conv_taps.hip: kstep(ky, c, kx) = (ky*KW + kx) * nchunk + c.
     // One per-lane 64-bit base + a wave-uniform byte offset per piece; the K position is a scalar running offset (32 bits: it stays inside a row).
     // A wavefront requests the 16-row groups BPP * wave .. BPP * wave + BPP - 1 of both planes.
-    const char* const w_lane = reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + bn0 + lrow) * (2 * d.Kpad)) + kc16;
-    const int w_row16 = 64 * d.Kpad;                      // bytes from one 16-row group of the weight image to the next
+    // WIDE: 8-row groups of full 128-byte lines; wavefront w requests the groups 2 BPP w .. 2 BPP w + 2 BPP - 1 (request r: parity r & 1, which
+    // flips bit 2 of the swizzled slot = 64 bytes)
+    const int kcB = WIDE ? ((lane & 7) ^ (lane >> 4)) * 16 : kc16;
+    const char* const w_lane = reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + bn0 + lrow) * (2 * d.Kpad)) + kcB;
+    const int w_row16 = (WIDE ? 32 : 64) * d.Kpad;        // bytes from one 16-row (WIDE: 8-row) group of the weight image to the next
     int w_k = 0;                                          // byte offset of the K-step the B stream is at
     const int dkx = nchunk * 128, dss = 128 - (KW - 1) * dkx;      // to the next kx of a (ky, chunk) / from its last kx to the next chunk; to the next ky: + 128
     int b_c = 0;                                          // chunk (within its ky) of the super-step the B stream is in
     const int npad_rows = d.Npad - bn0;                   // weight rows of this tile that exist (the rest reads the zero page)
-    auto issue_B_plane = [&](int plane, int bs) __attribute__((always_inline)) {
+    auto issue_B = [&](auto RQ, int bs) __attribute__((always_inline)) {           // request r of 2 BPP: (plane, group) / WIDE: 8-row group
+        constexpr int r = decltype(RQ)::value;
         if (abl == 2) return;
-#pragma unroll
-        for (int i = 0; i < BPP; ++i) {
+        if constexpr (WIDE) {
+            const int grp = wave * (2 * BPP) + r;
+            const bool ok = grp * 8 < npad_rows;          // (wave-uniform)
+            const unsigned long src = (unsigned long)(w_lane + ((long)grp * w_row16 + w_k)) ^ (unsigned long)((r & 1) * 64);     // (lines are 128-byte aligned)
+            glds16(ok ? reinterpret_cast<const char*>(src) : zp, Bst + bs * B_BYTES + grp * 1024);
+        } else {
+            constexpr int plane = r / BPP, i = r % BPP;
             const int grp = wave * BPP + i;
             const bool ok = grp * 16 < npad_rows;         // (wave-uniform)
             glds16(ok ? w_lane + ((long)grp * w_row16 + plane * 64 + w_k) : zp, Bst + bs * B_BYTES + plane * BN * 64 + grp * 1024);
@@ -217,14 +257,14 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
         Rb[i] = wm * WTM + i * 32 + l31;
         oxp[i] = (bm0 + Rb[i]) % W - p_i;
     }
-    const unsigned b_lane = (unsigned)((wn * WTN + l31) * 64);     // B fragment rows: wave-tile base (multiple of 32) + l31
+    // B fragment rows: wave-tile base (multiple of 32) + l31; WIDE: 128-byte rows, slot (plane*4 + khalf*2 + lh) ^ ((l31 >> 1) & 7)
+    const unsigned b_lane = WIDE ? (unsigned)((wn * WTN + l31) * 128 + ((lh ^ ((l31 >> 1) & 7)) * 16)) : (unsigned)((wn * WTN + l31) * 64);
     const unsigned so0 = (unsigned)swz(l31, lh) * 2u, so1 = (unsigned)swz(l31, 2 + lh) * 2u;
 
     // ---- prologue: A rows of super-step 0 and the B tile of step 0, landed and published
     static_for<APW>([&](auto IT) __attribute__((always_inline)) { issue_A(IT, 0); });
     a_advance();
-    issue_B_plane(0, 0);
-    issue_B_plane(1, 0);
+    static_for<2 * BPP>([&](auto RQ) __attribute__((always_inline)) { issue_B(RQ, 0); });
     advance_B(false);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -240,7 +280,8 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
             constexpr int i = decltype(I)::value;
             const bool xin = (unsigned)(oxp[i] + sh) < (unsigned)W;
             const int R = xin ? Rb[i] + sh : AR;
-            fa_a0[i] = lds0 + Ab + (unsigned)R * 64u + (unsigned)(((R >> 2) & 3) ^ lh) * 16u;  // k-half 0: slot lh; k-half 1: slot 2 + lh (^ 32 bytes)
+            if constexpr (WIDE) fa_a0[i] = lds0 + Ab + (unsigned)R * 128u + (unsigned)(((R >> 1) & 7) ^ lh) * 16u;   // k-half 1: ^ 32 bytes, lo: ^ 64 bytes
+            else fa_a0[i] = lds0 + Ab + (unsigned)R * 64u + (unsigned)(((R >> 2) & 3) ^ lh) * 16u;  // k-half 0: slot lh; k-half 1: slot 2 + lh (^ 32 bytes)
         });
         fa_bb = lds0 + (unsigned)(bs * B_BYTES) + b_lane;
     };
@@ -264,8 +305,13 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
             const unsigned so = ks ? so1 : so0;
             static_for<TN>([&](auto J) __attribute__((always_inline)) {
                 constexpr int j = decltype(J)::value;
-                rd(Bh[ks][j], bb + so + j * 32 * 64);
-                rd(Bl[ks][j], bb + so + BN * 64 + j * 32 * 64);
+                if constexpr (WIDE) {
+                    rd(Bh[ks][j], (bb ^ (ks ? 32u : 0u)) + j * 32 * 128);
+                    rd(Bl[ks][j], (bb ^ (ks ? 96u : 64u)) + j * 32 * 128);
+                } else {
+                    rd(Bh[ks][j], bb + so + j * 32 * 64);
+                    rd(Bl[ks][j], bb + so + BN * 64 + j * 32 * 64);
+                }
             });
         };
         auto loadA = [&](auto U) __attribute__((always_inline)) {
@@ -274,7 +320,7 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
                 constexpr int ii = decltype(II)::value;
                 const unsigned a = a0[2 * ih + ii] ^ (ks ? 32u : 0u);
                 rd(Ah[set][ii], a);
-                rd(Al[set][ii], a + APL);
+                rd(Al[set][ii], WIDE ? a ^ 64u : a + APL);
             });
         };
         loadB(std::integral_constant<int, 0>{});
@@ -331,14 +377,7 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
                 static_for<r1 - r0>([&](auto RR) __attribute__((always_inline)) {
                     constexpr int r = r0 + decltype(RR)::value;
                     if constexpr (r < 2 * BPP) {
-                        if (moreB) {
-                            constexpr int plane = r / BPP, i = r % BPP;
-                            if (abl != 2) {
-                                const int grp = wave * BPP + i;
-                                const bool ok = grp * 16 < npad_rows;     // (wave-uniform)
-                                glds16(ok ? w_lane + ((long)grp * w_row16 + plane * 64 + w_k) : zp, Bst + (bs ^ 1) * B_BYTES + plane * BN * 64 + grp * 1024);
-                            }
-                        }
+                        if (moreB) issue_B(std::integral_constant<int, r>{}, bs ^ 1);
                     } else {
                         constexpr int it = kx + (r - 2 * BPP) * ASTEPS;
                         if constexpr (kx < ASTEPS && it < APW) {
@@ -375,19 +414,26 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
 }
 
-template <int BM, int BN, int KW>
-int launch_kw(const ConvP& p, hipStream_t s) {
+template <int BM, int BN, int KW, bool WIDE>
+int launch_kw_img(const ConvP& p, hipStream_t s) {
     constexpr size_t smem = (size_t)2 * (2 * BN * 64) + (size_t)2 * (2 * (BM + HALO + 1) * 64);
     static_assert(smem <= 160 * 1024, "LDS buffers do not fit");
     static std::atomic<unsigned long long> lds_set{0};
-    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_taps_il_kernel<BM, BN, KW>), (int)smem, lds_set, "conv_taps_il")) return rc;
+    if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_taps_il_kernel<BM, BN, KW, WIDE>), (int)smem, lds_set, "conv_taps_il")) return rc;
     ConvP q = p;
     q.mtiles = cdiv(p.M, BM);
     q.ntiles = cdiv(p.Cout_g, BN);
     q.mchunk = cdiv(q.mtiles, 8);
     dim3 grid(q.xcd_swizzle ? 8 * q.mchunk * q.ntiles : q.mtiles * q.ntiles, p.d.groups);
-    hipLaunchKernelGGL((conv_taps_il_kernel<BM, BN, KW>), grid, dim3(BM * 2), smem, s, q);
+    hipLaunchKernelGGL((conv_taps_il_kernel<BM, BN, KW, WIDE>), grid, dim3(BM * 2), smem, s, q);
     return fgt_check_launch("conv_taps_il");
+}
+
+// interleaved split inputs (in_split = 2; weights are always per-step interleaved lines): the wide LDS image; plane inputs: 64-byte rows
+template <int BM, int BN, int KW>
+int launch_kw(const ConvP& p, hipStream_t s) {
+    static const bool wide = [] { const char* e = getenv("FGT_TAPS_WIDE"); return !(e && e[0] == '0'); }();      // (0: A/B measurements)
+    return p.d.in_split == 2 && wide ? launch_kw_img<BM, BN, KW, true>(p, s) : launch_kw_img<BM, BN, KW, false>(p, s);
 }
 
 template <int BM, int BN>

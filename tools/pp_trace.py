@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--build", action="store_true")
     ap.add_argument("--layer", default="e20enc10")
     ap.add_argument("--tile", default="256x128it")
+    ap.add_argument("--il", action="store_true", help="interleaved split inputs (the wide LDS image)")
     a = ap.parse_args()
     if a.build:
         from fgt_amd import build
@@ -39,7 +40,7 @@ def main():
     x1 = torch.randn(N, H, W, C1, device=dev) if C1 else None
     w = torch.randn(Cout, (C0 + C1) // g, kh, kw, device=dev) * 0.02
     pc = ops.PackedConv(w, torch.zeros(Cout, device=dev), groups=g)
-    xs, x1s = ops.split(x), (ops.split(x1) if C1 else None)
+    xs, x1s = ops.split(x, interleave=a.il), (ops.split(x1, interleave=a.il) if C1 else None)        # --il: the wide LDS image (8-row x 128-byte pieces)
     for _ in range(5):
         ops.conv2d(xs, pc, x1=x1s, stride=s, pad=p, act="lrelu", tile=a.tile, precision="bf16x3")
     torch.cuda.synchronize()

@@ -108,7 +108,7 @@ def main():
         cells = []
         for t in TILES:
             o1, o2 = torch.empty_like(out), torch.empty_like(out)
-            if t.endswith(("s3", "s4", "pp", "il", "p8", "p8n", "p8l", "ea", "lw", "xy", "w", "t")) or t.startswith("x2") or a.split_only:        # split inputs only
+            if t.endswith(("ig", "it", "s3", "s4", "pp", "il", "p8", "p8n", "p8l", "ea", "lw", "xy", "w", "t")) or t.startswith("x2") or a.split_only:        # split inputs only
                 ops.conv2d(x, pc, x1=x1, stride=s, pad=p, upsample=up, act="lrelu", tile="128x128", precision="bf16x3", out=o1)
                 ms_a = float("inf")
             else:
