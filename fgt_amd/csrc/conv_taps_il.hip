@@ -22,8 +22,16 @@
 //   128 x 128, 4 wavefronts, 68 KB of LDS: two workgroups per CU        ("128x128it")
 //   256 x 128, 8 wavefronts, 100 KB; 256 x 256, 8 wavefronts, 132 KB: one workgroup per CU  ("256x128it", "256x256it")
 // Step (kx tap of a (ky, 32-channel chunk) super-step) of every wavefront:
-//   | first reads ... then per group of four MFMAs ONE request behind it: the B(s+1) pieces first, then this tap's A(ss+1) pieces; behind the
-//     last group the next step's fragment addresses; vmcnt(this step's A pieces) | barrier
+//   (before the barrier: the first A fragments — their A buffer was published at least a barrier ago) | barrier | 4 B reads | 24 (48) MFMAs with
+//   AT MOST ONE filler behind each — a ds_read_b128 of the next sub-step, or one block of the next step's fragment addresses — and ONE LDS-DMA
+//   request behind every fourth (the B(s+1) pieces first, then A pieces of the next (ky, chunk)) | wait for this step's B requests | barrier
+// What the per-wavefront timeline (tools/pp_trace.py) said along the way, cycles per step of the 128 x 128 tile at two workgroups per CU:
+//   requests all behind the first 12 MFMAs 3 260 -> one per four MFMAs 2 950 -> wide image 2 980 (the DMA engine was not the bound) -> first A
+//   reads before the barrier + first MFMA group waiting for 2 reads instead of 8 (barrier -> first MFMA 560 -> 235) 2 850 -> fillers one per
+//   MFMA instead of a burst behind each group (a lone wavefront hides ~5 issue slots per MFMA, a burst leaves the pipe idle) 2 570; no
+//   compare-and-branch chain in front of the vmcnt wait: another 2 % in the sweeps.  A wavefront ALONE on its SIMD (one workgroup per CU, no
+//   DMA) still needs 1 000-1 100 cycles for its 24 MFMAs (768) + ~900 for tail / barrier / first reads: the two wavefronts of a SIMD fall into
+//   lock step (period ~ 2 x MFMAs + the rest) rather than filling each other's gaps; s_setprio for the second half of a step did not break it.
 // Normal mode only (the reused taps are the kx taps of a stride-1 "same" convolution): the transposed k x 1 mode and the nearest-x2 upsampling
 // stay on conv_taps.hip's tiles (fgt_conv_taps_il_launch declines them).  The request path is written for few live scalars: its first version
 // kept conv_taps.hip's generality and executed ~200 v_readlane reloads of spilled SGPRs per step.
@@ -65,6 +73,9 @@ template <int MAXA> __device__ __forceinline__ void wait_vmcnt_upto(int na) {   
     }
 }
 
+#ifndef FGT_IL_A_EARLY
+#define FGT_IL_A_EARLY 2          // A request schedule: 0 spread / 1 all in tap 0; 2: the default per instance (below)
+#endif
 constexpr int HALO = 16;          // extra A rows per (ky, chunk): (kw - 1) * dw <= 16
 
 #ifdef FGT_PP_TRACE
@@ -100,7 +111,16 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     constexpr int NGA = BM / 16 / NW;                    // A row groups (of both planes) a wavefront owns: 2
     constexpr int APW = 2 * NGA + 1;                     // A pieces a wavefront may own per (ky, chunk): 2 groups x 2 planes + the halo group (last two waves);
                                                          // WIDE: 4 groups of 8 full rows + a halo group (last two waves)
-    constexpr int ASTEPS = KW - 1;                       // they go out in taps 0 .. KW-2 of the previous super-step (piece it in tap it % ASTEPS)
+    // Schedule of a wavefront's A requests for the next (ky, chunk), ASCHED:
+    //   0  piece it in tap it % (KW-1); a tap's pieces may still fly at its end, the last land by the end of tap KW-1 — so the FIRST step of a
+    //      super-step reads its A fragments behind the barrier, the others before it (PRE);
+    //   1  all in tap 0, landed by the end of tap 1 and published by ITS barrier: every step reads its first A fragments before the barrier
+    //      in front of it.  (9 requests per wavefront in one step overrun the CU's DMA queue for a while; a third schedule — spread as in 0,
+    //      the pieces of tap KW-2 first in their step and waited for at its end — was measured 3 % slower than this one, run 38.)
+    // Default: 0 on the 64-byte image (narrow pieces: more requests in a step cost more than the early reads buy), 1 on the wide image.
+    constexpr int ASCHED = FGT_IL_A_EARLY != 2 ? FGT_IL_A_EARLY : (WIDE ? 1 : 0);
+    constexpr bool A_EARLY = ASCHED != 0;                 // every step's first A fragments are read before the barrier in front of it
+    constexpr int ASTEPS = ASCHED == 1 ? 1 : KW - 1;
     constexpr int MAXA = (APW + ASTEPS - 1) / ASTEPS;    // most A pieces a wavefront requests in one step
     constexpr int BPP = GB / NW;                         // B pieces per plane and wavefront (256x256: 2, 256x128: 1, 128x128: 2)
     static_assert((HPS == 3 || NU == 4) && (BM == 256 || BM == 128) && (BN == 128 || BN == 256) && NGA == 2 && BPP >= 1 && GB % NW == 0 && KW >= 3 && TM % 2 == 0 && WM * WN == NW,
@@ -271,86 +291,98 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
 
     // ---- fragment addresses of a step (tap kx of A buffer Ab, B stage bs): computed for the NEXT step behind the current step's last MFMAs
     unsigned fa_a0[TM], fa_bb = 0;
+    int fa_sh = 0;                                        // the tap shift the parts below work with
+    auto frag_addr_part = [&](auto PARTc, int kx, unsigned Ab, int bs) __attribute__((always_inline)) {    // part i: A block i (part 0 also: shift, B)
+        constexpr int i = decltype(PARTc)::value;
+        if constexpr (i == 0) {
+            // (opaque: the per-tap fragment addresses are recomputed per step, not hoisted and kept live across the loop)
+            int shv = kx * dwx;
+            asm volatile("" : "+v"(shv));
+            fa_sh = __builtin_amdgcn_readfirstlane(shv);
+            fa_bb = lds0 + (unsigned)(bs * B_BYTES) + b_lane;
+        }
+        const bool xin = (unsigned)(oxp[i] + fa_sh) < (unsigned)W;
+        const int R = xin ? Rb[i] + fa_sh : AR;
+        if constexpr (WIDE) fa_a0[i] = lds0 + Ab + (unsigned)R * 128u + (unsigned)(((R >> 1) & 7) ^ lh) * 16u;   // k-half 1: ^ 32 bytes, lo: ^ 64 bytes
+        else fa_a0[i] = lds0 + Ab + (unsigned)R * 64u + (unsigned)(((R >> 2) & 3) ^ lh) * 16u;  // k-half 0: slot lh; k-half 1: slot 2 + lh (^ 32 bytes)
+    };
     auto frag_addr = [&](int kx, unsigned Ab, int bs) __attribute__((always_inline)) {
-        // (opaque: the per-tap fragment addresses are recomputed per step, not hoisted and kept live across the loop)
-        int shv = kx * dwx;
-        asm volatile("" : "+v"(shv));
-        const int sh = __builtin_amdgcn_readfirstlane(shv);
-        static_for<TM>([&](auto I) __attribute__((always_inline)) {
-            constexpr int i = decltype(I)::value;
-            const bool xin = (unsigned)(oxp[i] + sh) < (unsigned)W;
-            const int R = xin ? Rb[i] + sh : AR;
-            if constexpr (WIDE) fa_a0[i] = lds0 + Ab + (unsigned)R * 128u + (unsigned)(((R >> 1) & 7) ^ lh) * 16u;   // k-half 1: ^ 32 bytes, lo: ^ 64 bytes
-            else fa_a0[i] = lds0 + Ab + (unsigned)R * 64u + (unsigned)(((R >> 2) & 3) ^ lh) * 16u;  // k-half 0: slot lh; k-half 1: slot 2 + lh (^ 32 bytes)
-        });
-        fa_bb = lds0 + (unsigned)(bs * B_BYTES) + b_lane;
+        static_for<TM>([&](auto I) __attribute__((always_inline)) { frag_addr_part(I, kx, Ab, bs); });
     };
     auto rd = [&](bf16x8& dst, unsigned addr) __attribute__((always_inline)) {
         u32x4 v;
         asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
         dst = __builtin_bit_cast(bf16x8, v);
     };
-    // ---- one step of one wavefront's matrix work: TM x TN x 6 MFMAs in sub-steps of 12 (k-half, pair of 32-row blocks), the NEXT sub-step's
-    // fragment reads in flight underneath (two register sets).  The wait carries the sub-step's fragments as "+v" operands, so no MFMA can be
-    // scheduled above it; LDS returns in order, so lgkmcnt(n) with n = the reads requested after them retires exactly this sub-step's (anything
-    // else in that queue only makes the wait stricter).  hook(u) runs behind sub-step u's MFMAs (pinned by the sched_barrier).
-    auto compute = [&](auto&& hook) __attribute__((always_inline)) {
+    // ---- one step of one wavefront's matrix work: TM x TN x 6 MFMAs in sub-steps of 12 (k-half, pair of 32-row blocks), three groups of four
+    // (lo*hi, hi*lo, hi*hi).  Fragment reads are inline assembly with hand-counted waits (hipcc alone hoists every read of a step above its
+    // first MFMA and waits for all of them): LDS returns in order, so lgkmcnt(n) with n = the reads requested after the ones needed retires
+    // exactly those; the wait carries the fragments as "+v" operands, so no MFMA can be scheduled above it.  Order of a step:
+    //   (before the barrier, in the previous step)  A fragments of sub-step 0 — their A buffer was published a barrier ago (PRE)
+    //   barrier | B fragments of k-half 0: hi, hi, lo, lo | wait hi | 4 MFMAs lo*hi | request slot | reads of the NEXT sub-step (B of the
+    //   next k-half first, then A lo, lo, hi, hi) | wait lo | 4 + 4 MFMAs, a request slot behind each | next sub-step: wait for its A lo
+    //   (all but the 2 youngest reads) ... behind the first group of the LAST sub-step: the next step's fragment addresses and its first A reads.
+    // So the first MFMA of a step waits for two ds_read_b128 behind the barrier instead of eight (+ eight more queued in front of the wait).
+    bf16x8 Bh[2][TN], Bl[2][TN];                          // [k half][32-column block]
+    bf16x8 Ah[2][2], Al[2][2];                            // [register set][block of the pair]
+    // read q of a B k-half (hi, hi, lo, lo) / of an A sub-step (lo, lo, hi, hi)
+    auto readB = [&](auto KS, auto Qc, unsigned bb) __attribute__((always_inline)) {
+        constexpr int ks = decltype(KS)::value, j = decltype(Qc)::value % TN, lo = decltype(Qc)::value / TN;
+        if constexpr (WIDE) rd(lo ? Bl[ks][j] : Bh[ks][j], (bb ^ (unsigned)((ks ? 32 : 0) + (lo ? 64 : 0))) + j * 32 * 128);
+        else rd(lo ? Bl[ks][j] : Bh[ks][j], bb + (ks ? so1 : so0) + (lo ? BN * 64 : 0) + j * 32 * 64);
+    };
+    auto readA = [&](auto U, auto Qc, const unsigned (&a0)[TM]) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value, ks = u / NIH, ih = u % NIH, set = u & 1;
+        constexpr int ii = decltype(Qc)::value % 2, hi = decltype(Qc)::value / 2;
+        const unsigned a = a0[2 * ih + ii] ^ (ks ? 32u : 0u);
+        rd(hi ? Ah[set][ii] : Al[set][ii], hi ? a : (WIDE ? a ^ 64u : a + APL));
+    };
+    auto loadB = [&](auto KS, unsigned bb) __attribute__((always_inline)) {
+        static_for<2 * TN>([&](auto Q) __attribute__((always_inline)) { readB(KS, Q, bb); });
+    };
+    auto loadA = [&](auto U, const unsigned (&a0)[TM]) __attribute__((always_inline)) {
+        static_for<4>([&](auto Q) __attribute__((always_inline)) { readA(U, Q, a0); });
+    };
+    // PRE: this step's first A fragments were requested before the barrier (by the previous step / the prologue); nxt(part): the next step's
+    // fragment addresses, one A block per part.  Every MFMA is followed by AT MOST one ds_read_b128 or one address part (a wavefront that is
+    // alone on its SIMD hides ~5 issue slots per MFMA; a burst behind a group of MFMAs leaves the pipe idle), a request slot behind every fourth.
+    auto compute = [&](auto PREc, auto PRENc, auto&& hook, auto&& nxt) __attribute__((always_inline)) {
+        constexpr bool PRE = decltype(PREc)::value, PRE_NEXT = decltype(PRENc)::value;
         unsigned a0[TM];
         static_for<TM>([&](auto I) __attribute__((always_inline)) { a0[decltype(I)::value] = fa_a0[decltype(I)::value]; });
         const unsigned bb = fa_bb;
-        bf16x8 Bh[2][TN], Bl[2][TN];                      // [k half][32-column block]
-        bf16x8 Ah[2][2], Al[2][2];                        // [register set][block of the pair]
-        auto loadB = [&](auto KS) __attribute__((always_inline)) {
-            constexpr int ks = decltype(KS)::value;
-            const unsigned so = ks ? so1 : so0;
-            static_for<TN>([&](auto J) __attribute__((always_inline)) {
-                constexpr int j = decltype(J)::value;
-                if constexpr (WIDE) {
-                    rd(Bh[ks][j], (bb ^ (ks ? 32u : 0u)) + j * 32 * 128);
-                    rd(Bl[ks][j], (bb ^ (ks ? 96u : 64u)) + j * 32 * 128);
-                } else {
-                    rd(Bh[ks][j], bb + so + j * 32 * 64);
-                    rd(Bl[ks][j], bb + so + BN * 64 + j * 32 * 64);
-                }
-            });
-        };
-        auto loadA = [&](auto U) __attribute__((always_inline)) {
-            constexpr int u = decltype(U)::value, ks = u / NIH, ih = u % NIH, set = u & 1;
-            static_for<2>([&](auto II) __attribute__((always_inline)) {
-                constexpr int ii = decltype(II)::value;
-                const unsigned a = a0[2 * ih + ii] ^ (ks ? 32u : 0u);
-                rd(Ah[set][ii], a);
-                rd(Al[set][ii], WIDE ? a ^ 64u : a + APL);
-            });
-        };
-        loadB(std::integral_constant<int, 0>{});
-        loadA(std::integral_constant<int, 0>{});
+        if constexpr (!PRE) loadA(std::integral_constant<int, 0>{}, a0);
+        loadB(std::integral_constant<int, 0>{}, bb);
         static_for<NU>([&](auto U) __attribute__((always_inline)) {
             constexpr int u = decltype(U)::value, ks = u / NIH, ih = u % NIH, set = u & 1;
             constexpr bool more = u + 1 < NU, nextB = more && (u + 1) % NIH == 0;
-            if constexpr (nextB) loadB(std::integral_constant<int, (u + 1) / NIH>{});
-            if constexpr (more) loadA(std::integral_constant<int, u + 1>{});
-            constexpr int pending = more ? 4 + (nextB ? 2 * TN : 0) : 0;          // reads requested after this sub-step's
-            asm volatile("s_waitcnt lgkmcnt(%8)"
-                         : "+v"(Ah[set][0]), "+v"(Al[set][0]), "+v"(Ah[set][1]), "+v"(Al[set][1]), "+v"(Bh[ks][0]), "+v"(Bl[ks][0]), "+v"(Bh[ks][1]), "+v"(Bl[ks][1])
-                         : "n"(pending));
+            constexpr int NB = nextB ? 2 * TN : 0;                                      // reads behind MFMA m: m < NB: B of the next k-half; then 4 A reads
+            constexpr int A0 = more ? NB : 4;                                           // (last sub-step: address parts behind MFMAs 0..TM-1, reads behind 4..7)
+            constexpr int NRD = more ? NB + 4 : (PRE_NEXT ? 8 : 0);
+            static_assert(TM <= 4 && NRD <= 8 && 12 == 3 * 2 * TN, "filler slots of a sub-step");
+            // operands of the first group: A lo of this sub-step and B hi of its k-half — everything but the 2 youngest reads
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(Al[set][0]), "+v"(Al[set][1]), "+v"(Bh[ks][0]), "+v"(Bh[ks][1]));
             if constexpr (u == 0) PP_STAMP(5);
-            // same products as conv_taps.hip / conv_split.hip (lo*hi, hi*lo, hi*hi per accumulator and k-half)
-            static_for<3>([&](auto P) __attribute__((always_inline)) {
-                constexpr int prod = decltype(P)::value;
-                static_for<2>([&](auto II) __attribute__((always_inline)) {
-                    constexpr int ii = decltype(II)::value;
-                    static_for<TN>([&](auto J) __attribute__((always_inline)) {
-                        constexpr int j = decltype(J)::value;
-                        const bf16x8 av = prod == 0 ? Al[set][ii] : Ah[set][ii];
-                        const bf16x8 bv = prod == 1 ? Bl[ks][j] : Bh[ks][j];
-                        acc[2 * ih + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[2 * ih + ii][j], 0, 0, 0);
-                    });
-                });
-                if constexpr (HPS == 3 || prod == 2) {
-                    __builtin_amdgcn_sched_barrier(0);    // the hook's address arithmetic / LDS-DMA issue goes BEHIND these MFMAs
-                    hook(std::integral_constant<int, HPS == 3 ? u * 3 + prod : u>{});
+            static_for<12>([&](auto Mc) __attribute__((always_inline)) {
+                constexpr int m = decltype(Mc)::value, prod = m / 4, ii = (m % 4) / TN, j = m % TN;
+                if constexpr (m == 4) {                                                 // hi*lo needs A hi and B lo: all but the reads behind MFMAs 0..3
+                    constexpr int pending = more ? 4 : 0;
+                    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(Ah[set][0]), "+v"(Ah[set][1]), "+v"(Bl[ks][0]), "+v"(Bl[ks][1]) : "n"(pending));
                 }
+                // same products as conv_taps.hip / conv_split.hip (lo*hi, hi*lo, hi*hi per accumulator and k-half)
+                const bf16x8 av = prod == 0 ? Al[set][ii] : Ah[set][ii];
+                const bf16x8 bv = prod == 1 ? Bl[ks][j] : Bh[ks][j];
+                acc[2 * ih + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[2 * ih + ii][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);                                      // the filler goes BEHIND this MFMA
+                if constexpr (more) {
+                    if constexpr (m < NB) readB(std::integral_constant<int, (u + 1) / NIH>{}, Mc, bb);
+                    else if constexpr (m < NB + 4) readA(std::integral_constant<int, u + 1>{}, std::integral_constant<int, m - NB>{}, a0);
+                } else {
+                    if constexpr (m < TM) nxt(Mc);
+                    if constexpr (PRE_NEXT && m >= 4 && m < 8) readA(std::integral_constant<int, 0>{}, std::integral_constant<int, m - 4>{}, fa_a0);
+                }
+                if constexpr (m % 4 == 3 && (HPS == 3 || m == 11)) hook(std::integral_constant<int, HPS == 3 ? u * 3 + prod : u>{});
+                __builtin_amdgcn_sched_barrier(0);
             });
         });
     };
@@ -359,6 +391,7 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
 
     int bs = 0;                                           // B stage of this step
     frag_addr(0, (unsigned)(2 * B_BYTES), 0);
+    if constexpr (A_EARLY) loadA(std::integral_constant<int, 0>{}, fa_a0);
     for (int ss = 0; ss < nss; ++ss) {
         const bool last = ss + 1 == nss;
         const unsigned Ab = (unsigned)(2 * B_BYTES + (ss & 1) * A_BYTES);          // byte offset of this super-step's A buffer in the LDS
@@ -367,8 +400,7 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
             const bool moreB = !(last && kx == KW - 1);
             int na = 0;
             // request slot h of this step: the B pieces of step s+1 first (they are read right behind the barrier), one per slot, then this
-            // wavefront's A pieces of super-step ss+1 that belong to tap kx (pieces it = kx, kx + ASTEPS, ...); the last slot also computes the
-            // next step's fragment addresses
+            // wavefront's A pieces of super-step ss+1 that belong to tap kx (pieces it = kx, kx + ASTEPS, ...)
             auto hook = [&](auto Hh) __attribute__((always_inline)) {
                 constexpr int h = decltype(Hh)::value;
                 // HPS == 3: requests r with r * NHOOK / NREQ == h; HPS == 1 (four slots): B plane 0 | B plane 1 | the A pieces | addresses only
@@ -385,18 +417,21 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
                         }
                     }
                 });
-                if constexpr (h == NHOOK - 1) {             // the next step's fragment addresses, under this step's last MFMAs
-                    constexpr int nkx = (kx + 1) % KW;
-                    const unsigned nAb = nkx == 0 ? (unsigned)(2 * B_BYTES + ((ss + 1) & 1) * A_BYTES) : Ab;
-                    frag_addr(nkx, nAb, bs ^ 1);
-                }
+            };
+            auto nxt = [&](auto PARTc) __attribute__((always_inline)) {  // the next step's fragment addresses, one A block per part
+                constexpr int nkx = (kx + 1) % KW;
+                const unsigned nAb = nkx == 0 ? (unsigned)(2 * B_BYTES + ((ss + 1) & 1) * A_BYTES) : Ab;
+                frag_addr_part(PARTc, nkx, nAb, bs ^ 1);
             };
             PP_STAMP(0);
-            compute(hook);
+            compute(std::integral_constant<bool, (A_EARLY || kx > 0)>{}, std::integral_constant<bool, (A_EARLY || kx + 1 < KW)>{}, hook, nxt);
             PP_STAMP(6);
             if (moreB) advance_B((kx + 1) % KW == KW - 1);
             __builtin_amdgcn_sched_barrier(0);
-            wait_vmcnt_upto<MAXA>(na);                    // the next step's B tile (and every older A piece) has landed; this step's A pieces may fly on
+            // the next step's B tile (and every older A piece) has landed; this step's A pieces may fly on.  (Taps without A requests: no
+            // compare-and-branch chain — five taken branches cost ~150 cycles per step.)
+            if constexpr (kx >= ASTEPS) wait_vmcnt<0>();
+            else wait_vmcnt_upto<MAXA>(na);
             PP_STAMP(3);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -416,8 +451,14 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
 
 template <int BM, int BN, int KW, bool WIDE>
 int launch_kw_img(const ConvP& p, hipStream_t s) {
-    constexpr size_t smem = (size_t)2 * (2 * BN * 64) + (size_t)2 * (2 * (BM + HALO + 1) * 64);
-    static_assert(smem <= 160 * 1024, "LDS buffers do not fit");
+    constexpr size_t smem0 = (size_t)2 * (2 * BN * 64) + (size_t)2 * (2 * (BM + HALO + 1) * 64);
+    static_assert(smem0 <= 160 * 1024, "LDS buffers do not fit");
+#ifdef FGT_PP_TRACE
+    static const size_t pad = [] { const char* e = getenv("FGT_IL_LDS_PAD"); return e ? (size_t)atoi(e) : 0; }();      // (occupancy experiments: one workgroup per CU)
+    const size_t smem = smem0 + pad;
+#else
+    constexpr size_t smem = smem0;
+#endif
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_taps_il_kernel<BM, BN, KW, WIDE>), (int)smem, lds_set, "conv_taps_il")) return rc;
     ConvP q = p;

@@ -57,6 +57,14 @@ def main():
         med = lambda a, b: np.median(t0[wv, :, b] - t0[wv, :, a])
         period = np.diff(t0[wv, :, 0])
         print(f"{wv:4d} | {med(0, 5):19.0f} | {med(5, 6):30.0f} | {med(6, 3):12.0f} | {med(3, 4):7.0f} | {np.median(period):11.0f}")
+    kw_ = int(kw)
+    print(f"wave 0, MEAN cycles by tap (step % {kw_}): top->first MFMA | MFMAs | tail+vmcnt | barrier | behind barrier -> next top | period")
+    for kx in range(kw_):
+        idx = [st for st in range(2, STEPS - 1) if st % kw_ == kx]
+        seg = lambda a, b: np.mean([t[0, st, b] - t[0, st, a] for st in idx])
+        gap = np.mean([t[0, st + 1, 0] - t[0, st, 4] for st in idx])
+        per = np.mean([t[0, st + 1, 0] - t[0, st, 0] for st in idx])
+        print(f"  tap {kx}: {seg(0, 5):6.0f} | {seg(5, 6):6.0f} | {seg(6, 3):6.0f} | {seg(3, 4):6.0f} | {gap:6.0f} | {per:6.0f}")
     print("steps 2..9 of wave 0 (G0) and wave 4 (G1), stamps relative to the first:")
     for wv in (0, 3):
         for st in range(2, 10):
