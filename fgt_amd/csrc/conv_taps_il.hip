@@ -116,7 +116,8 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     //      super-step reads its A fragments behind the barrier, the others before it (PRE);
     //   1  all in tap 0, landed by the end of tap 1 and published by ITS barrier: every step reads its first A fragments before the barrier
     //      in front of it.  (9 requests per wavefront in one step overrun the CU's DMA queue for a while; a third schedule — spread as in 0,
-    //      the pieces of tap KW-2 first in their step and waited for at its end — was measured 3 % slower than this one, run 38.)
+    //      the pieces of tap KW-2 first in their step and waited for at its end — was measured 3 % slower than this one (run 38), the A
+    //      requests behind the step's last MFMA instead of in its request slots 1-3 % slower (run 41).)
     // Default: 0 on the 64-byte image (narrow pieces: more requests in a step cost more than the early reads buy), 1 on the wide image.
     constexpr int ASCHED = FGT_IL_A_EARLY != 2 ? FGT_IL_A_EARLY : (WIDE ? 1 : 0);
     constexpr bool A_EARLY = ASCHED != 0;                 // every step's first A fragments are read before the barrier in front of it

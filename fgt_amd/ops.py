@@ -456,7 +456,8 @@ def _aliases(out, out_s, *ins):
 
 
 def _autotune(d, args, candidates=None):
-    """Time each tile candidate on the current stream (1 warm + 2 timed launches) and return the fastest tile code."""
+    """Time each tile candidate on the current stream (1 warm + 4 timed launches; candidates of a family differ by 2-10 %, two launches
+    were within the noise) and return the fastest tile code."""
     fn, st = _lib.lib().fgt_conv2d, _stream()
     best, best_ms = 0, None
     for name in (candidates or TILE_CANDIDATES):
@@ -465,8 +466,8 @@ def _autotune(d, args, candidates=None):
             continue
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        fn(*args, st)
-        fn(*args, st)
+        for _ in range(4):
+            fn(*args, st)
         e1.record()
         e1.synchronize()
         ms = e0.elapsed_time(e1)
