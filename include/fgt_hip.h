@@ -166,7 +166,11 @@ typedef struct fgt_conv_desc {
                                   * (3x3: -31 % LDS-DMA instructions, the im2col stream from memory shrinks by kw).  It accumulates in the order (ky, chunk, kx):
                                   * NOT bit-identical to the other kernels, same error.  fgt_conv2d therefore routes by GEOMETRY: a layer this kernel serves runs
                                   * on it whenever tile = 0 (k x 1 layers only when H >= 16) or a +200 code; an explicit tile of another family selects that family.  Its tiles are bit-identical
-                                  * to each other.  FGT_CONV_TAPS=0 (environment) turns the routing off. */
+                                  * to each other.  FGT_CONV_TAPS=0 (environment) turns the routing off.
+                                  * Codes 200 + 26 / 5 / 17 ("128x128it", "256x128it", "256x256it"; round 4) = the same arithmetic with the step's LDS-DMA
+                                  * requests and fragment reads interleaved into its MFMAs (csrc/conv_taps_il.hip: 128x128 on 4 wavefronts at two
+                                  * workgroups per CU, 256x128 and 256x256 on 8; a wide LDS image for interleaved inputs): bit-identical to the other
+                                  * tap tiles; they decline k x 1 and upsampling layers (and 256x256 kw != 3) with FGT_EINVAL. */
 #define FGT_TILE_TAPS_BREG 300   /* DIAGNOSTIC BUILDS ONLY: the same kernel with weights in MFMA fragment order (w_il = 2) loaded straight into registers */
 #define FGT_TILE_F16_WIDE 100    /* FGT_PREC_F16 only: tile code + 100 = the same tile on the "wide" LDS image (a stage row is the pixel's whole
                                   * 128-byte line of the 64-channel K-step; an LDS-DMA instruction copies 8 full cache lines instead of 16 half
