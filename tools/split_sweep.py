@@ -58,6 +58,11 @@ LAYERS = {  # name: (N, H, W, C0, C1, Cout, groups, k, stride, pad)
     "dec up 64->64 120x216": (8, 120, 216, 64, 0, 64, 1, 3, 1, 1),
     "lafc up 96+96->48 120x216": (8, 120, 216, 96, 96, 48, 1, 3, 1, 1),
     "lafc up 192+192->96 60x108": (8, 60, 108, 192, 192, 96, 1, 3, 1, 1),
+    # 4-channel input convs (FGT flow encoder, RAFT flow encoder) and the same with Cin zero-padded to 8 (split planes need C % 8 == 0)
+    "in4 5x5 4->64 240x432": (20, 240, 432, 4, 0, 64, 1, 5, 1, 2),
+    "in8 5x5 8->64 240x432": (20, 240, 432, 8, 0, 64, 1, 5, 1, 2),
+    "in4 7x7 4->128 60x108": (32, 60, 108, 4, 0, 128, 1, 7, 1, 3),
+    "in8 7x7 8->128 60x108": (32, 60, 108, 8, 0, 128, 1, 7, 1, 3),
     # LAFC P3D temporal convs: 3 x 1 over (T = 3, H*W)
     "lafc p3d 96 3x1 T": (8, 3, 25920, 96, 0, 96, 1, (3, 1), 1, (1, 0)),
     "lafc p3d 192 3x1 T": (8, 3, 6480, 192, 0, 192, 1, (3, 1), 1, (1, 0)),
@@ -121,9 +126,9 @@ def main():
                 try:
                     ms_b = bench(lambda: ops.conv2d(xs, pc, x1=x1s, stride=s, pad=p, upsample=up, act="lrelu", tile=t, precision="bf16x3", out=o2), a.reps)
                 except RuntimeError as e:                                              # e.g. a tap-reusing tile on a layer that kernel does not serve
-                    if "does not serve" not in str(e):
+                    if "does not serve" not in str(e) and "must be multiples" not in str(e):
                         raise
-                    cells.append(f"{'-':>18s}")
+                    cells.append(f"{fl / ms_a / 1e9:5.0f}/    -/    - ")
                     continue
             ms_c = float("inf")
             if can_il and (wide or not a.split_only):
