@@ -11,10 +11,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # no fallback — a missing file raises.
 LIB_PATH = os.environ.get("FGT_HIP_LIB") or os.path.join(_HERE, "lib", "libfgt_hip.so")
 
-ABI_VERSION = 6        # include/fgt_hip.h: what fgt_abi_version() of a matching build returns
+ABI_VERSION = 7        # include/fgt_hip.h: what fgt_abi_version() of a matching build returns
 
 ACT = {"none": 0, None: 0, "lrelu": 1, "relu": 2, "sigmoid": 3, "tanh": 4}
-EPI = {"none": 0, None: 0, "mul": 1, "add": 2, "gru": 3}
+EPI = {"none": 0, None: 0, "mul": 1, "add": 2, "gru": 3, "affine": 4, "ps_add2": 5}
 PREC = {"fp32": 0, None: 0, "bf16x3": 1, "f16": 2}
 TILE = {"auto": 0, None: 0, "128x128": 1, "128x64": 2, "64x64": 3, "128x32": 4, "256x128": 5, "128x128x8": 6, "256x128x16": 7, "256x64x8": 8, "256x128x8s3": 10, "256x128x16s3": 11, "128x128x8s4": 12, "256x128x8pp": 13, "128x128x8pp": 14, "256x128x8il": 16, "256x256p8": 17, "256x128p8": 18, "128x128ea": 26, "128x64ea": 27, "64x64ea": 28, "128x128x8ea": 29, "256x128x16ea": 30, "256x64x8ea": 31, "128x128x8lw": 32, "128x128lw": 33, "128x64lw": 34, "128x128x8xy": 35,
         "256x128ea": 38,      # f16 kernel only
@@ -36,7 +36,8 @@ class ConvDesc(C.Structure):
                [(n, C.c_int) for n in ("epi", "act2", "ld_aux1", "ld_aux2")] + \
                [("out_scale", C.c_float)] + \
                [(n, C.c_int) for n in ("Kpad", "Npad", "tile", "precision", "in_split", "out_split", "ldo_s", "ooff_s", "w_il", "k_alg")] + \
-               [(n, C.c_longlong) for n in ("ps0", "ps1", "pso")]
+               [(n, C.c_longlong) for n in ("ps0", "ps1", "pso")] + \
+               [(n, C.c_int) for n in ("ps_r", "ps_c", "ps_g0", "ps_H", "ps_W", "ky_skip_n0", "aux_per_image", "n_alg")]      # ABI 7
 
 
 class AttnDesc(C.Structure):

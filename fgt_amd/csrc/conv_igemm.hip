@@ -375,10 +375,10 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
         FGT_REQUIRE(p.Cout_g % 4 == 0 && !d.out_nchw && d.ldo_s % 4 == 0 && d.ooff_s % 4 == 0 && (d.pso == -1 || (d.pso % 4 == 0 && d.pso > 0)),
                     "fgt_conv2d: out_split needs Cout/groups, ldo_s, ooff_s, pso multiples of 4 (pso = -1: fp16 plane) and NHWC output");
         FGT_REQUIRE(d.out_split == 1 || (d.ldo % 4 == 0 && d.ooff % 4 == 0), "fgt_conv2d: out_split = 2 needs ldo, ooff multiples of 4");
-        FGT_REQUIRE(d.pso != 32 || (p.Cout_g % 32 == 0 && d.ooff_s % 32 == 0 && d.ldo_s % 64 == 0),
+        FGT_REQUIRE(d.pso != 32 || ((p.Cout_g % 32 == 0 || d.ps_r > 0) && d.ooff_s % 32 == 0 && d.ldo_s % 64 == 0),
                     "fgt_conv2d: interleaved out_s (pso = 32) needs Cout/groups, ooff_s multiples of 32 and ldo_s a multiple of 64");
         FGT_REQUIRE(d.epi == FGT_EPI_NONE || d.ld_aux1 % 4 == 0, "fgt_conv2d: out_split needs ld_aux1 % 4 == 0");
-        FGT_REQUIRE(d.epi != FGT_EPI_GRU || d.ld_aux2 % 4 == 0, "fgt_conv2d: out_split needs ld_aux2 % 4 == 0");
+        FGT_REQUIRE(d.epi < FGT_EPI_GRU || d.ld_aux2 % 4 == 0, "fgt_conv2d: out_split needs ld_aux2 % 4 == 0");
     }
     FGT_REQUIRE(((uintptr_t)x0 & 15) == 0 && ((uintptr_t)x1 & 15) == 0 && ((uintptr_t)w_packed & 15) == 0,
                 "fgt_conv2d: pointers must be 16-byte aligned");
@@ -390,11 +390,28 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     p.K = d.kh * d.kw * p.Cg;
     FGT_REQUIRE(d.Kpad % BK == 0 && d.Kpad >= p.K, "fgt_conv2d: Kpad %d invalid for K %d", d.Kpad, p.K);
     FGT_REQUIRE(d.Npad % 128 == 0 && d.Npad >= p.Cout_g, "fgt_conv2d: Npad %d invalid for Cout/groups %d", d.Npad, p.Cout_g);
+    FGT_REQUIRE(d.epi >= FGT_EPI_NONE && d.epi <= FGT_EPI_PS_ADD2, "fgt_conv2d: unknown epilogue %d", d.epi);
     if (d.epi != FGT_EPI_NONE) FGT_REQUIRE(aux1 != nullptr, "fgt_conv2d: epilogue needs aux1");
-    if (d.epi == FGT_EPI_GRU) FGT_REQUIRE(aux2 != nullptr, "fgt_conv2d: GRU epilogue needs aux2");
+    if (d.epi >= FGT_EPI_GRU) FGT_REQUIRE(aux2 != nullptr, "fgt_conv2d: GRU / affine / sub-pixel-add epilogues need aux2");
+    // ---- ABI 7: fold as a convolution (sub-pixel output, per-image aux tables, ky = 0 skipping)
+    FGT_REQUIRE(d.ps_r >= 0 && d.ky_skip_n0 >= 0 && (d.aux_per_image == 0 || d.aux_per_image == 1), "fgt_conv2d: bad ps_r / ky_skip_n0 / aux_per_image");
+    FGT_REQUIRE(d.epi != FGT_EPI_PS_ADD2 || d.ps_r > 0, "fgt_conv2d: FGT_EPI_PS_ADD2 needs the sub-pixel output (ps_r > 0)");
+    FGT_REQUIRE(!(d.ps_r || d.aux_per_image) || d.kw > 1 || d.kh == 1, "fgt_conv2d: sub-pixel output / per-image aux tables are not built for k x 1 layers (transposed tile order)");
+    FGT_REQUIRE(!d.aux_per_image || d.epi != FGT_EPI_NONE, "fgt_conv2d: aux_per_image without an epilogue operand");
+    FGT_REQUIRE(d.epi < FGT_EPI_AFFINE || (d.ld_aux1 % 4 == 0 && d.ld_aux2 % 4 == 0 && p.Cout_g % 4 == 0), "fgt_conv2d: affine / sub-pixel-add epilogues need ld_aux1, ld_aux2, Cout/groups multiples of 4");
+    if (d.ps_r) {
+        FGT_REQUIRE(d.groups == 1 && !d.out_nchw && d.ps_c > 0 && d.ps_c % 4 == 0 && d.ps_g0 >= d.ps_r * d.ps_c && d.ps_g0 % 4 == 0 &&
+                    d.Cout == d.ps_g0 + (d.ps_r - 1) * d.ps_r * d.ps_c, "fgt_conv2d: sub-pixel output needs groups = 1, NHWC, ps_c %% 4 == 0 and Cout = ps_g0 + (r-1)*r*ps_c (got r %d, c %d, g0 %d, Cout %d)", d.ps_r, d.ps_c, d.ps_g0, d.Cout);
+        FGT_REQUIRE(d.ps_H > 0 && d.ps_W > 0 && d.ps_H <= d.ps_r * Ho && d.ps_W <= d.ps_r * Wo, "fgt_conv2d: sub-pixel output map %dx%d does not fit %d x the %dx%d grid", d.ps_H, d.ps_W, d.ps_r, Ho, Wo);
+        FGT_REQUIRE((d.out_split == 1 || (d.ldo % 4 == 0 && d.ooff % 4 == 0)) && (d.epi == FGT_EPI_NONE || d.ld_aux1 % 4 == 0), "fgt_conv2d: sub-pixel output needs float4-aligned rows");
+        FGT_REQUIRE(!d.out_split || d.pso != 32 || d.ps_c % 32 == 0, "fgt_conv2d: interleaved sub-pixel out_s needs ps_c %% 32 == 0");
+    }
+    FGT_REQUIRE(!(d.ps_r || d.aux_per_image || d.epi >= FGT_EPI_AFFINE) || p.Cout_g > 4, "fgt_conv2d: the Cout <= 4 kernels have no sub-pixel / per-image-table epilogue");
+    FGT_REQUIRE(d.ky_skip_n0 == 0 || (d.groups == 1 && d.kh >= 2 && d.upsample == 0), "fgt_conv2d: ky_skip_n0 needs groups = 1, kh >= 2, no upsampling");
     const long M = (long)d.N * Ho * Wo;
     FGT_REQUIRE(M < (1l << 31), "fgt_conv2d: M too large");
     p.M = (int)M; p.HoWo = Ho * Wo; p.nk = d.Kpad / (d.in_split == 3 ? 64 : BK);
+    p.div_howo = fgt_fastdiv_make((unsigned)(Ho * Wo)); p.div_wo = fgt_fastdiv_make((unsigned)Wo);
     static const int pipe_env = [] { const char* e = getenv("FGT_CONV_PIPE"); return e ? atoi(e) : 1; }();
     p.pipe = pipe_env;
     static const int xcd_env = [] { const char* e = getenv("FGT_CONV_XCD"); return e ? atoi(e) : 1; }();
@@ -435,11 +452,14 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     // unique-byte floor: input map(s) once (4 B per value, fp32 or hi + lo), weights once, every output form once, aux operands once
     // (fp16 tensors — in_split = 3, out_s with pso = -1 — are 2 B per value)
     const double in_b = d.in_split == 3 ? 2.0 : 4.0, os_b = (d.out_split && d.pso < 0) ? 2.0 : 4.0;
+    // (per-image aux tables are Ho*Wo rows; a sub-pixel map holds ps_H*ps_W*ps_c values per image, and its PS_ADD2 residual as many)
+    const double out_vals = d.ps_r ? (double)d.N * d.ps_H * d.ps_W * d.ps_c : (double)M * d.Cout;
+    const double aux1_vals = d.epi == FGT_EPI_NONE ? 0.0 : (d.aux_per_image ? (double)Ho * Wo * d.Cout : (double)M * d.Cout);
+    const double aux2_vals = d.epi < FGT_EPI_GRU ? 0.0 : d.epi == FGT_EPI_PS_ADD2 ? out_vals : (d.epi == FGT_EPI_AFFINE && d.aux_per_image ? (double)Ho * Wo * d.Cout : (double)M * d.Cout);
     const double conv_bytes = in_b * ((double)d.N * d.H * d.W * (d.C0 + d.C1) + (double)d.Cout * p.K) +
-                              (double)M * d.Cout * ((d.out_split != 1 ? 4.0 : 0.0) + (d.out_split ? os_b : 0.0) +
-                                                    4.0 * ((d.epi != FGT_EPI_NONE ? 1 : 0) + (d.epi == FGT_EPI_GRU ? 1 : 0)));
+                              out_vals * ((d.out_split != 1 ? 4.0 : 0.0) + (d.out_split ? os_b : 0.0)) + 4.0 * (aux1_vals + aux2_vals);
     // (Cout <= 4 VALU kernels: an HBM-bound pass over the input map — their own kind, bytes only)
-    const int prof = direct ? fgt_prof_begin(FGT_PROF_CONV_SMALL, 0.0, conv_bytes, s) : fgt_prof_begin(FGT_PROF_CONV, 2.0 * (double)M * p.Cout_g * (d.k_alg > 0 ? d.k_alg : p.K) * d.groups, conv_bytes, s);
+    const int prof = direct ? fgt_prof_begin(FGT_PROF_CONV_SMALL, 0.0, conv_bytes, s) : fgt_prof_begin(FGT_PROF_CONV, 2.0 * (double)M * (d.n_alg > 0 ? d.n_alg : p.Cout_g) * (d.k_alg > 0 ? d.k_alg : p.K) * d.groups, conv_bytes, s);
     int rc;
     if (direct) rc = fgt_conv_direct(p, s);   // Cout <= 4: VALU direct conv (fp32)
     else if (d.in_split == 3) rc = fgt_conv_f16_launch(tile, p, s);

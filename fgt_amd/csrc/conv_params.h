@@ -2,6 +2,18 @@
 #pragma once
 #include "common.h"
 
+// Exact n / d for 0 <= n < 2^31 with one 32 x 32 -> 64-bit multiply: mul = ceil(2^sh / d), sh = 31 + ceil(log2 d)  (host: fgt_fastdiv_make)
+struct FgtFastDiv {
+    unsigned mul;
+    int sh;
+};
+inline FgtFastDiv fgt_fastdiv_make(unsigned d) {
+    int s = 0;
+    while ((1ull << s) < d) ++s;
+    const int sh = 31 + s;
+    return FgtFastDiv{(unsigned)(((1ull << sh) + d - 1) / d), sh};
+}
+
 struct ConvP {
     fgt_conv_desc d;
     const float *x0, *x1, *w, *cscale, *cbias, *aux1, *aux2;
@@ -13,6 +25,7 @@ struct ConvP {
     int mtiles, ntiles, mchunk, xcd_swizzle;   // tile grid and XCD-aware ordering (set by the launcher)
     int pipe;   // bf16x3: software-pipelined K loop (FGT_CONV_PIPE=0 selects the plain double-buffered loop)
     int tr_li = 0;  // conv_taps.hip, k x 1 convolutions: != 0 (= H) when the tile's rows walk the image in (n, x, y) order; the epilogue maps them back
+    FgtFastDiv div_howo, div_wo;   // rows -> (image, y, x) in the epilogue (sub-pixel output / per-image aux tables)
     int nt_store;   // epilogue stores non-temporal (default; FGT_CONV_NT=0 for A/B measurements): the output is written once and read by the NEXT
                     // kernel — keeping it out of the XCD's L2 leaves the cache to the A / B tiles this kernel re-reads.  Measured per layer
                     // (profiles/r03_run2_split_sweep_nt_stores.txt): K = 512 GEMMs +5...10 %, 3x3 layers +2 %, none slower

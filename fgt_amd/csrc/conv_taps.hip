@@ -101,7 +101,9 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     const int dwx = tr ? d.dh : d.dw, d_o = tr ? d.dw : d.dh, p_i = tr ? d.ph : d.pw, p_o = tr ? d.pw : d.ph;
     const bool il = d.in_split == 2;
     const int nch0 = p.Cg0 / 32, nch1 = p.Cg1 / 32, nchunk = nch0 + nch1;
-    const int nss = (tr ? d.kw : d.kh) * nchunk;
+    // ABI 7 (desc.ky_skip_n0, normal mode): the weights of this tile's columns are all zero for ky = 0 — its K walk starts at ky = 1
+    const int ky0 = (!tr && d.ky_skip_n0 > 0 && bn0 >= d.ky_skip_n0) ? 1 : 0;
+    const int nss = ((tr ? d.kw : d.kh) - ky0) * nchunk;
     const long cstride = il ? 128 : 64;                  // bytes from one 32-channel chunk of a pixel to the next
 
     // ---- im2col source iterator (wave-uniform): the super-step whose A rows are requested next.  Byte pointers to chunk (ky, c) of pixel 0:
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     const char* a_hi = src_hi(0);
     const char* a_lo = a_hi + src_lo_off(0);
     int a_ld = d.ld0, a_left = nch0, a_src = 0;
-    int a_dy = -p_o, a_dyW = -p_o * So;                   // outer tap shift: in outer coordinates / in pixels
+    int a_dy = ky0 * d_o - p_o, a_dyW = a_dy * So;        // outer tap shift: in outer coordinates / in pixels
     auto a_advance = [&]() {
         a_hi += cstride; a_lo += cstride;
         if (--a_left == 0) {
@@ -168,6 +170,10 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     }
     // (transposed: the reused taps are ky: + kw * nchunk per tap, and the step to the next kx is the step to the next chunk)
     const long dkx = (long)nchunk * (tr ? d.kw : 1) * 128, dss = 128 - (KW - 1) * dkx, dky = tr ? dss : 128;
+    if (ky0) {
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) wp[it] += (long)KW * dkx;      // the K-steps of ky = 0
+    }
     int b_c = 0;                                          // chunk (within its ky) of the super-step the B stream is in
     auto issue_B = [&](int bs) {
 #pragma unroll

@@ -150,7 +150,10 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     const int dwx = d.dw, p_i = d.pw;
     const bool il = d.in_split == 2;
     const int nch0 = p.Cg0 / 32, nch1 = p.Cg1 / 32, nchunk = nch0 + nch1;
-    const int nss = d.kh * nchunk;
+    // ABI 7 (desc.ky_skip_n0): the weights of this tile's columns are all zero for ky = 0 — its K walk starts at ky = 1 (fold as a convolution:
+    // the sub-pixel rows ry >= 1 of a token cell receive nothing from the token row above)
+    const int ky0 = (d.ky_skip_n0 > 0 && bn0 >= d.ky_skip_n0) ? 1 : 0;
+    const int nss = (d.kh - ky0) * nchunk;
     const int cstride = il ? 128 : 64;                   // bytes from one 32-channel chunk of a pixel to the next
 
     // ---- im2col source iterator (wave-uniform): the super-step whose A rows are requested next (conv_taps.hip, normal mode)
@@ -163,7 +166,7 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     const char* a_hi = src_hi(0);
     const char* a_lo = a_hi + src_lo_off(0);
     int a_ld2 = 2 * d.ld0, a_left = nch0, a_src = 0;      // (a_ld2: bytes from one pixel of the source to the next)
-    int a_dy = -d.ph, a_dyW = -d.ph * W;                  // ky tap shift: in rows / in pixels
+    int a_dy = ky0 * d.dh - d.ph, a_dyW = a_dy * W;       // ky tap shift: in rows / in pixels
     auto a_advance = [&]() {
         a_hi += cstride; a_lo += cstride;
         if (--a_left == 0) {
@@ -235,8 +238,8 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     const int kcB = WIDE ? ((lane & 7) ^ (lane >> 4)) * 16 : kc16;
     const char* const w_lane = reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + bn0 + lrow) * (2 * d.Kpad)) + kcB;
     const int w_row16 = (WIDE ? 32 : 64) * d.Kpad;        // bytes from one 16-row (WIDE: 8-row) group of the weight image to the next
-    int w_k = 0;                                          // byte offset of the K-step the B stream is at
     const int dkx = nchunk * 128, dss = 128 - (KW - 1) * dkx;      // to the next kx of a (ky, chunk) / from its last kx to the next chunk; to the next ky: + 128
+    int w_k = ky0 * KW * dkx;                             // byte offset of the K-step the B stream is at
     int b_c = 0;                                          // chunk (within its ky) of the super-step the B stream is in
     const int npad_rows = d.Npad - bn0;                   // weight rows of this tile that exist (the rest reads the zero page)
     auto issue_B = [&](auto RQ, int bs) __attribute__((always_inline)) {           // request r of 2 BPP: (plane, group) / WIDE: 8-row group

@@ -61,6 +61,37 @@ __device__ __forceinline__ int conv_out_row(const ConvP& p, int m) {
     return n * p.HoWo + y * (p.HoWo / p.tr_li) + x;
 }
 
+__device__ __forceinline__ int fgt_fastdiv(int n, const FgtFastDiv f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.sh); }
+
+// ABI 7 (fold as a convolution): output column n -> sub-pixel (ry, rx) and channel; false for the padding columns between the ry = 0 block and ps_g0.
+__device__ __forceinline__ bool conv_ps_column(const fgt_conv_desc& d, int n, int& ry, int& rx, int& ch) {
+    const int rc = d.ps_r * d.ps_c;
+    bool ok = true;
+    int q = n;
+    if (n >= rc) { ok = n >= d.ps_g0; q = n - (d.ps_g0 - rc); }
+    ry = q / rc;
+    const int r2 = q - ry * rc;
+    rx = r2 / d.ps_c;
+    ch = r2 - rx * d.ps_c;
+    return ok;
+}
+
+// Tile row mt -> row `mo` of the output tensor (sub-pixel output: the pixel of this column's sub-pixel; okr = it lies inside the ps_H x ps_W map)
+// and row `rem` of the per-image aux tables.
+__device__ __forceinline__ void conv_row_of(const ConvP& p, int mt, int ry, int rx, bool col_in, long& mo, int& rem, bool& okr) {
+    const fgt_conv_desc& d = p.d;
+    okr = true;
+    rem = 0;
+    if (!d.ps_r && !d.aux_per_image) { mo = conv_out_row(p, mt); return; }
+    const int f = fgt_fastdiv(mt, p.div_howo);
+    rem = mt - f * p.HoWo;
+    if (!d.ps_r) { mo = mt; return; }
+    const int I = fgt_fastdiv(rem, p.div_wo), J = rem - I * d.Wo;
+    const int y = d.ps_r * I + ry, x = d.ps_r * J + rx;
+    okr = col_in && y < d.ps_H && x < d.ps_W;
+    mo = ((long)f * d.ps_H + y) * d.ps_W + x;
+}
+
 // ---- epilogue.  The accumulators go through LDS (the tile buffers are free now) so that the global side is a compact,
 // coalesced float4 loop shared by every epilogue flavour: bias / per-channel scale, activation, mul / add / GRU combine,
 // then the fp32 store (NHWC slice or NCHW) and / or the pre-split bf16 store (desc.out_split) the next conv's LDS-DMA
@@ -81,7 +112,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
     const int l31 = lane & 31, lh = lane >> 5;
     float* Cs = smem;
     const bool vec_ok = (p.Cout_g % 4 == 0) && !d.out_nchw && (d.ldo % 4 == 0) && (d.ooff % 4 == 0) &&
-                        (d.epi == FGT_EPI_NONE || d.ld_aux1 % 4 == 0) && (d.epi != FGT_EPI_GRU || d.ld_aux2 % 4 == 0);
+                        (d.epi == FGT_EPI_NONE || d.ld_aux1 % 4 == 0) && (d.epi < FGT_EPI_GRU || d.ld_aux2 % 4 == 0);
     const bool want_f32 = d.out_split != 1, want_split = d.out_split != 0;
 
     // ---- fast path (every layer of the hot path: float4-aligned channels-last output): WAVE-PRIVATE staging.  Each wavefront
@@ -103,6 +134,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 sc = (p.cscale && col_ok) ? *reinterpret_cast<const float4*>(p.cscale + co) : one;
         const float4 bi = (p.cbias && col_ok) ? *reinterpret_cast<const float4*>(p.cbias + co) : zero;
+        // ABI 7, sub-pixel output: a lane keeps its 4 columns, so its sub-pixel and output channel are per-lane constants (ps_c % 4 == 0: a float4 never
+        // straddles two sub-pixels); a row's (image, I, J) costs two multiply-shift divisions.
+        int ps_ry = 0, ps_rx = 0, och = co;
+        bool ps_col = true;
+        if (d.ps_r) ps_col = conv_ps_column(d, n, ps_ry, ps_rx, och);
         // The body is instantiated per number of aux operands (AUX = 0: no epilogue operand, 1: mul / add, 2: GRU) and dispatched on desc.epi.
         // With desc.epi tested at run time inside ONE body, hipcc put `s_waitcnt vmcnt(0)` in front of every row group (the join of the
         // paths with and without aux loads) — and on gfx9 that counter also holds the STORES until they are acknowledged: every group of
@@ -126,10 +162,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
             for (int u0 = 0; u0 < UN; ++u0) {
                 const int mt = bm0 + wm * WTM + i * 32 + r0 + (c0 + u0) * RPI;
                 const bool okk = col_ok && mt < p.M;
-                const int m = conv_out_row(p, mt);
+                long m;
+                int rem;
+                bool okr;
+                conv_row_of(p, mt, ps_ry, ps_rx, ps_col, m, rem, okr);
+                const long m1 = d.aux_per_image ? (long)rem : m;
                 // (out-of-range lanes read the zero page: the select is on the address, the loads stay back to back)
-                if constexpr (AUX >= 1) a1[u0] = *reinterpret_cast<const float4*>(okk ? p.aux1 + (long)m * d.ld_aux1 + co : p.zero_page);
-                if constexpr (AUX >= 2) a2[u0] = *reinterpret_cast<const float4*>(okk ? p.aux2 + (long)m * d.ld_aux2 + co : p.zero_page);
+                if constexpr (AUX >= 1) a1[u0] = *reinterpret_cast<const float4*>(okk ? p.aux1 + m1 * d.ld_aux1 + co : p.zero_page);
+                if constexpr (AUX >= 2) {
+                    const float* q2 = d.epi == FGT_EPI_PS_ADD2 ? p.aux2 + m * d.ld_aux2 + och : p.aux2 + (d.epi == FGT_EPI_AFFINE ? m1 : m) * d.ld_aux2 + co;
+                    a2[u0] = *reinterpret_cast<const float4*>(okk && okr ? q2 : p.zero_page);
+                }
             }
         };
         if constexpr (AUX >= 1 && AHEAD) load_aux(std::integral_constant<int, 0>{}, ax1[0], ax2[0]);
@@ -157,41 +200,51 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
             }
 #pragma unroll
             for (int u0 = 0; u0 < UN; ++u0) {
-                const int m = conv_out_row(p, mrow + (c0 + u0) * RPI);
+                long m;
+                int rem_;
+                bool okr;
+                conv_row_of(p, mrow + (c0 + u0) * RPI, ps_ry, ps_rx, ps_col, m, rem_, okr);
                 float v[4] = {cv[u0].x * sc.x + bi.x, cv[u0].y * sc.y + bi.y, cv[u0].z * sc.z + bi.z, cv[u0].w * sc.w + bi.w};
                 float x1[4] = {0.f, 0.f, 0.f, 0.f}, x2[4] = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (AUX >= 1) { const float4 t = ax1[ab][u0]; x1[0] = t.x; x1[1] = t.y; x1[2] = t.z; x1[3] = t.w; }
                 if constexpr (AUX >= 2) { const float4 t = ax2[ab][u0]; x2[0] = t.x; x2[1] = t.y; x2[2] = t.z; x2[3] = t.w; }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    float x = fgt_act(v[u], d.act, d.slope) * d.out_scale;
+                    float pre = v[u];
+                    if constexpr (AUX == 2) {           // ABI 7: the two kinds applied in front of the activation
+                        if (d.epi == FGT_EPI_AFFINE) pre = fmaf(pre, x2[u], x1[u]);
+                        else if (d.epi == FGT_EPI_PS_ADD2) pre = pre + x1[u] + x2[u];
+                    }
+                    float x = fgt_act(pre, d.act, d.slope) * d.out_scale;
                     if constexpr (AUX == 1) {
                         if (d.epi == FGT_EPI_MUL) x *= x1[u];
                         else x = fgt_act(x + x1[u], d.act2, d.slope);
                     }
-                    if constexpr (AUX == 2) x = (1.f - x1[u]) * x2[u] + x1[u] * x;
+                    if constexpr (AUX == 2) {
+                        if (d.epi == FGT_EPI_GRU) x = (1.f - x1[u]) * x2[u] + x1[u] * x;
+                    }
                     v[u] = x;
                 }
-                if (ok[u0]) {
+                if (ok[u0] && okr) {
                     typedef float nt_f4 __attribute__((ext_vector_type(4)));
                     typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
                     const bool nt = p.nt_store != 0;
                     if (want_f32) {
-                        float* o = p.out + (long)m * d.ldo + d.ooff + co;
+                        float* o = p.out + m * d.ldo + d.ooff + och;
                         if (nt) __builtin_nontemporal_store(nt_f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<nt_f4*>(o));
                         else *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
                     }
                     if (want_split) {
-                        const int cs = d.ooff_s + co;       // pso == 32: interleaved layout, channel c -> (c/32)*64 + c%32, lo 32 further
+                        const int cs = d.ooff_s + och;      // pso == 32: interleaved layout, channel c -> (c/32)*64 + c%32, lo 32 further
                         if (p.pso < 0) {                    // pso == -1: one fp16 plane (in_split = 3 of the consumer)
                             const uint2 h = fgt_half4(make_float4(v[0], v[1], v[2], v[3]));
-                            __bf16* o = p.out_s + (long)m * d.ldo_s + cs;
+                            __bf16* o = p.out_s + m * d.ldo_s + cs;
                             if (nt) __builtin_nontemporal_store(nt_u2{h.x, h.y}, reinterpret_cast<nt_u2*>(o));
                             else *reinterpret_cast<uint2*>(o) = h;
                         } else {
                             uint2 hi, lo;
                             split4(make_float4(v[0], v[1], v[2], v[3]), hi, lo);
-                            __bf16* o = p.out_s + (long)m * d.ldo_s + (p.pso == 32 ? ((cs >> 5) << 6) + (cs & 31) : cs);
+                            __bf16* o = p.out_s + m * d.ldo_s + (p.pso == 32 ? ((cs >> 5) << 6) + (cs & 31) : cs);
                             if (nt) {
                                 __builtin_nontemporal_store(nt_u2{hi.x, hi.y}, reinterpret_cast<nt_u2*>(o));
                                 __builtin_nontemporal_store(nt_u2{lo.x, lo.y}, reinterpret_cast<nt_u2*>(o + p.pso));
@@ -207,7 +260,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         });
         };
         if (d.epi == FGT_EPI_NONE) body(std::integral_constant<int, 0>{});
-        else if (d.epi == FGT_EPI_GRU) body(std::integral_constant<int, 2>{});
+        else if (d.epi >= FGT_EPI_GRU) body(std::integral_constant<int, 2>{});
         else body(std::integral_constant<int, 1>{});
         return;
     }
@@ -232,39 +285,48 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
             const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
             const int n = bn0 + c4 * 4;
             if (mbase + row >= p.M || n >= p.Cout_g) continue;
-            const int m = conv_out_row(p, mbase + row);
+            const int co = g * p.Cout_g + n;
+            int ps_ry = 0, ps_rx = 0, och = co, rem;
+            bool okr;
+            long m;
+            const bool ps_col = d.ps_r ? conv_ps_column(d, n, ps_ry, ps_rx, och) : true;     // (host: sub-pixel output implies vec_ok)
+            conv_row_of(p, mbase + row, ps_ry, ps_rx, ps_col, m, rem, okr);
+            if (!okr) continue;
+            const long m1 = d.aux_per_image ? (long)rem : m;
             const float4 cv = *reinterpret_cast<const float4*>(Cs + row * BN + c4 * 4);
             float v[4] = {cv.x, cv.y, cv.z, cv.w};
-            const int co = g * p.Cout_g + n;
             const int nvalid = min(4, p.Cout_g - n);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (u < nvalid) {
                     const float cs = p.cscale ? p.cscale[co + u] : 1.f;
                     const float cb = p.cbias ? p.cbias[co + u] : 0.f;
-                    float x = fgt_act(v[u] * cs + cb, d.act, d.slope) * d.out_scale;
+                    float pre = v[u] * cs + cb;
+                    if (d.epi == FGT_EPI_AFFINE) pre = fmaf(pre, p.aux2[m1 * d.ld_aux2 + co + u], p.aux1[m1 * d.ld_aux1 + co + u]);
+                    else if (d.epi == FGT_EPI_PS_ADD2) pre = pre + p.aux1[m1 * d.ld_aux1 + co + u] + p.aux2[m * d.ld_aux2 + och + u];
+                    float x = fgt_act(pre, d.act, d.slope) * d.out_scale;
                     if (d.epi == FGT_EPI_MUL) {
-                        x *= p.aux1[(long)m * d.ld_aux1 + co + u];
+                        x *= p.aux1[m1 * d.ld_aux1 + co + u];
                     } else if (d.epi == FGT_EPI_ADD) {
-                        x = fgt_act(x + p.aux1[(long)m * d.ld_aux1 + co + u], d.act2, d.slope);
+                        x = fgt_act(x + p.aux1[m1 * d.ld_aux1 + co + u], d.act2, d.slope);
                     } else if (d.epi == FGT_EPI_GRU) {
-                        const float z = p.aux1[(long)m * d.ld_aux1 + co + u];
-                        const float hh = p.aux2[(long)m * d.ld_aux2 + co + u];
+                        const float z = p.aux1[m * d.ld_aux1 + co + u];
+                        const float hh = p.aux2[m * d.ld_aux2 + co + u];
                         x = (1.f - z) * hh + z * x;
                     }
                     v[u] = x;
                 }
             }
             if (vec_ok) {
-                if (want_f32) *reinterpret_cast<float4*>(p.out + (long)m * d.ldo + d.ooff + co) = make_float4(v[0], v[1], v[2], v[3]);
+                if (want_f32) *reinterpret_cast<float4*>(p.out + m * d.ldo + d.ooff + och) = make_float4(v[0], v[1], v[2], v[3]);
                 if (want_split) {       // validated by the host: vec_ok holds whenever out_split is set
-                    const int cs = d.ooff_s + co;       // pso == 32: interleaved layout, channel c -> (c/32)*64 + c%32, lo 32 further
+                    const int cs = d.ooff_s + och;      // pso == 32: interleaved layout, channel c -> (c/32)*64 + c%32, lo 32 further
                     if (p.pso < 0) {                    // pso == -1: one fp16 plane
-                        *reinterpret_cast<uint2*>(p.out_s + (long)m * d.ldo_s + cs) = fgt_half4(make_float4(v[0], v[1], v[2], v[3]));
+                        *reinterpret_cast<uint2*>(p.out_s + m * d.ldo_s + cs) = fgt_half4(make_float4(v[0], v[1], v[2], v[3]));
                     } else {
                         uint2 hi, lo;
                         split4(make_float4(v[0], v[1], v[2], v[3]), hi, lo);
-                        __bf16* o = p.out_s + (long)m * d.ldo_s + (p.pso == 32 ? ((cs >> 5) << 6) + (cs & 31) : cs);
+                        __bf16* o = p.out_s + m * d.ldo_s + (p.pso == 32 ? ((cs >> 5) << 6) + (cs & 31) : cs);
                         *reinterpret_cast<uint2*>(o) = hi;
                         *reinterpret_cast<uint2*>(o + p.pso) = lo;
                     }
@@ -273,7 +335,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 const int n_img = m / p.HoWo, rem = m - n_img * p.HoWo;
                 for (int u = 0; u < nvalid; ++u) p.out[((long)n_img * d.Cout + co + u) * p.HoWo + rem] = v[u];
             } else {
-                for (int u = 0; u < nvalid; ++u) p.out[(long)m * d.ldo + d.ooff + co + u] = v[u];
+                for (int u = 0; u < nvalid; ++u) p.out[m * d.ldo + d.ooff + co + u] = v[u];
             }
         }
     }

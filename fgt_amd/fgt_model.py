@@ -23,6 +23,82 @@ from .ops import PackedConv
 SPLIT_ATTENTION = os.environ.get("FGT_SPLIT_ATTN", "1") != "0"
 
 
+# bf16x3 mode: nn.Fold behind a per-token Linear (FusionFeedForward's first half, Vec2Patch) runs as ONE stride-1 3x3 convolution over the
+# token grid with a sub-pixel epilogue (fgt_conv_desc.ps_r) on the tap-reusing kernel — no [tokens, 49*c] patch matrix, no fold pass.
+# FGT_FOLD_CONV=0: Linear + fgt_fold (the fp32 / f16 modes' path), kept for A/B measurements.
+FOLD_CONV = os.environ.get("FGT_FOLD_CONV", "1") != "0"
+
+
+def fold_conv_supported(k, s, p):
+    """fold(kernel k, stride s, padding p) of a per-token Linear is a 3x3 token-grid convolution with s x s sub-pixels when k = 2s + 1, p = s
+    (the shipped 7 / 3 / 3, FGT/config/train.yaml:70-72): token offsets -1, 0, +1 cover every kernel position."""
+    return k == 2 * s + 1 and p == s
+
+
+def fold_conv_layout(cc, s):
+    """Output columns of the fold convolution: [ry = 0: (rx, c) | zeros up to g0 | ry >= 1: (ry, rx, c)]; g0 is a tile boundary (128) so that
+    the tiles of the ry >= 1 block skip the ky = 0 taps (fgt_conv_desc.ky_skip_n0).  Returns (g0, Cout, first column of sub-pixel (ry, rx))."""
+    g0 = ops.ceil_to(s * cc, 128)
+    col0 = lambda ry, rx: rx * cc if ry == 0 else g0 + ((ry - 1) * s + rx) * cc
+    return g0, g0 + (s - 1) * s * cc, col0
+
+
+def fold_conv_weight(w, cc, k, s):
+    """Linear weight [cc*k*k, cin] (row c*k*k + ky*k + kx: the channel order of nn.Fold, ffn_base.py:39 / model.py:96) -> the conv weight
+    [Cout, cin, 3, 3]: tap (a, b) = token offset (a - 1, b - 1) carries kernel position (s + ry - s*(a-1), s + rx - s*(b-1)) of sub-pixel
+    (ry, rx) where it exists — pixel s*I + ry lies in the patch of token I + di at row ky = s*(I - (I + di)) + p + ry."""
+    cin = w.shape[1]
+    g0, cout, col0 = fold_conv_layout(cc, s)
+    w4 = w.detach().float().view(cc, k, k, cin)
+    W = torch.zeros(cout, cin, 3, 3, dtype=torch.float32, device=w.device)
+    for ry in range(s):
+        for rx in range(s):
+            n0 = col0(ry, rx)
+            for a in range(3):
+                ky = s + ry - s * (a - 1)
+                for b in range(3):
+                    kx = s + rx - s * (b - 1)
+                    if 0 <= ky < k and 0 <= kx < k:
+                        W[n0:n0 + cc, :, a, b] = w4[:, ky, kx, :]
+    return W
+
+
+def fold_conv_tables(bias, cc, k, s, th, tw, normalize):
+    """Per-position tables of the fold convolution on a th x tw token grid, [th*tw, Cout] fp32 on the CPU: `offset` = the Linear's biases summed
+    over the (token, kernel position) pairs that reach the sub-pixel — tokens outside the grid contribute nothing, not even their bias — and
+    `scale` = 1 / fold(ones) (ffn_base.py:58-66) or None; with normalisation the offset is pre-multiplied by the scale (epilogue: v*scale + offset)."""
+    g0, cout, col0 = fold_conv_layout(cc, s)
+    b4 = bias.detach().double().cpu().view(cc, k, k)
+
+    def axis(n):        # valid[i, r, a]: token i + a - 1 exists and has kernel position s + r - s*(a-1); pos[r, a] = that position (clamped)
+        i = torch.arange(n).view(n, 1, 1)
+        r = torch.arange(s).view(1, s, 1)
+        a = torch.arange(3).view(1, 1, 3)
+        kp = s + r - s * (a - 1)
+        ok = (kp >= 0) & (kp < k) & (i + a - 1 >= 0) & (i + a - 1 < n)
+        return ok.double(), kp.clamp(0, k - 1).view(s, 3)
+
+    vy, py = axis(th)
+    vx, px = axis(tw)
+    cnt = vy.sum(-1).view(th, 1, s, 1) * vx.sum(-1).view(1, tw, 1, s)                       # [th, tw, ry, rx]
+    bsel = b4[:, py.view(s, 3, 1, 1), px.view(1, 1, s, 3)]                                  # [c, ry, a, rx, b]
+    off = torch.einsum("iya,jxb,cyaxb->ijyxc", vy, vx, bsel)                                # [th, tw, ry, rx, c]
+    scale = None
+    if normalize:
+        inv = 1.0 / cnt.clamp(min=1.0)
+        off = off * inv.unsqueeze(-1)
+        scale = torch.zeros(th, tw, cout, dtype=torch.float64)
+    offset = torch.zeros(th, tw, cout, dtype=torch.float64)
+    for ry in range(s):
+        for rx in range(s):
+            n0 = col0(ry, rx)
+            offset[:, :, n0:n0 + cc] = off[:, :, ry, rx]
+            if normalize:
+                scale[:, :, n0:n0 + cc] = inv[:, :, ry, rx].unsqueeze(-1)
+    f = lambda t: None if t is None else t.view(th * tw, cout).float().contiguous()
+    return f(offset), f(scale)
+
+
 # ----------------------------------------------------------------------------- parameter holders
 class ConvParams(nn.Module):
     """weight [Cout, Cin/groups, kh, kw] + bias [Cout] (same names/shapes as nn.Conv2d)."""
@@ -259,7 +335,28 @@ class FGT(nn.Module):
         w2 = ffn.conv2[2].weight.detach()
         # Linear(hidden -> c) on unfold(...) == k x k / stride s conv over the folded map (ffn_base.py:40-45,56-75)
         w2c = w2.view(w2.shape[0], cc, self.cfg["k"][0], self.cfg["k"][1])
-        return dict(conv1=PackedConv(w1p, b1p), conv2=PackedConv(w2c, ffn.conv2[2].bias), cc=cc)
+        P = dict(conv1=PackedConv(w1p, b1p), conv2=PackedConv(w2c, ffn.conv2[2].bias), cc=cc)
+        P.update(self._pack_fold_conv(w1, b1, cc))
+        return P
+
+    def _pack_fold_conv(self, w, b, cc):
+        """Linear + nn.Fold as a token-grid convolution (fold_conv_weight): the packed 3x3 weights, the bias on the CPU (the per-position tables
+        depend on the token grid and are built on first use: _fold_tables) — only where the patch geometry allows it."""
+        k, s, p = self.cfg["k"][0], self.cfg["s"][0], self.cfg["p"][0]
+        if not (FOLD_CONV and fold_conv_supported(k, s, p) and cc % 4 == 0):
+            return {}
+        pc = PackedConv(fold_conv_weight(w, cc, k, s), None)
+        pc.k_alg = w.shape[1]                                     # credited work: the Linear's (rows x cin x k*k*cc), not the zero taps
+        return dict(fc=pc, fc_bias=b.detach().float().cpu(), fc_tables={})
+
+    def _fold_tables(self, P, th, tw, dev, normalize):
+        """(offset, scale) tables of a fold convolution for a th x tw token grid, on `dev` (built on the CPU, copied synchronously: usable from any
+        stream afterwards)."""
+        key = (th, tw, str(dev))
+        if key not in P["fc_tables"]:
+            off, sc = fold_conv_tables(P["fc_bias"], P["cc"], self.cfg["k"][0], self.cfg["s"][0], th, tw, normalize)
+            P["fc_tables"][key] = (off.to(dev), None if sc is None else sc.to(dev))
+        return P["fc_tables"][key]
 
     def _pack_temporal(self, m):
         a = m.attention
@@ -301,6 +398,7 @@ class FGT(nn.Module):
         cc = we.shape[0] // k2
         P["v2p"] = PackedConv(we.view(cc, k2, -1).permute(1, 0, 2).reshape(cc * k2, -1), be.view(cc, k2).permute(1, 0).reshape(-1))
         P["v2p_c"] = cc
+        P["v2p_fc"] = dict(cc=cc, **self._pack_fold_conv(we, be, cc))
         d = self.decoder
         P["dec"] = [self._pack_block(d.layer1.conv), self._pack_block(d.layer2), self._pack_block(d.layer3.conv),
                     self._pack_block(d.final)]
@@ -330,6 +428,16 @@ class FGT(nn.Module):
         """x_res + FusionFeedForward(y)  (ffn_base.py:53-77).  y may be a Split (bf16x3 mode)."""
         k, s, p = self.cfg["k"][0], self.cfg["s"][0], self.cfg["p"][0]
         sc = self._split_chain()
+        if "fc" in P and sc and not self._f16() and isinstance(y, ops.Split):
+            # Linear + fold / fold(ones) + ReLU as one 3x3 convolution over the token grid: K = 9 * c on the tap-reusing kernel, the folded map
+            # written pre-split by the sub-pixel epilogue; the [tokens, k*k*cc] hidden matrix (768 MB per batched launch) never exists
+            g0 = fold_conv_layout(P["cc"], s)[0]
+            off, scale = self._fold_tables(P, th, tw, x_res.device, True)
+            F = ops.conv2d(y.view(bt, th, tw, -1), P["fc"], stride=1, pad=1, act="relu", epi="affine", aux1=off, aux2=scale, aux_per_image=True,
+                           ps=(s, P["cc"], g0, Hf, Wf), ky_skip_n0=g0, n_alg=k * k * P["cc"], out_split="only", out_il=ops.split_il(P["cc"]))
+            out = torch.empty_like(x_res)
+            ops.conv2d(F, P["conv2"], stride=s, pad=p, epi="add", aux1=x_res, out=out.view(bt, th, tw, -1))
+            return out
         # [bt*n, k*k*cc] tap-major; f16 mode: the hidden (the largest tensor of the block, 768 MB per batched launch as fp32) as fp16
         Y = ops.linear(y, P["conv1"], out_split="only" if self._f16() else None)
         # fold(x) / fold(ones); in split mode the ReLU in front of the second Linear is applied here, once per value,
@@ -533,14 +641,24 @@ class FGT(nn.Module):
             bt = n_out
             x, enc = x[: bt * n], enc[:bt]
         sc = "only" if self._split_chain() else None
-        if self._f16():
-            # the token stream is fp32; rounding it once here (one pass over [rows, 512]) lets the widest GEMM of the path (512 -> 6272) run
-            # on the fp16 kernel and hand fold() an fp16 patch matrix (1.6 GB per clip pass as fp32)
-            Y = ops.linear(ops.split(x), P["v2p"], out_split="only")
+        VP = P["v2p_fc"]
+        if "fc" in VP and sc and not self._f16():
+            # Vec2Patch (Linear 512 -> 49*128 + nn.Fold, model.py:102-110) + the encoder residual (model.py:280) as one 3x3 token-grid convolution
+            k, s = cfg["k"][0], cfg["s"][0]
+            g0 = fold_conv_layout(VP["cc"], s)[0]
+            off, _ = self._fold_tables(VP, th, tw, x.device, False)
+            xs = ops.split(x, interleave=ops.split_il(x.shape[1]))
+            feat = ops.conv2d(xs.view(bt, th, tw, -1), VP["fc"], stride=1, pad=1, epi="ps_add2", aux1=off, aux2=enc, aux_per_image=True,
+                              ps=(s, VP["cc"], g0, Hf, Wf), ky_skip_n0=g0, n_alg=k * k * VP["cc"], out_split="only", out_il=ops.split_il(VP["cc"]))
         else:
-            Y = ops.linear(x, P["v2p"])
-        # soft composition + encoder residual; split mode: written pre-split for the decoder's first conv (its only consumer)
-        feat = ops.fold(Y, bt, th, tw, P["v2p_c"], cfg["k"][0], cfg["s"][0], cfg["p"][0], Hf, Wf, normalize=False, res=enc, out_split=bool(sc))
+            if self._f16():
+                # the token stream is fp32; rounding it once here (one pass over [rows, 512]) lets the widest GEMM of the path (512 -> 6272) run
+                # on the fp16 kernel and hand fold() an fp16 patch matrix (1.6 GB per clip pass as fp32)
+                Y = ops.linear(ops.split(x), P["v2p"], out_split="only")
+            else:
+                Y = ops.linear(x, P["v2p"])
+            # soft composition + encoder residual; split mode: written pre-split for the decoder's first conv (its only consumer)
+            feat = ops.fold(Y, bt, th, tw, P["v2p_c"], cfg["k"][0], cfg["s"][0], cfg["p"][0], Hf, Wf, normalize=False, res=enc, out_split=bool(sc))
         D = P["dec"]
         y = self._block(feat, D[0], stride=1, pad=1, upsample=True, out_split=sc, out_il=ops.split_il(D[0][0].Cout))
         y = self._block(y, D[1], stride=1, pad=1, out_split=sc, out_il=ops.split_il(D[1][0].Cout))

@@ -60,7 +60,9 @@ def load_tuning(path):
     import ast
     import json
     for k, v in json.load(open(path)).items():
-        _tile_cache[ast.literal_eval(k)] = int(v)
+        key = ast.literal_eval(k)
+        _tile_cache[key] = int(v)
+        _tile_validated.discard(key)            # a loaded tile is checked against the geometry's kernel family again (conv2d)
 
 
 if os.environ.get("FGT_TUNING_FILE") and os.path.exists(os.environ["FGT_TUNING_FILE"]):
@@ -136,7 +138,7 @@ class Split:
     def view(self, *shape):
         if self.h:
             return Split(self.data.view(*shape), h=True)
-        return Split(self.data.view(*shape[:-1], 2 * shape[-1]), True) if self.il else Split(self.data.view(2, *shape))
+        return Split(self.data.view(*shape[:-1], 2 * shape[-1] if shape[-1] >= 0 else -1), True) if self.il else Split(self.data.view(2, *shape))
 
     def __getitem__(self, idx):            # leading-dimension slices (rows / frames)
         if self.h:
@@ -304,9 +306,11 @@ def prepack_weights(pc, mode=None):
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
            epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None,
-           out_split=None, out_s=None, out_il=False, out_h=None):
+           out_split=None, out_s=None, out_il=False, out_h=None, ps=None, ky_skip_n0=0, aux_per_image=False, n_alg=0):
     """fgt_conv2d.  x (and optional x1) are channels-last maps (fp32 tensors, or `Split`s for the LDS-DMA bf16x3 path);
-    returns/outputs a channels-last map (or NCHW).  out_split: None -> fp32 result; "only" -> a Split; "both" -> (fp32, Split)."""
+    returns/outputs a channels-last map (or NCHW).  out_split: None -> fp32 result; "only" -> a Split; "both" -> (fp32, Split).
+    ps = (r, c, g0, Hf, Wf): sub-pixel output (fold as a convolution, fgt_conv_desc.ps_r): the result is the [N, Hf, Wf, c] map;
+    ky_skip_n0 / aux_per_image / n_alg: the fields of the same name."""
     in_split = isinstance(x, Split)
     if in_split:
         assert x1 is None or (isinstance(x1, Split) and x1.il == x.il and x1.h == x.h), "conv2d: both sources must be split the same way"
@@ -330,14 +334,15 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     Ho = (Hin + 2 * ph - dh * (pc.kh - 1) - 1) // sh + 1
     Wo = (Win + 2 * pw - dw * (pc.kw - 1) - 1) // sw + 1
     osp = {None: 0, False: 0, "only": 1, "both": 2}[out_split]
+    oshape = (N, Ho, Wo, pc.Cout) if ps is None else (N, ps[3], ps[4], ps[1])       # (sub-pixel output: the folded map)
     if out is None and osp != 1:
-        out = torch.empty((N, pc.Cout, Ho, Wo) if out_nchw else (N, Ho, Wo, pc.Cout), dtype=torch.float32, device=x.device)
+        out = torch.empty((N, pc.Cout, Ho, Wo) if out_nchw else oshape, dtype=torch.float32, device=x.device)
     ldo = 0
     if out_nchw:
-        assert out.is_contiguous() and tuple(out.shape) == (N, pc.Cout, Ho, Wo)
+        assert ps is None and out.is_contiguous() and tuple(out.shape) == (N, pc.Cout, Ho, Wo)
     elif out is not None:
         o4, oN, oH, oW, oC, ldo = _as_map(out)
-        assert (oN * oH * oW, oC) == (N * Ho * Wo, pc.Cout), f"conv2d: out shape {tuple(out.shape)} != {(N, Ho, Wo, pc.Cout)}"
+        assert (oN * oH * oW, oC) == (oshape[0] * oshape[1] * oshape[2], oshape[3]), f"conv2d: out shape {tuple(out.shape)} != {oshape}"
     d = ConvDesc()
     d.N, d.H, d.W = N, H, W
     d.C0, d.ld0, d.off0 = C0, ld0, 0
@@ -352,6 +357,9 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     d.out_scale = float(out_scale)
     d.Kpad, d.Npad, d.tile = pc.Kpad, pc.Npad, TILE[tile]
     d.k_alg = getattr(pc, "k_alg", 0)
+    if ps is not None:
+        d.ps_r, d.ps_c, d.ps_g0, d.ps_H, d.ps_W = (int(v) for v in ps)
+    d.ky_skip_n0, d.aux_per_image, d.n_alg = int(ky_skip_n0), int(bool(aux_per_image)), int(n_alg)
     prec = precision if precision is not None else DEFAULT_CONV_PRECISION
     if prec == "f16" and not (in_split and xs.h):
         prec = "bf16x3"                      # 'f16' = fp16 where the operand arrives as fp16; fp32 inputs are not rounded to 11 bits here
@@ -370,9 +378,9 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
         if out_s is None:
             # out_h: None = the split output follows the arithmetic mode (fp16 plane in 'f16'), False = always the bf16 pair (RAFT / LAFC
             # stay in bf16x3 under the 'f16' switch)
-            out_s = Split.empty((N, Ho, Wo, pc.Cout), x.device, interleaved=bool(out_il), h=False if out_il else out_h)
+            out_s = Split.empty(oshape, x.device, interleaved=bool(out_il), h=False if out_il else out_h)
         s4, sN, sH, sW, sC, ldo_s = _as_map(out_s.hi)
-        assert (sN * sH * sW, sC) == (N * Ho * Wo, pc.Cout * (2 if out_s.il else 1)), f"conv2d: out_s shape {tuple(out_s.shape)}"
+        assert (sN * sH * sW, sC) == (oshape[0] * oshape[1] * oshape[2], oshape[3] * (2 if out_s.il else 1)), f"conv2d: out_s shape {tuple(out_s.shape)}"
         d.ldo_s, d.ooff_s, d.pso = ldo_s, 0, out_s.ps
     if d.precision == 0 or (in_split and xs.h and pc.Cout // pc.groups <= 4 and d.tile == 0):
         wbuf = pc.w                          # (fp16 map into a Cout <= 4 layer: fp32 weights and arithmetic, csrc/conv_direct.hip)
@@ -388,7 +396,8 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
             _ptr(None if out_s is None else out_s.data))
     if d.tile == 0 and AUTOTUNE and pc.Cout // pc.groups > 4:
         key = (N, H, W, C0, C1, pc.Cout, pc.groups, pc.kh, pc.kw, sh, sw, ph, pw, dh, dw, d.upsample, d.epi, d.out_nchw, d.precision,
-               d.in_split, d.out_split, d.w_il, int(bool(osp) and out_s.il) + 2 * int(bool(osp) and out_s.h), d.pad_mode, d.in_relu)
+               d.in_split, d.out_split, d.w_il, int(bool(osp) and out_s.il) + 2 * int(bool(osp) and out_s.h), d.pad_mode, d.in_relu,
+               d.ps_r, d.ps_c, d.ps_H, d.ps_W, d.ky_skip_n0)
         best = _tile_cache.get(key)
         if best is not None and key not in _tile_validated:
             # A cached / loaded tile must belong to the kernel family the GEOMETRY routes this layer to (taps-routed layers: codes 200-299,

@@ -40,6 +40,10 @@ extern "C" {
 #define FGT_EPI_MUL 1     /* v *= aux1[m, n]                                         */
 #define FGT_EPI_ADD 2     /* v += aux1[m, n]; then act2                              */
 #define FGT_EPI_GRU 3     /* v = (1 - aux1[m,n]) * aux2[m,n] + aux1[m,n] * v  (z, h) */
+/* ABI 7 — applied BEFORE the activation, on the accumulator (+ cscale / cbias): */
+#define FGT_EPI_AFFINE 4  /* v = act(v * aux2[m,n] + aux1[m,n]): per-position scale and offset tables (fold()'s 1/count and summed biases) */
+#define FGT_EPI_PS_ADD2 5 /* v = act(v + aux1[m,n] + aux2[pixel,c]): aux1 a table in the conv's own (row, column) layout, aux2 a map in the
+                           * SUB-PIXEL output layout (desc.ps_r > 0: the encoder residual of Vec2Patch, model.py:280)               */
 
 const char* fgt_last_error(void);
 int fgt_abi_version(void);
@@ -117,6 +121,22 @@ typedef struct fgt_conv_desc {
     int k_alg;              /* profiling only: kh*kw*Cin/groups BEFORE zero-padding of the input channels (flow 2 -> 4, RGB 3 -> 4),
                              * the K that fgt_prof_* credits as algorithmic work; 0 = use the padded K                        */
     long long ps0, ps1, pso;/* plane strides (bf16 elements) of x0, x1, out_s                                            */
+    /* ---- ABI 7: nn.Fold after a per-token Linear as ONE stride-1 convolution over the token grid (ffn_base.py:53-77, model.py:102-110).
+     * fold(kernel 2r+1, stride r, padding r) of Linear(x) is a transposed convolution; its sub-pixel form: output pixel (r*I + ry, r*J + rx),
+     * channel c of the folded map is output column (ry, rx, c) of a 3x3 "same" convolution over the [N, H, W] token grid whose tap
+     * (ky, kx) = (di + 1, dj + 1) carries row (c, r + ry - r*di, r + rx - r*dj) of the Linear's weight (zero where that kernel position does
+     * not exist).  Column order: [ry = 0: (rx, c), r*ps_c columns | zero padding up to ps_g0 | ry = 1..r-1: (ry, rx, c)]; the columns with
+     * ry >= 1 have no ky = 0 tap (ky_skip_n0).  The epilogue scatters: out[n, r*I + ry, r*J + rx, ooff + c] (pixel stride ldo / ldo_s),
+     * dropping sub-pixels outside the ps_H x ps_W map (r*H >= ps_H, r*W >= ps_W). */
+    int ps_r;               /* 0: off | r: sub-pixel factor (groups == 1, out_nchw == 0, ps_c % 4 == 0)                     */
+    int ps_c;               /* channels per output pixel                                                                  */
+    int ps_g0;              /* first column of the ry >= 1 block (>= r*ps_c; columns [r*ps_c, ps_g0) are dropped)           */
+    int ps_H, ps_W;         /* size of the output map                                                                     */
+    int ky_skip_n0;         /* > 0: the weights of output columns >= ky_skip_n0 are all zero for ky = 0; the tap-reusing kernels start the K
+                             * walk of tiles that lie entirely in those columns at ky = 1 (other kernels multiply the zeros: same result up to
+                             * the sign of zero)                                                                           */
+    int aux_per_image;      /* 1: aux1 (and aux2 of FGT_EPI_AFFINE) are [Ho*Wo, Cout] tables shared by all N images (row = m mod Ho*Wo) */
+    int n_alg;              /* profiling only: output columns credited as algorithmic work (0 = Cout/groups), see k_alg     */
 } fgt_conv_desc;
 
 #define FGT_PREC_FP32 0

@@ -86,10 +86,12 @@ def _dense_weight(pc):
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
            epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None,
-           out_split=None, out_s=None, out_il=False, out_h=None):
+           out_split=None, out_s=None, out_il=False, out_h=None, ps=None, ky_skip_n0=0, aux_per_image=False, n_alg=0):
+    """ps = (r, c, g0, Hf, Wf): the sub-pixel output of fgt_conv_desc.ps_r (fold as a convolution); ky_skip_n0 / n_alg change no value."""
     if out_split:
         assert not out_nchw
-        y = conv2d(x, pc, x1, stride, pad, dil, upsample, pad_mode, in_relu, act, slope, epi, aux1, aux2, act2, out_scale, out)
+        y = conv2d(x, pc, x1, stride, pad, dil, upsample, pad_mode, in_relu, act, slope, epi, aux1, aux2, act2, out_scale, out,
+                   ps=ps, aux_per_image=aux_per_image)
         if out_s is not None:                      # a preallocated Split (possibly a channel slice of a wider buffer)
             out_s.put(y.reshape(out_s.x.shape))
             sp = out_s
@@ -128,9 +130,27 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
         y = y * pc.scale.view(1, -1, 1, 1)
     if pc.bias is not None:
         y = y + pc.bias.view(1, -1, 1, 1)
-    y = _ACT[act](y, slope) * out_scale
     Nn, Co, Ho, Wo = y.shape
     y = y.permute(0, 2, 3, 1)
+    tab = lambda a: a.reshape(1, Ho, Wo, Co) if aux_per_image else a.reshape(Nn, Ho, Wo, Co)
+    if epi == "affine":                           # ABI 7: in front of the activation
+        y = y * tab(aux2) + tab(aux1)
+    elif epi == "ps_add2":
+        assert ps is not None
+        y = y + tab(aux1)
+    if ps is not None:                            # column (ry, rx, c) of token cell (I, J) -> pixel (r*I + ry, r*J + rx), channel c
+        r, c, g0, Hf, Wf = ps
+        assert Co == g0 + (r - 1) * r * c and pc.groups == 1 and not out_nchw
+        m = y.new_zeros(Nn, r * Ho, r * Wo, c)
+        for ry in range(r):
+            for rx in range(r):
+                n0 = rx * c if ry == 0 else g0 + ((ry - 1) * r + rx) * c
+                m[:, ry::r, rx::r] = y[..., n0:n0 + c]
+        y = m[:, :Hf, :Wf]
+        Ho, Wo, Co = Hf, Wf, c
+        if epi == "ps_add2":
+            y = y + aux2.reshape(Nn, Hf, Wf, c)
+    y = _ACT[act](y, slope) * out_scale
     if epi == "mul":
         y = y * aux1.reshape(Nn, Ho, Wo, Co)
     elif epi == "add":
