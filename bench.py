@@ -147,16 +147,18 @@ def _b(bound):
     return "hbm" if str(bound).startswith("hbm") else "mfma"
 
 
-def compact_line(full, detail_path=None):
-    """The ONE JSON line of the bench contract, derived from the full record `full` (which goes to `detail_path`): contract keys,
-    `roofline` of the dominant kernel, compact `rooflines` (kind / bound / frac / ms), `cpu_baseline`, `parity_vs_cpu_oracle`,
-    `fp32_exact` {value, ms_per_step, roofline_frac}, `c4` {per stage: ms + hardware / effective fractions, pipeline frames/s}.
-    Always < LINE_LIMIT bytes (tests/test_bench_line.py); optional blocks are dropped from the tail if a future field overflows it."""
+def _contract_line(full):
+    """The keys the driver's contract names, and nothing that can fail on a partial record."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "data")
     line = {k: full[k] for k in keep if k in full}
-    line["dtype"] = _short(full.get("dtype", ""), 120)
-    cfg = full.get("config", {})
-    line["config"] = {k: (_short(v, 200) if isinstance(v, str) else v) for k, v in cfg.items()}
+    line["dtype"] = _short(str(full.get("dtype", "")), 120)
+    cfg = full.get("config") or {}
+    line["config"] = {k: (_short(v, 200) if isinstance(v, str) else v) for k, v in cfg.items()} if isinstance(cfg, dict) else {"workload": _short(str(cfg), 200)}
+    return line
+
+
+def _optional_blocks(full, line):
+    """roofline / rooflines / cpu_baseline / parity / fp32_exact / c4 / sharded blocks of the compact line (may raise on an unexpected record)."""
     for k in ("effective_tflops", "host_enqueue_ms_per_step", "output_checksum", "output_sane", "strong_error"):
         if k in full:
             line[k] = full[k]
@@ -233,15 +235,40 @@ def compact_line(full, detail_path=None):
             if k == "strong_scaling_ideal":
                 v = {kk: vv for kk, vv in v.items() if kk != "note"}
             line[k] = v
+
+
+def compact_line(full, detail_path=None):
+    """The ONE JSON line of the bench contract, derived from the full record `full` (which goes to `detail_path`): contract keys,
+    `roofline` of the dominant kernel, compact `rooflines` (kind / bound / frac / ms), `cpu_baseline`, `parity_vs_cpu_oracle`,
+    `fp32_exact` {value, ms_per_step, roofline_frac}, `c4` {per stage: ms + hardware / effective fractions, pipeline frames/s}.
+    Always < LINE_LIMIT bytes (tests/test_bench_line.py): optional blocks are dropped from the tail if a future field overflows it, and a record
+    the optional blocks cannot digest (a missing key, an unexpected shape) still yields the contract keys — a final line is ALWAYS printed."""
+    line = _contract_line(full)
+    try:
+        _optional_blocks(full, line)
+    except Exception as e:  # noqa: BLE001 — whatever a partial record throws, the contract keys go out
+        line = _contract_line(full)
+        line["compact_error"] = _short(f"{type(e).__name__}: {e}", 200)
+        core = {"roofline": ("bound", "kind", "achieved", "peak", "unit", "frac", "traffic"), "cpu_baseline": ("value", "unit", "cores", "kind", "sample")}
+        for k, keys in core.items():                    # the two objects the contract adds: their scalar core
+            v = full.get(k)
+            if isinstance(v, dict):
+                line[k] = {kk: (_short(v[kk], 200) if isinstance(v[kk], str) else v[kk]) for kk in keys if kk in v and not isinstance(v[kk], (dict, list))}
     if detail_path:
         line["detail"] = detail_path
-    # safety net: never exceed the limit — drop optional blocks from the least important end
-    for k in ("phases_ms", "f16", "rooflines", "strong_scaling_ideal", "c4", "fp32_exact", "parity_vs_cpu_oracle"):
+    # safety net: never exceed the limit — drop optional blocks from the least important end, then fall back to the contract keys alone
+    for k in ("phases_ms", "f16", "rooflines", "strong_scaling_ideal", "c4", "fp32_exact", "parity_vs_cpu_oracle", "pipeline_sharded", "strong_scaling_same_clip",
+              "weak_scaling_clip_per_rank", "feature_exchange"):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
         if k in line:
             line.pop(k)
             line.setdefault("dropped", []).append(k)
+    if len(json.dumps(line)) >= LINE_LIMIT:
+        dropped = sorted(set(line) - set(_contract_line(full)))
+        line = _contract_line(full)
+        line["config"] = {k: v for k, v in line["config"].items() if not isinstance(v, (str, dict, list))}
+        line["dropped"] = dropped
     return line
 
 

@@ -48,7 +48,7 @@ __device__ __forceinline__ Bilin bilin(float ix, float iy) {
 // four taps are loaded UNCONDITIONALLY from clamped addresses and zeroed by a select (grid_sample's zeros padding) so that all of a
 // lane's loads are in flight together — the round-3 kernel walked the channels of a pixel with four predicated scalar loads each
 // (0.12 of the HBM roof on 3-channel frames).  Same arithmetic, same order: v = ((0 + nw*wnw) + ne*wne) + sw*wsw) + se*wse.
-template <int V>
+template <int V, bool FLOW8 = true>
 __global__ void __launch_bounds__(256) warp_kernel(const float* __restrict__ img, int ldi, const float* __restrict__ flow, int B, int H, int W, int C,
                                                    int align_corners, int absolute, float* __restrict__ out, int ldo) {
     typedef float vec __attribute__((ext_vector_type(V)));
@@ -59,7 +59,9 @@ __global__ void __launch_bounds__(256) warp_kernel(const float* __restrict__ img
         const int c = (int)(item - pix * cpv) * V;
         const int x = (int)(pix % W); const long r = pix / W;
         const int y = (int)(r % H); const long b = r / H;
-        const float2 fl = *reinterpret_cast<const float2*>(flow + pix * 2);
+        float2 fl;                                       // (FLOW8 = false: a flow pointer at an odd float offset — two 4-byte loads)
+        if constexpr (FLOW8) fl = *reinterpret_cast<const float2*>(flow + pix * 2);
+        else fl = make_float2(flow[pix * 2], flow[pix * 2 + 1]);
         float ix, iy;
         sample_coord(fl.x, fl.y, x, y, W, H, align_corners, absolute, ix, iy);
         const Bilin bl = bilin(ix, iy);
@@ -350,7 +352,8 @@ extern "C" int fgt_warp(const float* img, int ldi, const float* flow, int B, int
     FGT_REQUIRE(img && flow && out && B > 0 && H > 1 && W > 1 && C > 0, "fgt_warp: bad arguments");
     FgtProfScope prof(FGT_PROF_WARP, 0.0, 4.0 * (double)B * H * W * (2.0 * C + 2.0), stream);
     const auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
-    FGT_REQUIRE(al(flow, 8), "fgt_warp: flow must be 8-byte aligned");
+    FGT_REQUIRE(al(flow, 4) && al(img, 4) && al(out, 4), "fgt_warp: pointers must be 4-byte aligned");
+    const bool flow8 = al(flow, 8);                    // (a contiguous view at an odd float offset is legal: scalar flow loads then)
     if (C == 2 && ldi == 2 && ldo == 2 && W % 2 == 0 && al(img, 8) && al(flow, 16) && al(out, 16)) {
         hipLaunchKernelGGL(warp_c2x2_kernel, dim3(grid_for((long)B * H * W / 2)), dim3(256), 0, (hipStream_t)stream, img, flow, B, H, W, align_corners,
                            absolute_coords, out);
@@ -362,7 +365,8 @@ extern "C" int fgt_warp(const float* img, int ldi, const float* flow, int B, int
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, img, ldi, flow, B, H, W, C, align_corners, absolute_coords, out, ldo);
     };
-    if (V == 4) go(warp_kernel<4>); else if (V == 2) go(warp_kernel<2>); else go(warp_kernel<1>);
+    if (!flow8) { if (V == 4) go(warp_kernel<4, false>); else if (V == 2) go(warp_kernel<2, false>); else go(warp_kernel<1, false>); }
+    else if (V == 4) go(warp_kernel<4>); else if (V == 2) go(warp_kernel<2>); else go(warp_kernel<1>);
     return fgt_check_launch("warp");
 }
 

@@ -91,6 +91,8 @@ def compute_flows(raft, frames, iters=20, batch=None, enc_batch=16, rank=0, worl
                 _, up = raft.iterate(fmap[a], fmap[b], cmap[a], iters=iters, test_mode=True)
                 ups.append(up)
             up = torch.cat(ups, 0)
+            if world == 1:
+                return up[:cnt], up[cnt:]                                    # one rank: contiguous slices, no interleaving copy
             both = torch.stack([up[:cnt], up[cnt:]], 1)                      # [cnt, 2 (fwd, bwd), 2, H, W]
         else:
             both = torch.zeros(0, 2, 2, H, W, dtype=torch.float32, device=frames.device)

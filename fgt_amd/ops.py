@@ -885,8 +885,8 @@ def hole_bounds(masks):
 def solver_report(name):
     """What the last `laplace_fill` / `poisson_blend` call did, read back from the device: solver, problems, iterations (mean / max), the
     number of problems that hit the iteration cap and the number the device NaN-filled because their box exceeded the promised bounds
-    (status 1; cannot happen with bounds from `hole_bounds` of the same masks).  FGT_SOLVER_CHECK=1 makes the two entry points assert
-    the latter is zero after every call (a blocking read-back: debugging only)."""
+    (status 1; cannot happen with bounds from `hole_bounds` of the same masks).  FGT_SOLVER_CHECK=1 makes the two entry points raise
+    RuntimeError after a call in which either count is non-zero (a blocking read-back: debugging only)."""
     st = last_solver.get(name, {})
     if st.get("solver") != "onchip":
         return {"solver": st.get("solver", "none")}
@@ -899,7 +899,10 @@ def solver_report(name):
 def _solver_check(name):
     if os.environ.get("FGT_SOLVER_CHECK") == "1" and not _capturing():
         rep = solver_report(name)
-        assert rep.get("nan_filled", 0) == 0, f"{name}: {rep['nan_filled']} problems exceeded the promised bounding box (NaN-filled)"
+        if rep.get("nan_filled", 0):
+            raise RuntimeError(f"{name}: {rep['nan_filled']} problems exceeded the promised bounding box (NaN-filled): `bounds` came from other masks?")
+        if rep.get("cap_hits", 0):
+            raise RuntimeError(f"{name}: {rep['cap_hits']} of {rep['problems']} problems hit the iteration cap without reaching the tolerance")
 
 
 def laplace_fill(maps, masks, iters=1000, tol=1e-6, solver=None, bounds=None):

@@ -222,7 +222,7 @@ class ClipRunner:
         # contributions, the most ordinary collective there is) — the degraded mode for a first RCCL run in which the uneven / zero-length
         # all_to_all_single misbehaves.  Same composite (tests/test_scheduler.py), ~2.7x the bytes on the wire at 8 ranks.
         self.exchange = "none" if world == 1 else os.environ.get("FGT_EXCHANGE", "a2a").lower()
-        if self.exchange not in ("none", "a2a", "allgather"):
+        if world > 1 and self.exchange not in ("a2a", "allgather"):
             raise ValueError(f"FGT_EXCHANGE={self.exchange!r}: expected 'a2a' or 'allgather'")
         if self.exchange == "allgather":
             # chunk j's gathered block = rows [j*world*ck, (j+1)*world*ck): rank r's frames of the chunk at offset r*ck

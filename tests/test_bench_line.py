@@ -66,3 +66,30 @@ def test_c4_error_and_missing_blocks():
     line = bench.compact_line(full)
     assert len(json.dumps(line)) < bench.LINE_LIMIT
     assert "error" in line["c4"] and "detail" not in line
+
+
+def test_partial_record_still_yields_the_contract_keys():
+    """a record an optional block cannot digest (a rooflines entry without its time, a c4 stage of an unexpected shape) must not
+    cost the final line — the contract keys, `roofline` and `cpu_baseline` still go out, with the reason."""
+    full = _canned()
+    del full["rooflines"][0]["kernel_ms_per_step"]
+    line = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    s = json.dumps(line)
+    assert len(s) < bench.LINE_LIMIT
+    for k in CONTRACT + ("roofline", "cpu_baseline", "compact_error"):
+        assert k in line, k
+    full = _canned()
+    full["c4"]["stages"]["raft_864x480"] = 3.0              # not a dict
+    line = bench.compact_line(full)
+    assert "compact_error" in line and all(k in line for k in CONTRACT)
+
+
+def test_oversized_non_droppable_blocks_fall_back_to_the_contract_keys():
+    full = _canned()
+    full["config"] = {"workload": "w" * 150, **{f"k{i}": "v" * 190 for i in range(40)}}      # 40 x 200 bytes of config survive every pop
+    full["pipeline_sharded"] = {f"s{i}": "p" * 100 for i in range(30)}
+    line = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    assert len(json.dumps(line)) < bench.LINE_LIMIT
+    for k in CONTRACT:
+        assert k in line, k
+    assert "dropped" in line

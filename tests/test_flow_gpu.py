@@ -101,6 +101,9 @@ def test_warp_every_vector_width_matches_oracle(C, H, W, dev):
     wide = torch.zeros(B, H, W, C + 5, device=dev)
     wide[..., 1:1 + C] = nhwc(img)
     assert torch.equal(ops.warp(wide[..., 1:1 + C], nhwc(flow)), out)          # an unaligned channel slice: the scalar path, same values
+    fbuf = torch.zeros(B * H * W * 2 + 1, device=dev)
+    fbuf[1:] = nhwc(flow).reshape(-1)
+    assert torch.equal(ops.warp(nhwc(img), fbuf[1:].view(B, H, W, 2)), out)    # a contiguous flow view at an odd float offset (4-byte aligned only)
 
 
 def test_raft_helper_kernels(dev):

@@ -47,11 +47,13 @@ def main():
         x1 = kw.get("x1")
         o = out[0] if isinstance(out, tuple) else out
         key = (tuple(xs), 0 if x1 is None else x1.shape[-1], pc.Cout, pc.groups, f"{pc.kh}x{pc.kw}", kw.get("stride", 1), ("f16" if x.h else "split") if isinstance(x, ops.Split) else "fp32",
-               {None: "f32", "only": "split", "both": "f32+split"}[kw.get("out_split")], kw.get("epi") or "-")
+               {None: "f32", "only": "split", "both": "f32+split"}[kw.get("out_split")], (kw.get("epi") or "-") + ("/ps" if kw.get("ps") else ""))
         osh = tuple(o.shape)
         M = osh[0] * osh[1] * osh[2] if len(osh) == 4 else osh[0]
         cin = (xs[-1] + (0 if x1 is None else x1.shape[-1]))
         flops = 2.0 * M * (pc.Cout // pc.groups) * pc.k_alg * pc.groups
+        if kw.get("ps"):                      # fold as a convolution: credited with the Linear's work (rows x cin x k*k*cc), written map = Hf x Wf x cc
+            flops = 2.0 * xs[0] * xs[1] * xs[2] * kw["n_alg"] * pc.k_alg
         h_in = isinstance(x, ops.Split) and x.h                        # fp16 tensors: 2 B per value
         osp = kw.get("out_split")
         h_out = bool(osp) and a.precision == "f16"
@@ -72,9 +74,9 @@ def main():
         g[0] += 1; g[1] += e0.elapsed_time(e1); g[2] += fl_; g[3] += by
     tot = sum(v[1] for v in agg.values())
     print(f"{len(recs)} conv launches, {tot:.2f} ms (event-bracketed, includes launch gaps)")
-    print(f"{'input':28s} {'C1':>4s} {'Cout':>5s} {'g':>2s} {'k':>4s} {'s':>2s} {'in':>6s} {'out':>9s} {'epi':>4s} {'calls':>5s} {'ms':>8s} {'%':>5s} {'TF alg':>7s} {'GB/s floor':>10s}")
+    print(f"{'input':28s} {'C1':>4s} {'Cout':>5s} {'g':>2s} {'k':>4s} {'s':>2s} {'in':>6s} {'out':>9s} {'epi':>10s} {'calls':>5s} {'ms':>8s} {'%':>5s} {'TF alg':>7s} {'GB/s floor':>10s}")
     for key, (n, ms_, fl_, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        print(f"{str(key[0]):28s} {key[1]:4d} {key[2]:5d} {key[3]:2d} {key[4]:>4s} {str(key[5]):>2s} {key[6]:>6s} {key[7]:>9s} {key[8]:>4s} {n:5d} {ms_:8.3f} {100 * ms_ / tot:5.1f} {fl_ / ms_ / 1e9:7.1f} {by / ms_ / 1e6:10.0f}")
+        print(f"{str(key[0]):28s} {key[1]:4d} {key[2]:5d} {key[3]:2d} {key[4]:>4s} {str(key[5]):>2s} {key[6]:>6s} {key[7]:>9s} {key[8]:>10s} {n:5d} {ms_:8.3f} {100 * ms_ / tot:5.1f} {fl_ / ms_ / 1e9:7.1f} {by / ms_ / 1e6:10.0f}")
 
 
 if __name__ == "__main__":
