@@ -18,6 +18,7 @@ the flow stages (conv/GEMM TF as executed, and the HBM-bound kernels: corr looku
 
 Not covered (out of scope): image I/O, cv2.resize / cv2.inpaint, scipy.ndimage mask dilation, edge maps.
 """
+import json
 import os
 import time
 
@@ -102,6 +103,14 @@ def _mfma(ms_unit, gflop_unit, prec):
             "unit": "TFLOP/s", "frac": round(alg * passes / peak, 4), "mfma_passes_per_product": passes}
 
 
+def _counter_traffic(prec):
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "kernel_traffic.json")
+    try:
+        return json.load(open(p)).get(prec, {})
+    except (OSError, ValueError):
+        return {}
+
+
 def _hbm(ms, nbytes):
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM, "unit": "GB/s", "frac": round(gbs / PEAK_HBM, 4), "algorithmic_bytes": int(nbytes)}
@@ -159,6 +168,9 @@ def run_stages(dev, prec="bf16x3", frames=80, H=240, W=432, fgt_ms=None, with_cp
             out["c2_spatial_mhsa"] = c2_spatial_mhsa(dev, fgt_model, prec)
             if prec != "fp32":
                 out["c2_spatial_mhsa"]["fp32_exact"] = {k: v for k, v in c2_spatial_mhsa(dev, fgt_model, "fp32").items() if k.startswith(("mfma_frac", "ms_per", "hbm_frac"))}
+            # the same module at the size the benchmark's step actually launches it (8 windows x 17 frames = 136 frames per call)
+            out["c2_spatial_mhsa"]["at_step_size_t136"] = {k: v for k, v in c2_spatial_mhsa(dev, fgt_model, prec, t=136, reps=3).items()
+                                                            if k.startswith(("mfma_frac", "ms_per", "hbm_frac"))}
         except Exception as e:  # noqa: BLE001
             out["c2_spatial_mhsa"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     st = out["stages"]
@@ -307,7 +319,13 @@ def run_stages(dev, prec="bf16x3", frames=80, H=240, W=432, fgt_ms=None, with_cp
         ms, fl, n, by = other[kind]
         if n == 0 or ms <= 0:
             continue
-        rl.append(dict(_hbm(ms, by), kind=kind, launches=n, avg_launch_us=round(1e3 * ms / n, 2)))
+        e = dict(_hbm(ms, by), kind=kind, launches=n, avg_launch_us=round(1e3 * ms / n, 2))
+        tr = _counter_traffic(prec).get(kind)
+        if tr and tr.get("traffic_over_algorithmic"):
+            # rocprofv3 FETCH_SIZE / WRITE_SIZE of this kernel at the same shapes (tools/hbm_micro.py under --pmc, profiles/kernel_traffic.json)
+            e.update(traffic_over_algorithmic=tr["traffic_over_algorithmic"], counter_bytes_per_launch=tr.get("hbm_bytes_per_launch"),
+                     counter_GBps=round(e["achieved"] * tr["traffic_over_algorithmic"], 1))
+        rl.append(e)
     ops.prof_collect("all")
     out["rooflines"] = rl
     # ------------------------------------------------------------------ CPU baselines on bounded samples (oracle = port of the reference)

@@ -407,6 +407,8 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
         FGT_REQUIRE(!d.out_split || d.pso != 32 || d.ps_c % 32 == 0, "fgt_conv2d: interleaved sub-pixel out_s needs ps_c %% 32 == 0");
     }
     FGT_REQUIRE(!(d.ps_r || d.aux_per_image || d.epi >= FGT_EPI_AFFINE) || p.Cout_g > 4, "fgt_conv2d: the Cout <= 4 kernels have no sub-pixel / per-image-table epilogue");
+    FGT_REQUIRE(d.ld_bias >= 0 && d.reserved0 == 0 && (d.ld_bias == 0 || (cbias != nullptr && p.Cout_g > 4 && d.ld_bias % 4 == 0 && d.ld_bias >= d.Cout && !d.ps_r && d.in_split != 3)),
+                "fgt_conv2d: a bias map (ld_bias > 0) needs cbias, Cout/groups > 4, ld_bias %% 4 == 0, ld_bias >= Cout, no sub-pixel output, no fp16 inputs");
     FGT_REQUIRE(d.ky_skip_n0 == 0 || (d.groups == 1 && d.kh >= 2 && d.upsample == 0), "fgt_conv2d: ky_skip_n0 needs groups = 1, kh >= 2, no upsampling");
     const long M = (long)d.N * Ho * Wo;
     FGT_REQUIRE(M < (1l << 31), "fgt_conv2d: M too large");
@@ -456,7 +458,8 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     const double out_vals = d.ps_r ? (double)d.N * d.ps_H * d.ps_W * d.ps_c : (double)M * d.Cout;
     const double aux1_vals = d.epi == FGT_EPI_NONE ? 0.0 : (d.aux_per_image ? (double)Ho * Wo * d.Cout : (double)M * d.Cout);
     const double aux2_vals = d.epi < FGT_EPI_GRU ? 0.0 : d.epi == FGT_EPI_PS_ADD2 ? out_vals : (d.epi == FGT_EPI_AFFINE && d.aux_per_image ? (double)Ho * Wo * d.Cout : (double)M * d.Cout);
-    const double conv_bytes = in_b * ((double)d.N * d.H * d.W * (d.C0 + d.C1) + (double)d.Cout * p.K) +
+    const double bmap_bytes = d.ld_bias > 0 ? 4.0 * (double)M * d.Cout : 0.0;
+    const double conv_bytes = bmap_bytes + in_b * ((double)d.N * d.H * d.W * (d.C0 + d.C1) + (double)d.Cout * p.K) +
                               out_vals * ((d.out_split != 1 ? 4.0 : 0.0) + (d.out_split ? os_b : 0.0)) + 4.0 * (aux1_vals + aux2_vals);
     // (Cout <= 4 VALU kernels: an HBM-bound pass over the input map — their own kind, bytes only)
     const int prof = direct ? fgt_prof_begin(FGT_PROF_CONV_SMALL, 0.0, conv_bytes, s) : fgt_prof_begin(FGT_PROF_CONV, 2.0 * (double)M * (d.n_alg > 0 ? d.n_alg : p.Cout_g) * (d.k_alg > 0 ? d.k_alg : p.K) * d.groups, conv_bytes, s);

@@ -507,14 +507,31 @@ int launch(const ConvP& p, hipStream_t s) {
 
 }  // namespace
 
-#ifdef FGT_PP_TRACE
+#if defined(FGT_PP_TRACE) && !defined(FGT_IL_PART)
 extern "C" int fgt_debug_pp_trace(unsigned long long* host_out, int n) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(fgt_pp_trace_buf), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
 }
 #endif
 
-// called by fgt_conv_taps_launch (conv_taps.hip) for the "...it" tile codes; same eligibility as the other tap tiles minus k x 1 / upsampling
+// called by fgt_conv_taps_launch (conv_taps.hip) for the "...it" tile codes; same eligibility as the other tap tiles minus k x 1 / upsampling.
+// Build time: the three tiles are separate translation units (this file = the 128 x 128 tile and the dispatcher; conv_taps_il_256x128.hip and
+// conv_taps_il_256x256.hip include it with FGT_IL_PART = 1 / 2) — one unit took 11 minutes of hipcc with the epilogue's instances.  Trace builds
+// (-DFGT_PP_TRACE: one stamp buffer) keep everything in this unit.
+int fgt_conv_taps_il_256x128(const ConvP& p, hipStream_t s);
+int fgt_conv_taps_il_256x256(const ConvP& p, hipStream_t s);
+#if defined(FGT_PP_TRACE)
+#if !defined(FGT_IL_PART)
+int fgt_conv_taps_il_256x128(const ConvP& p, hipStream_t s) { return launch<256, 128>(p, s); }
+int fgt_conv_taps_il_256x256(const ConvP& p, hipStream_t s) { return launch<256, 256>(p, s); }
+#endif
+#elif defined(FGT_IL_PART) && FGT_IL_PART == 1
+int fgt_conv_taps_il_256x128(const ConvP& p, hipStream_t s) { return launch<256, 128>(p, s); }
+#elif defined(FGT_IL_PART) && FGT_IL_PART == 2
+int fgt_conv_taps_il_256x256(const ConvP& p, hipStream_t s) { return launch<256, 256>(p, s); }
+#endif
+#if !defined(FGT_IL_PART)
 int fgt_conv_taps_il_launch(int bm, int bn, const ConvP& p, hipStream_t s) {
     if (bm == 128) return launch<128, 128>(p, s);
-    return bn == 256 ? launch<256, 256>(p, s) : launch<256, 128>(p, s);
+    return bn == 256 ? fgt_conv_taps_il_256x256(p, s) : fgt_conv_taps_il_256x128(p, s);
 }
+#endif

@@ -97,7 +97,8 @@ __device__ __forceinline__ void conv_row_of(const ConvP& p, int mt, int ry, int 
 // then the fp32 store (NHWC slice or NCHW) and / or the pre-split bf16 store (desc.out_split) the next conv's LDS-DMA
 // loader consumes.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
 // STAGE = floats per LDS stage; the caller guarantees 2 stages are allocated and no longer in use.
-template <int BM, int BN, int WM, int WN, int STAGE, int TM, int TN>
+// BIAS_MAP = false: a kernel family that never sees desc.ld_bias > 0 (the fp16 kernels: the host rejects the combination) skips those instances.
+template <int BM, int BN, int WM, int WN, int STAGE, int TM, int TN, bool BIAS_MAP = true>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], float* smem, int bm0, int bn0, int g) {
     constexpr int NT = WM * WN * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -112,7 +113,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
     const int l31 = lane & 31, lh = lane >> 5;
     float* Cs = smem;
     const bool vec_ok = (p.Cout_g % 4 == 0) && !d.out_nchw && (d.ldo % 4 == 0) && (d.ooff % 4 == 0) &&
-                        (d.epi == FGT_EPI_NONE || d.ld_aux1 % 4 == 0) && (d.epi < FGT_EPI_GRU || d.ld_aux2 % 4 == 0);
+                        (d.epi == FGT_EPI_NONE || d.ld_aux1 % 4 == 0) && (d.epi < FGT_EPI_GRU || d.ld_aux2 % 4 == 0) && d.ld_bias % 4 == 0;
     const bool want_f32 = d.out_split != 1, want_split = d.out_split != 0;
 
     // ---- fast path (every layer of the hot path: float4-aligned channels-last output): WAVE-PRIVATE staging.  Each wavefront
@@ -133,7 +134,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         const int co = g * p.Cout_g + n;
         const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 sc = (p.cscale && col_ok) ? *reinterpret_cast<const float4*>(p.cscale + co) : one;
-        const float4 bi = (p.cbias && col_ok) ? *reinterpret_cast<const float4*>(p.cbias + co) : zero;
+        const float4 bi = (p.cbias && col_ok && d.ld_bias == 0) ? *reinterpret_cast<const float4*>(p.cbias + co) : zero;
         // ABI 7, sub-pixel output: a lane keeps its 4 columns, so its sub-pixel and output channel are per-lane constants (ps_c % 4 == 0: a float4 never
         // straddles two sub-pixels); a row's (image, I, J) costs two multiply-shift divisions.
         int ps_ry = 0, ps_rx = 0, och = co;
@@ -145,18 +146,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         // stores was waited for before the next one was issued, 13 k cycles for 64 KB per workgroup in the K = 512 GEMMs
         // (profiles/r02_run8_conv_trace_qkv_epilogue.txt).  AUX = 0 has no load behind its first store: the stores stream.
         auto body = [&](auto auxc) __attribute__((always_inline)) {
-        constexpr int AUX = decltype(auxc)::value;
+        constexpr int AUX = decltype(auxc)::value & 3;
+        constexpr bool BMAP = (decltype(auxc)::value >> 2) != 0;       // desc.ld_bias > 0: the bias is an [M, Cout] map (one more loaded operand)
+        constexpr bool LD = AUX >= 1 || BMAP;
         // loads of UN row groups in flight together (the 128-accumulator-register tiles have little room: 2 at a time)
         // (two aux operands, each held for two groups: 2 rows at a time as well)
-        constexpr int UN = (TM * TN >= 8 || TM * TN == 1 || AUX == 2) ? 2 : ITER;      // (one accumulator tile per wavefront: the <= 85-register tiles)
+        constexpr int UN = (TM * TN >= 8 || TM * TN == 1 || AUX == 2 || BMAP) ? 2 : ITER;      // (one accumulator tile per wavefront: the <= 85-register tiles)
         constexpr int GPB = ITER / UN, NG = TM * GPB;                  // row groups per 32-row block, per wavefront
         // Aux operands are requested ONE GROUP AHEAD, in front of the previous group's stores: the wait for a group's operands then covers
         // the loads older than those stores, not the stores (same counter, in order) — otherwise every group would wait for the write
         // acknowledgements of the group before it.
         // (not in the one-accumulator-tile kernels, which run at <= 85 registers: there a group's operands are requested right before use)
         constexpr bool AHEAD = TM * TN > 1;
-        float4 ax1[AHEAD ? 2 : 1][UN], ax2[AHEAD ? 2 : 1][UN];
-        auto load_aux = [&](auto gc, float4 (&a1)[UN], float4 (&a2)[UN]) __attribute__((always_inline)) {
+        float4 ax1[AHEAD ? 2 : 1][UN], ax2[AHEAD ? 2 : 1][UN], axb[AHEAD ? 2 : 1][UN];
+        auto load_aux = [&](auto gc, float4 (&a1)[UN], float4 (&a2)[UN], float4 (&ab_)[UN]) __attribute__((always_inline)) {
             constexpr int gi = decltype(gc)::value, i = gi / GPB, c0 = (gi % GPB) * UN;
 #pragma unroll
             for (int u0 = 0; u0 < UN; ++u0) {
@@ -173,9 +176,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                     const float* q2 = d.epi == FGT_EPI_PS_ADD2 ? p.aux2 + m * d.ld_aux2 + och : p.aux2 + (d.epi == FGT_EPI_AFFINE ? m1 : m) * d.ld_aux2 + co;
                     a2[u0] = *reinterpret_cast<const float4*>(okk && okr ? q2 : p.zero_page);
                 }
+                if constexpr (BMAP) ab_[u0] = *reinterpret_cast<const float4*>(okk ? p.cbias + m * d.ld_bias + co : p.zero_page);
             }
         };
-        if constexpr (AUX >= 1 && AHEAD) load_aux(std::integral_constant<int, 0>{}, ax1[0], ax2[0]);
+        if constexpr (LD && AHEAD) load_aux(std::integral_constant<int, 0>{}, ax1[0], ax2[0], axb[0]);
         static_for<NG>([&](auto gc) {
             constexpr int gi = decltype(gc)::value, i = gi / GPB, c0 = (gi % GPB) * UN;
             if constexpr (gi % GPB == 0) {
@@ -186,8 +190,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 __builtin_amdgcn_wave_barrier();                       // the patch is exchanged between lanes of this wavefront only
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            if constexpr (AUX >= 1 && AHEAD && gi + 1 < NG) load_aux(std::integral_constant<int, gi + 1>{}, ax1[(gi + 1) & 1], ax2[(gi + 1) & 1]);
-            if constexpr (AUX >= 1 && !AHEAD) load_aux(gc, ax1[0], ax2[0]);
+            if constexpr (LD && AHEAD && gi + 1 < NG) load_aux(std::integral_constant<int, gi + 1>{}, ax1[(gi + 1) & 1], ax2[(gi + 1) & 1], axb[(gi + 1) & 1]);
+            if constexpr (LD && !AHEAD) load_aux(gc, ax1[0], ax2[0], axb[0]);
             constexpr int ab = AHEAD ? (gi & 1) : 0;
             const int mrow = bm0 + wm * WTM + i * 32 + r0;
             float4 cv[UN];
@@ -204,7 +208,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 int rem_;
                 bool okr;
                 conv_row_of(p, mrow + (c0 + u0) * RPI, ps_ry, ps_rx, ps_col, m, rem_, okr);
-                float v[4] = {cv[u0].x * sc.x + bi.x, cv[u0].y * sc.y + bi.y, cv[u0].z * sc.z + bi.z, cv[u0].w * sc.w + bi.w};
+                const float4 bv = BMAP ? axb[ab][u0] : bi;
+                float v[4] = {cv[u0].x * sc.x + bv.x, cv[u0].y * sc.y + bv.y, cv[u0].z * sc.z + bv.z, cv[u0].w * sc.w + bv.w};
                 float x1[4] = {0.f, 0.f, 0.f, 0.f}, x2[4] = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (AUX >= 1) { const float4 t = ax1[ab][u0]; x1[0] = t.x; x1[1] = t.y; x1[2] = t.z; x1[3] = t.w; }
                 if constexpr (AUX >= 2) { const float4 t = ax2[ab][u0]; x2[0] = t.x; x2[1] = t.y; x2[2] = t.z; x2[3] = t.w; }
@@ -259,7 +264,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
             if constexpr (gi % GPB == GPB - 1) __builtin_amdgcn_wave_barrier();     // the patch is rewritten by the next row block
         });
         };
-        if (d.epi == FGT_EPI_NONE) body(std::integral_constant<int, 0>{});
+        if (BIAS_MAP && d.ld_bias > 0) {       // a bias MAP (RAFT's GRU convs: the iteration-invariant context term, update.py:45-58): its own instances
+            if constexpr (BIAS_MAP) {
+                if (d.epi == FGT_EPI_NONE) body(std::integral_constant<int, 4>{});
+                else if (d.epi >= FGT_EPI_GRU) body(std::integral_constant<int, 6>{});
+                else body(std::integral_constant<int, 5>{});
+            }
+        } else if (d.epi == FGT_EPI_NONE) body(std::integral_constant<int, 0>{});
         else if (d.epi >= FGT_EPI_GRU) body(std::integral_constant<int, 2>{});
         else body(std::integral_constant<int, 1>{});
         return;
@@ -300,7 +311,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
             for (int u = 0; u < 4; ++u) {
                 if (u < nvalid) {
                     const float cs = p.cscale ? p.cscale[co + u] : 1.f;
-                    const float cb = p.cbias ? p.cbias[co + u] : 0.f;
+                    const float cb = !p.cbias ? 0.f : d.ld_bias > 0 ? p.cbias[m * d.ld_bias + co + u] : p.cbias[co + u];
                     float pre = v[u] * cs + cb;
                     if (d.epi == FGT_EPI_AFFINE) pre = fmaf(pre, p.aux2[m1 * d.ld_aux2 + co + u], p.aux1[m1 * d.ld_aux1 + co + u]);
                     else if (d.epi == FGT_EPI_PS_ADD2) pre = pre + p.aux1[m1 * d.ld_aux1 + co + u] + p.aux2[m * d.ld_aux2 + och + u];

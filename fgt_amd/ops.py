@@ -306,11 +306,12 @@ def prepack_weights(pc, mode=None):
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
            epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None,
-           out_split=None, out_s=None, out_il=False, out_h=None, ps=None, ky_skip_n0=0, aux_per_image=False, n_alg=0):
+           out_split=None, out_s=None, out_il=False, out_h=None, ps=None, ky_skip_n0=0, aux_per_image=False, n_alg=0, bias_map=None):
     """fgt_conv2d.  x (and optional x1) are channels-last maps (fp32 tensors, or `Split`s for the LDS-DMA bf16x3 path);
     returns/outputs a channels-last map (or NCHW).  out_split: None -> fp32 result; "only" -> a Split; "both" -> (fp32, Split).
     ps = (r, c, g0, Hf, Wf): sub-pixel output (fold as a convolution, fgt_conv_desc.ps_r): the result is the [N, Hf, Wf, c] map;
-    ky_skip_n0 / aux_per_image / n_alg: the fields of the same name."""
+    ky_skip_n0 / aux_per_image / n_alg: the fields of the same name.  bias_map: an fp32 [N, Ho, Wo, Cout] (or [rows, Cout]) map added in front of
+    the activation INSTEAD of pc.bias (fgt_conv_desc.ld_bias; the caller folds the bias into it)."""
     in_split = isinstance(x, Split)
     if in_split:
         assert x1 is None or (isinstance(x1, Split) and x1.il == x.il and x1.h == x.h), "conv2d: both sources must be split the same way"
@@ -318,7 +319,7 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
         x, x1 = xs.hi, (None if x1s is None else x1s.hi)
     else:
         _require_dev(x, x1)
-    _require_dev(aux1, aux2, out)
+    _require_dev(aux1, aux2, out, bias_map)
     x, N, H, W, C0, ld0 = _as_map(x)
     C1, ld1 = 0, 0
     if x1 is not None:
@@ -360,6 +361,11 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     if ps is not None:
         d.ps_r, d.ps_c, d.ps_g0, d.ps_H, d.ps_W = (int(v) for v in ps)
     d.ky_skip_n0, d.aux_per_image, d.n_alg = int(ky_skip_n0), int(bool(aux_per_image)), int(n_alg)
+    bias = pc.bias
+    if bias_map is not None:
+        b4, bN, bH, bW, bC, d.ld_bias = _as_map(bias_map)
+        assert (bN * bH * bW, bC) == (N * Ho * Wo, pc.Cout), f"conv2d: bias_map shape {tuple(bias_map.shape)}"
+        bias = b4
     prec = precision if precision is not None else DEFAULT_CONV_PRECISION
     if prec == "f16" and not (in_split and xs.h):
         prec = "bf16x3"                      # 'f16' = fp16 where the operand arrives as fp16; fp32 inputs are not rounded to 11 bits here
@@ -392,12 +398,12 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
         d.w_il = int(wil)
         if d.tile >= 300:                    # diagnostic builds: weights in MFMA fragment order (csrc/diag/conv_taps_breg.hip)
             wbuf, d.w_il = _frag_weights(pc), 2
-    args = (C.byref(d), _ptr(x), _ptr(x1), _ptr(wbuf), _ptr(pc.scale), _ptr(pc.bias), _ptr(aux1), _ptr(aux2), _ptr(out),
+    args = (C.byref(d), _ptr(x), _ptr(x1), _ptr(wbuf), _ptr(pc.scale), _ptr(bias), _ptr(aux1), _ptr(aux2), _ptr(out),
             _ptr(None if out_s is None else out_s.data))
     if d.tile == 0 and AUTOTUNE and pc.Cout // pc.groups > 4:
         key = (N, H, W, C0, C1, pc.Cout, pc.groups, pc.kh, pc.kw, sh, sw, ph, pw, dh, dw, d.upsample, d.epi, d.out_nchw, d.precision,
                d.in_split, d.out_split, d.w_il, int(bool(osp) and out_s.il) + 2 * int(bool(osp) and out_s.h), d.pad_mode, d.in_relu,
-               d.ps_r, d.ps_c, d.ps_H, d.ps_W, d.ky_skip_n0)
+               d.ps_r, d.ps_c, d.ps_H, d.ps_W, d.ky_skip_n0, int(d.ld_bias > 0))
         best = _tile_cache.get(key)
         if best is not None and key not in _tile_validated:
             # A cached / loaded tile must belong to the kernel family the GEOMETRY routes this layer to (taps-routed layers: codes 200-299,
@@ -409,7 +415,7 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
                 _tile_cache.pop(key, None)
             else:
                 _tile_validated.add(key)
-        if best is None and not torch.cuda.is_current_stream_capturing() and not _aliases(out, out_s, x, x1, aux1, aux2):
+        if best is None and not torch.cuda.is_current_stream_capturing() and not _aliases(out, out_s, x, x1, aux1, aux2, bias_map):
             # (tuning re-launches the kernel into the caller's buffers and synchronises: illegal under stream capture, and it would
             #  corrupt an output that aliases an input / aux operand — such calls run on the static tile and are not cached)
             taps = bool(_lib.lib().fgt_conv_taps_route(C.byref(d)))

@@ -120,6 +120,7 @@ class RAFT(nn.Module):
         self.update_block = UpdateBlockParams(self.corr_levels * (2 * self.corr_radius + 1) ** 2)
         self._packed, self._key = None, None
         self.use_graph = os.environ.get("FGT_GRAPHS", "0") == "1"
+        self.hoist_context = os.environ.get("FGT_RAFT_HOIST", "1") != "0"
         self._graphs = {}
 
     # ------------------------------------------------------------------ packing
@@ -156,7 +157,18 @@ class RAFT(nn.Module):
             c1w, c1b = u.encoder.convc1.weight.detach(), u.encoder.convc1.bias.detach()
             cpad = (-c1w.shape[1]) % 32
             P["enc"]["convc1p"] = PackedConv(torch.cat([c1w, torch.zeros(c1w.shape[0], cpad, 1, 1, device=c1w.device, dtype=c1w.dtype)], 1), c1b)
-            P["gru"] = {n: self._pk(getattr(u.gru, n)) for n in ("convz1", "convr1", "convq1", "convz2", "convr2", "convq2")}
+            # SepConvGRU (update.py:36-60): hx = [h | inp | motion]; `inp` = relu(cnet[:, 128:]) does not change over the refinement loop
+            # (raft.py:112-115, 126-128), so each conv is split into the per-iteration part over [h | motion] (256 of the 384 input channels)
+            # and the context part over `inp` (+ bias), which iterate() evaluates ONCE per pair and hands to the per-iteration conv as a
+            # bias map (fgt_conv_desc.ld_bias): a third of the GRU's multiply-adds leaves the loop.  FGT_RAFT_HOIST=0: the undivided convs.
+            P["gru"], P["gru_it"], P["gru_ctx"] = {}, {}, {}
+            for n in ("convz1", "convr1", "convq1", "convz2", "convr2", "convq2"):
+                cv = getattr(u.gru, n)
+                w, b = cv.weight.detach(), cv.bias.detach()
+                hd = self.hidden_dim
+                P["gru"][n] = self._pk(cv)
+                P["gru_it"][n] = PackedConv(torch.cat([w[:, :hd], w[:, 2 * hd:]], 1), None)
+                P["gru_ctx"][n] = PackedConv(w[:, hd:2 * hd], b)
             P["fh"] = (self._pk(u.flow_head.conv1), self._pk(u.flow_head.conv2))
             P["mask"] = (self._pk(u.mask[0]), self._pk(u.mask[2]))
             self._packed, self._key = P, key
@@ -263,6 +275,14 @@ class RAFT(nn.Module):
             ops.split(cmap.view(rows, 256)[:, 128:], relu=True, out=xbuf_s.channels(0, 128))       # inp = relu(cnet[:, 128:])
             ops.split(net, out=net_s)
             motion_s, flow_s = xbuf_s.channels(128, 256), xbuf_s.channels(254, 256)
+        hoist = self.hoist_context
+        pads = {"1": (0, 2), "2": (2, 0)}
+        if hoist:
+            # the context term of every GRU conv, once per pair: conv over inp + bias, fp32 maps [rows, 128] (update.py:45-58 restricted to hx[:, 128:256])
+            GI, GC = P["gru_it"], P["gru_ctx"]
+            inp_in = s4(xbuf_s.channels(0, 128)) if sc else m4(xbuf)[..., :128]
+            ctx = {g_ + s_: ops.conv2d(inp_in, GC["conv" + g_ + s_], pad=pads[s_]) for s_ in ("1", "2") for g_ in ("z", "r", "q")}
+            x_it = s4(motion_s) if sc else m4(xbuf)[..., 128:]
         ups = []
         for it in range(iters):
             if sc:
@@ -281,9 +301,10 @@ class RAFT(nn.Module):
                 # SepConvGRU (update.py:36-60): horizontal then vertical pass; z stays fp32 (an epilogue operand), r * h goes on split, the new
                 # hidden state is written in both forms (fp32: the next pass's epilogue operands and the heads; split: the next convs' input)
                 for s_, pad in (("1", (0, 2)), ("2", (2, 0))):
-                    z = ops.conv2d(s4(net_s), G["convz" + s_], x1=s4(xbuf_s), pad=pad, act="sigmoid")
-                    ops.conv2d(s4(net_s), G["convr" + s_], x1=s4(xbuf_s), pad=pad, act="sigmoid", epi="mul", aux1=net, out_split="only", out_s=rh_s)
-                    net, _ = ops.conv2d(s4(rh_s), G["convq" + s_], x1=s4(xbuf_s), pad=pad, act="tanh", epi="gru", aux1=z, aux2=net, out_split="both", out_s=net_s)
+                    gz, gr, gq = ((GI["conv" + g_ + s_], dict(x1=x_it, bias_map=ctx[g_ + s_])) if hoist else (G["conv" + g_ + s_], dict(x1=s4(xbuf_s))) for g_ in "zrq")
+                    z = ops.conv2d(s4(net_s), gz[0], pad=pad, act="sigmoid", **gz[1])
+                    ops.conv2d(s4(net_s), gr[0], pad=pad, act="sigmoid", epi="mul", aux1=net, out_split="only", out_s=rh_s, **gr[1])
+                    net, _ = ops.conv2d(s4(rh_s), gq[0], pad=pad, act="tanh", epi="gru", aux1=z, aux2=net, out_split="both", out_s=net_s, **gq[1])
                     net = net.view(rows, 128)
                 d = ops.conv2d(s4(net_s), P["fh"][0], pad=1, act="relu")
             else:
@@ -294,9 +315,10 @@ class RAFT(nn.Module):
                 ops.conv2d(cor, E["conv"], x1=flo, pad=1, act="relu", out=m4(xbuf)[..., 128:254])
                 ops.axpby(flow4[:, :2], out=xbuf[:, 254:256])
                 for s_, pad in (("1", (0, 2)), ("2", (2, 0))):
-                    z = ops.conv2d(m4(net), G["convz" + s_], x1=m4(xbuf), pad=pad, act="sigmoid")
-                    rh = ops.conv2d(m4(net), G["convr" + s_], x1=m4(xbuf), pad=pad, act="sigmoid", epi="mul", aux1=net)
-                    net = ops.conv2d(rh, G["convq" + s_], x1=m4(xbuf), pad=pad, act="tanh", epi="gru", aux1=z, aux2=net).view(B * n, 128)
+                    gz, gr, gq = ((GI["conv" + g_ + s_], dict(x1=x_it, bias_map=ctx[g_ + s_])) if hoist else (G["conv" + g_ + s_], dict(x1=m4(xbuf))) for g_ in "zrq")
+                    z = ops.conv2d(m4(net), gz[0], pad=pad, act="sigmoid", **gz[1])
+                    rh = ops.conv2d(m4(net), gr[0], pad=pad, act="sigmoid", epi="mul", aux1=net, **gr[1])
+                    net = ops.conv2d(rh, gq[0], pad=pad, act="tanh", epi="gru", aux1=z, aux2=net, **gq[1]).view(B * n, 128)
                 d = ops.conv2d(m4(net), P["fh"][0], pad=1, act="relu")
             # FlowHead + coords update (update.py:6-15, raft.py:131-132)
             new_coords = torch.empty_like(coords1)

@@ -153,7 +153,7 @@ def compose_torch(out, nb, frames01, masks, comp, visited):
 class ClipRunner:
     def __init__(self, model, frames01, flows_normed, masks, neighbor_stride=5, ref_length=10, num_ref=-1,
                  rank=0, world=1, forward=None, group=None, cache_features=None, encode_chunk=20, use_graphs=False, window_batch=8,
-                 n_streams=None, prune_last=True):
+                 n_streams=None, prune_last=True, exchange=None):
         self.model = model
         # prune_last: the last transformer pair computes only the frames the tool consumes (FGT.transform_decode `tq`): exact
         self.prune_last = bool(prune_last)
@@ -221,7 +221,8 @@ class ClipRunner:
         # FGT_EXCHANGE=allgather: replace the needed-rows all-to-all by a plain all_gather_into_tensor of every chunk (equal-sized
         # contributions, the most ordinary collective there is) — the degraded mode for a first RCCL run in which the uneven / zero-length
         # all_to_all_single misbehaves.  Same composite (tests/test_scheduler.py), ~2.7x the bytes on the wire at 8 ranks.
-        self.exchange = "none" if world == 1 else os.environ.get("FGT_EXCHANGE", "a2a").lower()
+        # (`exchange=` overrides the environment: bench.py --gpus N runs the sharded clip once per mode)
+        self.exchange = "none" if world == 1 else (exchange or os.environ.get("FGT_EXCHANGE", "a2a")).lower()
         if world > 1 and self.exchange not in ("a2a", "allgather"):
             raise ValueError(f"FGT_EXCHANGE={self.exchange!r}: expected 'a2a' or 'allgather'")
         if self.exchange == "allgather":

@@ -54,7 +54,7 @@ int fgt_init(int device);
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
  *
- * out[n, oy, ox, ooff + g*Cout_g + co] = epi( act( cscale[co] * sum_{ky,kx,ci} x(...) * w + cbias[co] ) )
+ * out[n, oy, ox, ooff + g*Cout_g + co] = epi( act( cscale[co] * sum_{ky,kx,ci} x(...) * w + cbias[co] ) )      (cbias[m, co] with desc.ld_bias > 0)
  *
  * Input: one or two channels-last sources concatenated per group: group g reads channels
  *   [g*C0/groups, (g+1)*C0/groups) of x0 followed by [g*C1/groups, ...) of x1 (C1 = 0: single source).
@@ -137,6 +137,10 @@ typedef struct fgt_conv_desc {
                              * the sign of zero)                                                                           */
     int aux_per_image;      /* 1: aux1 (and aux2 of FGT_EPI_AFFINE) are [Ho*Wo, Cout] tables shared by all N images (row = m mod Ho*Wo) */
     int n_alg;              /* profiling only: output columns credited as algorithmic work (0 = Cout/groups), see k_alg     */
+    int ld_bias;            /* 0: `cbias` is a [Cout] vector (or NULL) | > 0: `cbias` is an [M, Cout] MAP with this row stride, added in front
+                             * of the activation like the vector (RAFT's SepConvGRU: the convolution of the iteration-invariant context
+                             * features `inp`, RAFT/update.py:45-58, raft.py:112-115, computed once per pair instead of once per iteration) */
+    int reserved0;          /* 0 */
 } fgt_conv_desc;
 
 #define FGT_PREC_FP32 0

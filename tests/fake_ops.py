@@ -86,12 +86,13 @@ def _dense_weight(pc):
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
            epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None,
-           out_split=None, out_s=None, out_il=False, out_h=None, ps=None, ky_skip_n0=0, aux_per_image=False, n_alg=0):
-    """ps = (r, c, g0, Hf, Wf): the sub-pixel output of fgt_conv_desc.ps_r (fold as a convolution); ky_skip_n0 / n_alg change no value."""
+           out_split=None, out_s=None, out_il=False, out_h=None, ps=None, ky_skip_n0=0, aux_per_image=False, n_alg=0, bias_map=None):
+    """ps = (r, c, g0, Hf, Wf): the sub-pixel output of fgt_conv_desc.ps_r (fold as a convolution); ky_skip_n0 / n_alg change no value;
+    bias_map replaces pc.bias by an [N, Ho, Wo, Cout] map (fgt_conv_desc.ld_bias)."""
     if out_split:
         assert not out_nchw
         y = conv2d(x, pc, x1, stride, pad, dil, upsample, pad_mode, in_relu, act, slope, epi, aux1, aux2, act2, out_scale, out,
-                   ps=ps, aux_per_image=aux_per_image)
+                   ps=ps, aux_per_image=aux_per_image, bias_map=bias_map)
         if out_s is not None:                      # a preallocated Split (possibly a channel slice of a wider buffer)
             out_s.put(y.reshape(out_s.x.shape))
             sp = out_s
@@ -128,7 +129,9 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     y = F.conv2d(inp, f16_round(wd) if (h16 and pc.Cout // G > 4) else wd, None, stride, (ph, pw), dil, G)
     if pc.scale is not None:
         y = y * pc.scale.view(1, -1, 1, 1)
-    if pc.bias is not None:
+    if bias_map is not None:
+        y = y + bias_map.reshape(y.shape[0], y.shape[2], y.shape[3], y.shape[1]).permute(0, 3, 1, 2)
+    elif pc.bias is not None:
         y = y + pc.bias.view(1, -1, 1, 1)
     Nn, Co, Ho, Wo = y.shape
     y = y.permute(0, 2, 3, 1)

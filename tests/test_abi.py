@@ -29,9 +29,9 @@ def test_library_exports_every_symbol():
 
 
 def test_struct_sizes_match_header():
-    # 44 ints/floats + 3 long long + the 8 ints of ABI 7 in fgt_conv_desc (44 * 4 = 176: no padding before the 8-byte fields; 232 bytes: none behind
+    # 44 ints/floats + 3 long long + the 10 ints of ABI 7 in fgt_conv_desc (44 * 4 = 176: no padding before the 8-byte fields; 240 bytes: none behind
     # them), 21 ints in fgt_attn_desc
-    assert ctypes.sizeof(_lib.ConvDesc) == 44 * 4 + 3 * 8 + 8 * 4
+    assert ctypes.sizeof(_lib.ConvDesc) == 44 * 4 + 3 * 8 + 10 * 4
     assert ctypes.sizeof(_lib.AttnDesc) == 22 * 4 + 8 + 2 * 4 + 5 * 8 + 2 * 4          # ... in_split, tq | ps* | compact, pad_row
 
 

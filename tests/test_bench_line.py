@@ -93,3 +93,23 @@ def test_oversized_non_droppable_blocks_fall_back_to_the_contract_keys():
     for k in CONTRACT:
         assert k in line, k
     assert "dropped" in line
+
+
+def test_graphs_policy_selects_replay_for_sharded_runs_and_launch_bound_hosts():
+    """at N > 1 a rank's share of the step (13-20 ms of kernels) is shorter than the time a slow host needs to enqueue its ~600
+    launches: bench.py --gpus N must replay hipGraphs by default; at N = 1 only when the probe step says the host is the bound."""
+    g = bench.graphs_enabled
+    assert g("auto", 8) and g("auto", 2) and g("auto", 2, 0.001, 1.0)
+    assert not g("auto", 1) and not g("auto", 1, 0.009, 0.100)            # the builder's boxes: 9 of 100 ms
+    assert g("auto", 1, 0.067, 0.102)                                      # the driver's round-4 box: 67 of 102 ms
+    assert g("on", 1) and not g("off", 8)
+
+
+def test_compact_line_carries_the_exchange_modes_and_launch_probe():
+    full = _canned()
+    full["strong_scaling_modes"] = {"allgather": {"value": 3000.0, "ms_per_step": 26.6, "host_enqueue_ms_per_step": 4.0, "output_checksum": 1.0},
+                                    "a2a": {"error": "a2a: RuntimeError: " + "x" * 250}}
+    full["host_launch_us_probe"] = 14.2
+    line = bench.compact_line(full)
+    assert line["strong_scaling_modes"]["allgather"]["value"] == 3000.0 and line["host_launch_us_probe"] == 14.2
+    assert len(json.dumps(line)) < bench.LINE_LIMIT

@@ -9,10 +9,13 @@ from fgt_amd import build as B
 
 
 def _usage(src):
-    cmd = [B._hipcc()] + B.FLAGS + ["-c", os.path.join(B.CSRC, src), "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    txt = r.stdout + r.stderr
+    # the report build() recorded when it compiled this source (same flags); compiled here only when the object is missing or stale
+    txt = B.usage_report(src)
+    if txt is None:
+        cmd = [B._hipcc()] + B.FLAGS + ["-c", os.path.join(B.CSRC, src), "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        txt = r.stdout + r.stderr
     names = re.findall(r"Function Name: (\S+)", txt)
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", txt)]
     # (round 2 exempted the 8-phase 256x256 tiles here: hipcc declined to unroll the epilogue's row-block loop with 8 accumulator tiles per

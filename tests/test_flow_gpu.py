@@ -60,6 +60,29 @@ def test_raft_matches_reference_golden(dev):
     assert r1 < 1e-3 and r2 < 1e-3           # 6 GRU iterations amplify fp32 round-off; flows are O(100) px with these weights
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_raft_context_term_hoisted_out_of_the_loop_is_exact(prec, dev, monkeypatch):
+    """RAFT/update.py:45-58: hx = [h | inp | motion] and `inp` never changes over the refinement loop (raft.py:112-115): the GRU convs are split
+    into a per-iteration part over [h | motion] and a context part over inp (+ bias) evaluated once per pair and added as a bias map.  Exact in
+    real arithmetic (a sum split in two); in fp32 the two forms differ by summation order only — both are held to the reference golden, and to
+    each other well inside it."""
+    from fgt_amd import ops
+    monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", prec)
+    g = load_golden("raft_128x160_it6.npz")
+    outs = {}
+    for hoist in (True, False):
+        m = raft_model.RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).eval()
+        m.load_state_dict(_sd("raft_state_keys.json"), strict=True)
+        m = m.to(dev)
+        m.hoist_context = hoist
+        outs[hoist] = m(g["image1"].to(dev), g["image2"].to(dev), iters=6, test_mode=True)
+        assert report(f"raft flow_up hoist={hoist} {prec}", outs[hoist][1], g["flow_up"])[1] < 1e-3
+    scale = g["flow_up"].abs().max().item()
+    d = (outs[True][1] - outs[False][1]).abs().max().item()
+    print(f"[parity] RAFT {prec}: context term hoisted vs in the loop: max |diff| {d:.3e} px (flows up to {scale:.1f} px)")
+    assert d < 3e-4 * scale
+
+
 def test_raft_240x432_two_iterations_matches_oracle(dev):
     sd = _sd("raft_state_keys.json")
     m = raft_model.RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).eval()

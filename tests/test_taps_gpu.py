@@ -179,3 +179,30 @@ def test_taps_routing_is_geometry_only(dev):
     assert torch.equal(ops.conv2d(ops.split(x40), pc40, pad=1, precision="bf16x3"), ops.conv2d(x40, pc40, pad=1, precision="bf16x3", tile="128x128"))
     # an explicit tile of another family on an eligible layer selects that family (A/B measurements): equal to the fp32-input kernel
     assert torch.equal(ops.conv2d(x, pc, pad=1, precision="bf16x3", tile="128x128x8ea"), ops.conv2d(xf, pc, pad=1, precision="bf16x3", tile="128x128"))
+
+
+def test_bias_map_in_front_of_the_activation(dev):
+    """fgt_conv_desc.ld_bias (ABI 7): the bias as an [M, Cout] map — RAFT's SepConvGRU convs take the convolution of the iteration-invariant
+    context features this way (RAFT/update.py:45-58).  Every epilogue flavour (none / mul / GRU), fp32 + split outputs, the horizontal pass and the
+    vertical one (tile rows in (n, x, y) order: the map is read at the mapped-back pixel), the register-staged fp32 kernel, the general epilogue."""
+    from fgt_amd import ops
+    B, H, W = 2, 17, 27
+    rows = B * H * W
+    net, xb = _rand(B, H, W, 128, seed=1).to(dev), _rand(B, H, W, 128, seed=2).to(dev)
+    z, hprev = torch.sigmoid(_rand(rows, 128, seed=3)).to(dev), _rand(rows, 128, seed=4).to(dev)
+    bmap = _rand(B, H, W, 128, seed=8).to(dev)
+    ns, xs = ops.split(net), ops.split(xb)
+    for ksz, pad in (((1, 5), (0, 2)), ((5, 1), (2, 0))):
+        pc = ops.PackedConv(_rand(128, 256, *ksz, seed=5, scale=0.03).to(dev), None)
+        lin = ops.conv2d(ns, pc, x1=xs, pad=pad, precision="bf16x3").view(rows, 128) + bmap.view(rows, 128)      # the pre-activation value
+        want = {"none": torch.sigmoid(lin), "mul": torch.sigmoid(lin) * hprev, "gru": (1 - z) * hprev + z * torch.tanh(lin)}
+        for epi, kw in (("gru", dict(act="tanh", epi="gru", aux1=z, aux2=hprev)), ("mul", dict(act="sigmoid", epi="mul", aux1=hprev)), ("none", dict(act="sigmoid"))):
+            o32, osp = ops.conv2d(ns, pc, x1=xs, pad=pad, precision="bf16x3", bias_map=bmap, out_split="both", **kw)
+            assert (o32.view(rows, 128) - want[epi]).abs().max().item() <= 2e-6, (ksz, epi)
+            assert torch.equal(osp.data, ops.split(o32).data)
+            for t in ("128x128", "128x64t", "128x128x8t"):
+                assert torch.equal(ops.conv2d(ns, pc, x1=xs, pad=pad, precision="bf16x3", bias_map=bmap, tile=t, **kw), o32) or t == "128x128", (ksz, epi, t)
+            f32 = ops.conv2d(net, pc, x1=xb, pad=pad, precision="fp32", bias_map=bmap, **kw)                         # register-staged exact kernel
+            assert (f32.view(rows, 128) - want[epi]).abs().max().item() <= 2e-5, (ksz, epi)
+            nchw = ops.conv2d(ns, pc, x1=xs, pad=pad, precision="bf16x3", bias_map=bmap, out_nchw=True, tile="128x64t", **kw)      # general epilogue
+            assert (nchw.permute(0, 2, 3, 1) - o32).abs().max().item() <= 1e-6, (ksz, epi)

@@ -49,6 +49,14 @@ elif has pmc; then
     echo "pmc $c exit $?"
   done
   python tools/pmc_traffic.py gpurun_out/pmcb_FETCH_SIZE gpurun_out/pmcb_WRITE_SIZE bf16x3 gpurun_out/kernel_traffic.json
+  echo "== PMC HBM traffic of the flow stages' bandwidth kernels (warp, correlation lookup) at the bench's shapes: tools/hbm_micro.py"
+  timeout 300 python tools/hbm_micro.py gpurun_out/hbm_micro_alg.json > gpurun_out/hbm_micro.log 2>&1; echo "hbm_micro exit $?"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmcm_$c" -o pmc -- python "$R/tools/hbm_micro.py" /tmp/hbm_micro_alg_$c.json > "$R/gpurun_out/pmcm_$c.log" 2>&1)
+    echo "pmc micro $c exit $?"
+  done
+  python tools/pmc_traffic.py gpurun_out/pmcm_FETCH_SIZE gpurun_out/pmcm_WRITE_SIZE bf16x3 gpurun_out/kernel_traffic.json \
+    "tools/hbm_micro.py (3 x the clip's warps at 432x240, RAFT 8 pairs at 864x480 x 20 iterations)" --merge warp,corr_lookup --alg gpurun_out/hbm_micro_alg.json
 fi
 if has pmc16; then
   echo "== PMC HBM traffic of the MFMA kernels, f16 mode (needs gpurun_out/tuning.json from the bench stage of this visit)"
