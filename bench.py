@@ -211,7 +211,7 @@ def _contract_line(full):
 
 def _optional_blocks(full, line):
     """roofline / rooflines / cpu_baseline / parity / fp32_exact / c4 / sharded blocks of the compact line (may raise on an unexpected record)."""
-    for k in ("effective_tflops", "host_enqueue_ms_per_step", "output_checksum", "output_sane", "strong_error"):
+    for k in ("effective_tflops", "host_enqueue_ms_per_step", "host_ms_per_step_in_timed_region_incl_queue_backpressure", "output_checksum", "output_sane", "strong_error"):
         if k in full:
             line[k] = full[k]
     r = full.get("roofline")
@@ -470,17 +470,19 @@ def main():
         for _ in range(args.warmup):
             runner.run()
         barrier()
-        if args.graphs == "auto" and world == 1 and not runner.use_graphs and runner.cache_features:
-            # probe step: how long does the host need to enqueue one step, next to how long the step takes?
-            t0 = time.perf_counter()
-            runner.run()
-            h = time.perf_counter() - t0
-            torch.cuda.synchronize()
-            runner.graph_probe = {"host_enqueue_ms": round(1e3 * h, 3), "step_ms": round(1e3 * (time.perf_counter() - t0), 3)}
-            if graphs_enabled("auto", 1, h, time.perf_counter() - t0):
-                runner.use_graphs = True
-                runner.run()                      # capture pass (untimed)
-                barrier()
+        # probe step: the host's OWN cost of enqueueing one step — against an idle queue, no event records — next to the step's wall time.
+        # (The timed region below enqueues K steps back to back: once the HIP queue holds its fill of launches the host BLOCKS in the launch
+        # calls until the GPU drains it, so host time per step there grows with K — 9 ms at K = 5, 31 ms at K = 10, 67 ms at K = 20 on the same
+        # kind of box (BENCH_r04) — and says nothing about how close the step is to launch-bound.  This probe does.)
+        t0 = time.perf_counter()
+        runner.run()
+        h = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        runner.graph_probe = {"host_enqueue_ms": round(1e3 * h, 3), "step_ms": round(1e3 * (time.perf_counter() - t0), 3), "graphs": bool(runner.use_graphs)}
+        if args.graphs == "auto" and world == 1 and not runner.use_graphs and runner.cache_features and graphs_enabled("auto", 1, h, time.perf_counter() - t0):
+            runner.use_graphs = True
+            runner.run()                      # capture pass (untimed)
+            barrier()
         if prof:
             ops.prof_collect("all")
             ops.prof_enable(True, kinds=list(KERNELS))      # the timed steps carry event pairs on the MFMA launches only (~250 per step)
@@ -603,7 +605,10 @@ def main():
                                     f"reference), windows cost-balanced over {world} ranks with equal lengths co-located, uint8 all-gather of window outputs"),
                        "conv_precision": prec, "per_frame_feature_cache": bool(runner.cache_features), "hip_graphs": bool(runner.use_graphs),
                        "graphs_mode": args.graphs, "window_batch": runner.window_batch},
-            "host_enqueue_ms_per_step": round(1e3 * res["host_dt"] / args.steps, 3),
+            # the host's own cost of enqueueing ONE step against an idle queue (probe step, see timed()); the K-step figure beside it includes the
+            # time the host spends blocked on the full launch queue (back-pressure of a GPU-bound step), which grows with K
+            "host_enqueue_ms_per_step": (getattr(runner, "graph_probe", None) or {}).get("host_enqueue_ms"),
+            "host_ms_per_step_in_timed_region_incl_queue_backpressure": round(1e3 * res["host_dt"] / args.steps, 3),
             "host_launch_us_probe": host_launch_us,
         }
         if getattr(runner, "graph_probe", None):
@@ -668,7 +673,8 @@ def main():
                 dt2, host2, comp2, kinds2 = timed(r2, prec, prof=not args.no_prof)
                 res2 = dict(dt=dt2, host_dt=host2, comp=comp2, kinds=kinds2, runner=r2, clip=clip2, exchange=mode)
                 strong_modes[mode] = {"value": round(args.frames * args.steps / dt2, 3), "ms_per_step": round(1e3 * dt2 / args.steps, 3),
-                                      "host_enqueue_ms_per_step": round(1e3 * host2 / args.steps, 3), "output_checksum": round(float(comp2.double().mean()), 6)}
+                                      "host_enqueue_ms_per_step": (getattr(r2, "graph_probe", None) or {}).get("host_enqueue_ms"), "hip_graphs": bool(r2.use_graphs),
+                                      "output_checksum": round(float(comp2.double().mean()), 6)}
                 if strong_res is None or dt2 < strong_res["dt"]:
                     strong_res = res2
             except Exception as e:      # the weak number (or the other mode) stands on its own; report instead of losing the line
