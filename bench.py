@@ -636,7 +636,7 @@ def main():
     n_sched = None
     out = None
     weak_res = strong_res = None
-    host_launch_us = launch_probe()
+    host_launch_us = None if args.no_prof else launch_probe()        # (--no-prof: the rocprofv3 --pmc passes: no probe launches in their traces)
 
     # ---------------------------------------------------------------- N = 1 (and the weak, clip-per-rank variant at N > 1)
     runner, clip = make_runner(False, 1234 + (rank if world > 1 else 0))

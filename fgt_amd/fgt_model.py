@@ -27,6 +27,8 @@ SPLIT_ATTENTION = os.environ.get("FGT_SPLIT_ATTN", "1") != "0"
 # token grid with a sub-pixel epilogue (fgt_conv_desc.ps_r) on the tap-reusing kernel — no [tokens, 49*c] patch matrix, no fold pass.
 # FGT_FOLD_CONV=0: Linear + fgt_fold (the fp32 / f16 modes' path), kept for A/B measurements.
 FOLD_CONV = os.environ.get("FGT_FOLD_CONV", "1") != "0"
+# the encoder's 8-group layer packed as 4 groups with block-diagonal weights (FGT._pack_encoder_layer); 0: as the reference groups it (A/B)
+ENC_MERGE_GROUPS = os.environ.get("FGT_ENC_MERGE_GROUPS", "1") != "0"
 
 
 def fold_conv_supported(k, s, p):
@@ -319,6 +321,30 @@ class FGT(nn.Module):
         self._zero_row(dev, self.cfg["c"] + self.cfg["cf"])
         return self
 
+    def _pack_encoder_layer(self, i):
+        """Encoder conv i (model.py:32-51).  The 640 -> 256 layer has 8 groups of 32 + 48 = 80 input and 32 output channels: 32-wide output tiles and
+        a 48-channel second source that no 32-channel K-step fits (it ran at 92 TFLOP/s, a quarter of its neighbours).  ENC_MERGE_GROUPS (default)
+        packs it as 4 groups of 64 + 96 -> 64 with block-diagonal weights: twice the multiply-adds, all of them with a zero weight, on 64-wide
+        tiles whose K-steps are whole 32-channel chunks — so every layer of the encoder chain can hand its output over in the interleaved split
+        layout.  The products that are not zero are the same ones; credited work stays the reference's (k_alg)."""
+        cin, cout, _, g = EncoderParams.SPEC[i]
+        conv = self.frame_endoder.layers[2 * i]
+        w, b = conv.weight, conv.bias
+        if not (ENC_MERGE_GROUPS and g == 8 and cin is not None):
+            return PackedConv(w, b, groups=g)
+        c0 = EncoderParams.SPEC[3][1] // g                      # channels per group from the skip source x0 (the input of layer 4, model.py:58-59): 32
+        c1 = w.shape[1] - c0                                    # ... from the previous layer: 48
+        co = cout // g
+        w = w.detach()
+        wm = torch.zeros(cout, 2 * (c0 + c1), 3, 3, dtype=w.dtype, device=w.device)
+        for gg in range(g):
+            h, rows = gg % 2, slice(gg * co, (gg + 1) * co)
+            wm[rows, h * c0:(h + 1) * c0] = w[rows, :c0]
+            wm[rows, 2 * c0 + h * c1:2 * c0 + (h + 1) * c1] = w[rows, c0:]
+        pc = PackedConv(wm, b, groups=g // 2)
+        pc.k_alg = 9 * (c0 + c1)                                # the reference's K per output channel (the zero half is not work it does)
+        return pc
+
     def _pack_block(self, blk):
         """ConvBlockParams -> (feature PackedConv, gating PackedConv | None)"""
         f = PackedConv(blk.featureConv.weight, blk.featureConv.bias)
@@ -382,8 +408,7 @@ class FGT(nn.Module):
 
     def _pack(self):
         P = {}
-        P["enc"] = [PackedConv(self.frame_endoder.layers[2 * i].weight, self.frame_endoder.layers[2 * i].bias, groups=g)
-                    for i, (_, _, _, g) in enumerate(EncoderParams.SPEC)]
+        P["enc"] = [self._pack_encoder_layer(i) for i in range(len(EncoderParams.SPEC))]
         P["fenc"] = [self._pack_block(self.flow_encoder[i]) for i in range(1, 5)]
         P["p2v"] = PackedConv(self.patch2vec.weight, self.patch2vec.bias)
         P["fp2v"] = PackedConv(self.f_patch2vec.weight, self.f_patch2vec.bias)
@@ -575,7 +600,7 @@ class FGT(nn.Module):
             # split outputs: interleaved where every consumer is a single-source conv (layers 0-2 and the last one, which feeds patch2vec);
             # layers 3-7 feed the two-source grouped convs, whose 640 -> 256 g8 member has 48 channels per group from the second source (not
             # a multiple of 32) and both sources of a conv share one layout: planes there
-            il = ops.split_il(E[i].Cout) and (i <= 2 or i == 8)
+            il = ops.split_il(E[i].Cout) and (i <= 2 or i == 8 or ENC_MERGE_GROUPS)
             if i <= 4:
                 e = ops.conv2d(e, E[i], stride=strides[i], pad=1, act="lrelu", out_split=osp, out=dst, out_il=il)
             else:
