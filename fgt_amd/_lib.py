@@ -37,7 +37,7 @@ class ConvDesc(C.Structure):
                [("out_scale", C.c_float)] + \
                [(n, C.c_int) for n in ("Kpad", "Npad", "tile", "precision", "in_split", "out_split", "ldo_s", "ooff_s", "w_il", "k_alg")] + \
                [(n, C.c_longlong) for n in ("ps0", "ps1", "pso")] + \
-               [(n, C.c_int) for n in ("ps_r", "ps_c", "ps_g0", "ps_H", "ps_W", "ky_skip_n0", "aux_per_image", "n_alg", "ld_bias", "reserved0")]      # ABI 7
+               [(n, C.c_int) for n in ("ps_r", "ps_c", "ps_g0", "ps_H", "ps_W", "ky_skip_n0", "aux_per_image", "n_alg", "ld_bias", "tile_order")]      # ABI 7
 
 
 class AttnDesc(C.Structure):

@@ -407,7 +407,7 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
         FGT_REQUIRE(!d.out_split || d.pso != 32 || d.ps_c % 32 == 0, "fgt_conv2d: interleaved sub-pixel out_s needs ps_c %% 32 == 0");
     }
     FGT_REQUIRE(!(d.ps_r || d.aux_per_image || d.epi >= FGT_EPI_AFFINE) || p.Cout_g > 4, "fgt_conv2d: the Cout <= 4 kernels have no sub-pixel / per-image-table epilogue");
-    FGT_REQUIRE(d.ld_bias >= 0 && d.reserved0 == 0 && (d.ld_bias == 0 || (cbias != nullptr && p.Cout_g > 4 && d.ld_bias % 4 == 0 && d.ld_bias >= d.Cout && !d.ps_r && d.in_split != 3)),
+    FGT_REQUIRE(d.ld_bias >= 0 && (d.tile_order == 0 || d.tile_order == 1) && (d.ld_bias == 0 || (cbias != nullptr && p.Cout_g > 4 && d.ld_bias % 4 == 0 && d.ld_bias >= d.Cout && !d.ps_r && d.in_split != 3)),
                 "fgt_conv2d: a bias map (ld_bias > 0) needs cbias, Cout/groups > 4, ld_bias %% 4 == 0, ld_bias >= Cout, no sub-pixel output, no fp16 inputs");
     FGT_REQUIRE(d.ky_skip_n0 == 0 || (d.groups == 1 && d.kh >= 2 && d.upsample == 0), "fgt_conv2d: ky_skip_n0 needs groups = 1, kh >= 2, no upsampling");
     const long M = (long)d.N * Ho * Wo;

@@ -31,8 +31,13 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) { f
 __device__ __forceinline__ bool conv_tile_index(const ConvP& p, int& m_idx, int& n_idx) {
     if (p.xcd_swizzle) {
         const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-        n_idx = i % p.ntiles;
-        m_idx = xcd * p.mchunk + i / p.ntiles;
+        if (p.d.tile_order == 1) {      // N-major inside the XCD's range of M tiles: co-resident workgroups share one N tile's weights in the L2
+            n_idx = i / p.mchunk;
+            m_idx = xcd * p.mchunk + i % p.mchunk;
+        } else {
+            n_idx = i % p.ntiles;
+            m_idx = xcd * p.mchunk + i / p.ntiles;
+        }
         return m_idx < p.mtiles;
     }
     m_idx = blockIdx.x % p.mtiles;

@@ -29,6 +29,8 @@ SPLIT_ATTENTION = os.environ.get("FGT_SPLIT_ATTN", "1") != "0"
 FOLD_CONV = os.environ.get("FGT_FOLD_CONV", "1") != "0"
 # the encoder's 8-group layer packed as 4 groups with block-diagonal weights (FGT._pack_encoder_layer); 0: as the reference groups it (A/B)
 ENC_MERGE_GROUPS = os.environ.get("FGT_ENC_MERGE_GROUPS", "1") != "0"
+# tile order of the fold convolutions (fgt_conv_desc.tile_order): 1 = N-major inside an XCD (their 7 / 21 MB weight matrices do not fit the L2)
+FOLD_TILE_ORDER = int(os.environ.get("FGT_FOLD_TILE_ORDER", "1"))
 
 
 def fold_conv_supported(k, s, p):
@@ -459,7 +461,7 @@ class FGT(nn.Module):
             g0 = fold_conv_layout(P["cc"], s)[0]
             off, scale = self._fold_tables(P, th, tw, x_res.device, True)
             F = ops.conv2d(y.view(bt, th, tw, -1), P["fc"], stride=1, pad=1, act="relu", epi="affine", aux1=off, aux2=scale, aux_per_image=True,
-                           ps=(s, P["cc"], g0, Hf, Wf), ky_skip_n0=g0, n_alg=k * k * P["cc"], out_split="only", out_il=ops.split_il(P["cc"]))
+                           ps=(s, P["cc"], g0, Hf, Wf), ky_skip_n0=g0, n_alg=k * k * P["cc"], out_split="only", out_il=ops.split_il(P["cc"]), tile_order=FOLD_TILE_ORDER)
             out = torch.empty_like(x_res)
             ops.conv2d(F, P["conv2"], stride=s, pad=p, epi="add", aux1=x_res, out=out.view(bt, th, tw, -1))
             return out
@@ -488,7 +490,8 @@ class FGT(nn.Module):
         if padded:
             s = ops.pad_tokens(s, bt, th, tw, nh, nw)
         # bf16x3 mode: the QKV GEMM hands q, k, v over pre-split; the attention streams K / V tiles by LDS-DMA (csrc/attention_split.hip)
-        qkv = ops.linear(s, P["qkv"], out_split="only" if (sc and SPLIT_ATTENTION) else None)
+        # (tile_order = 1: N-major — the 12 N tiles' 3.1 MB of weights: co-resident workgroups share one N tile's rows in the L2; -3...5 % on this GEMM)
+        qkv = ops.linear(s, P["qkv"], out_split="only" if (sc and SPLIT_ATTENTION) else None, tile_order=1)
         a = ops.attention_temporal(qkv, b, t, nh, nw, cfg["heads"], G, c, out_split=sc and not padded, tq=tq)
         if tq is not None and tq < t:
             n = th * tw
@@ -674,7 +677,7 @@ class FGT(nn.Module):
             off, _ = self._fold_tables(VP, th, tw, x.device, False)
             xs = ops.split(x, interleave=ops.split_il(x.shape[1]))
             feat = ops.conv2d(xs.view(bt, th, tw, -1), VP["fc"], stride=1, pad=1, epi="ps_add2", aux1=off, aux2=enc, aux_per_image=True,
-                              ps=(s, VP["cc"], g0, Hf, Wf), ky_skip_n0=g0, n_alg=k * k * VP["cc"], out_split="only", out_il=ops.split_il(VP["cc"]))
+                              ps=(s, VP["cc"], g0, Hf, Wf), ky_skip_n0=g0, n_alg=k * k * VP["cc"], out_split="only", out_il=ops.split_il(VP["cc"]), tile_order=FOLD_TILE_ORDER)
         else:
             if self._f16():
                 # the token stream is fp32; rounding it once here (one pass over [rows, 512]) lets the widest GEMM of the path (512 -> 6272) run

@@ -36,6 +36,7 @@ TILE_CANDIDATES = ("128x128", "64x64", "128x64", "256x128", "128x32", "128x128x8
 # Layers that fgt_conv2d routes to the tap-reusing kernel (csrc/conv_taps.hip; decided by geometry: fgt_conv_taps_route) are tuned among ITS
 # tiles only — they are bit-identical to each other, so results never depend on tuning.
 TAPS_CANDIDATES = ("128x128x8t", "128x128t", "128x64t", "128x64x8t", "64x64t", "128x128it", "256x128it", "256x256it")     # (...it: csrc/conv_taps_il.hip, interleaved requests; declines k x 1 / upsampling layers)
+_FORCE_TILE_ORDER = int(os.environ["FGT_CONV_TILE_ORDER"]) if os.environ.get("FGT_CONV_TILE_ORDER") else None      # A/B: fgt_conv_desc.tile_order for every layer
 _tile_cache = {}
 _tile_validated = set()      # keys whose cached tile has been checked against the geometry's kernel family (conv2d)
 
@@ -306,7 +307,7 @@ def prepack_weights(pc, mode=None):
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
            epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None,
-           out_split=None, out_s=None, out_il=False, out_h=None, ps=None, ky_skip_n0=0, aux_per_image=False, n_alg=0, bias_map=None):
+           out_split=None, out_s=None, out_il=False, out_h=None, ps=None, ky_skip_n0=0, aux_per_image=False, n_alg=0, bias_map=None, tile_order=0):
     """fgt_conv2d.  x (and optional x1) are channels-last maps (fp32 tensors, or `Split`s for the LDS-DMA bf16x3 path);
     returns/outputs a channels-last map (or NCHW).  out_split: None -> fp32 result; "only" -> a Split; "both" -> (fp32, Split).
     ps = (r, c, g0, Hf, Wf): sub-pixel output (fold as a convolution, fgt_conv_desc.ps_r): the result is the [N, Hf, Wf, c] map;
@@ -361,6 +362,7 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     if ps is not None:
         d.ps_r, d.ps_c, d.ps_g0, d.ps_H, d.ps_W = (int(v) for v in ps)
     d.ky_skip_n0, d.aux_per_image, d.n_alg = int(ky_skip_n0), int(bool(aux_per_image)), int(n_alg)
+    d.tile_order = int(tile_order) if _FORCE_TILE_ORDER is None else _FORCE_TILE_ORDER
     bias = pc.bias
     if bias_map is not None:
         b4, bN, bH, bW, bC, d.ld_bias = _as_map(bias_map)
@@ -403,7 +405,7 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     if d.tile == 0 and AUTOTUNE and pc.Cout // pc.groups > 4:
         key = (N, H, W, C0, C1, pc.Cout, pc.groups, pc.kh, pc.kw, sh, sw, ph, pw, dh, dw, d.upsample, d.epi, d.out_nchw, d.precision,
                d.in_split, d.out_split, d.w_il, int(bool(osp) and out_s.il) + 2 * int(bool(osp) and out_s.h), d.pad_mode, d.in_relu,
-               d.ps_r, d.ps_c, d.ps_H, d.ps_W, d.ky_skip_n0, int(d.ld_bias > 0))
+               d.ps_r, d.ps_c, d.ps_H, d.ps_W, d.ky_skip_n0, int(d.ld_bias > 0), d.tile_order)
         best = _tile_cache.get(key)
         if best is not None and key not in _tile_validated:
             # A cached / loaded tile must belong to the kernel family the GEOMETRY routes this layer to (taps-routed layers: codes 200-299,

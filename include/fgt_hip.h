@@ -140,7 +140,11 @@ typedef struct fgt_conv_desc {
     int ld_bias;            /* 0: `cbias` is a [Cout] vector (or NULL) | > 0: `cbias` is an [M, Cout] MAP with this row stride, added in front
                              * of the activation like the vector (RAFT's SepConvGRU: the convolution of the iteration-invariant context
                              * features `inp`, RAFT/update.py:45-58, raft.py:112-115, computed once per pair instead of once per iteration) */
-    int reserved0;          /* 0 */
+    int tile_order;         /* 0: every XCD walks its M tiles with the N tiles of one M tile adjacent in time (they share the im2col rows in that
+                             * XCD's L2) | 1: N-major — an XCD finishes all its M tiles for one N tile before the next: the workgroups resident together
+                             * read the SAME weight rows (one N tile's K x 128 weights stay in the 4 MB L2) at the price of streaming the input once
+                             * per N tile.  For layers whose whole weight matrix does not fit the L2 (the fold convolutions: 7 and 21 MB).  Results
+                             * are identical (the order of tiles, not of any sum) */
 } fgt_conv_desc;
 
 #define FGT_PREC_FP32 0

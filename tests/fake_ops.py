@@ -86,7 +86,7 @@ def _dense_weight(pc):
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
            epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None,
-           out_split=None, out_s=None, out_il=False, out_h=None, ps=None, ky_skip_n0=0, aux_per_image=False, n_alg=0, bias_map=None):
+           out_split=None, out_s=None, out_il=False, out_h=None, ps=None, ky_skip_n0=0, aux_per_image=False, n_alg=0, bias_map=None, tile_order=0):
     """ps = (r, c, g0, Hf, Wf): the sub-pixel output of fgt_conv_desc.ps_r (fold as a convolution); ky_skip_n0 / n_alg change no value;
     bias_map replaces pc.bias by an [N, Ho, Wo, Cout] map (fgt_conv_desc.ld_bias)."""
     if out_split:
