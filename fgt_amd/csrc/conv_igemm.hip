@@ -420,6 +420,7 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     p.xcd_swizzle = xcd_env;
     static const int nt_env = [] { const char* e = getenv("FGT_CONV_NT"); return e ? atoi(e) : 1; }();
     p.nt_store = nt_env;
+
     p.zero_page = fgt_zero_page();
     FGT_REQUIRE(p.zero_page != nullptr, "fgt_conv2d: could not allocate the zero page");
     p.x0 = x0; p.x1 = x1 ? x1 : x0; p.w = w_packed; p.cscale = cscale; p.cbias = cbias; p.aux1 = aux1; p.aux2 = aux2; p.out = out;

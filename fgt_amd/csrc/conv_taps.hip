@@ -12,14 +12,20 @@
 //
 // For a stride-1 convolution whose output map has the size of its input map, the A tile of tap (ky, kx) is the A tile of tap (ky, 0)
 // shifted by kx * dw PIXELS in the flattened (n, y, x) index: output pixel m reads input pixel m + (ky*dh - ph) * W + (kx*dw - pw)
-// whenever that pixel is in the same image row.  So this kernel walks K in the order (ky, chunk, kx) and loads, per (ky, chunk), BM + 16
+// whenever that pixel is in the same image row.  So this kernel walks K in the order (chunk, ky, kx) and loads, per (ky, chunk), BM + 16
 // consecutive input rows ONCE (9 pieces per plane instead of 8 per tap): for a 3x3 layer 18 + 3 * 16 = 66 LDS-DMA instructions per
 // (ky, chunk) instead of 96 (-31 %), for the 1x5 GRU convs of RAFT 18 + 80 instead of 160 (-39 %) — and the pieces that remain are mostly
 // WEIGHT rows (L2 hits), the im2col stream from the Infinity Cache / HBM shrinks by kw.  Tap kx reads its MFMA fragments from LDS rows
 // r + kx*dw; a pixel whose tap leaves the image row (x + kx*dw - pw outside [0, W)) reads the plane's zero row instead; rows whose input
 // row y + ky*dh - ph is outside the image were never fetched (the DMA read the zero page).
 //
-// Numerics: the same products as conv_split.hip, accumulated in the order (ky, chunk, kx) instead of (ky, kx, chunk) — NOT bit-identical
+// K ORDER (round 5): the walk is (chunk, ky, kx) — the three ky taps of a 32-channel chunk in consecutive super-steps.  Their im2col rows are the
+// same cache lines one image row apart (another tile's ky = 0 rows, or this tile's own for narrow maps): walked (ky, chunk, kx), a line came back
+// nchunk super-steps later, long evicted from the XCD's 4 MB L2, and the DMA of two thirds of the A pieces paid the fabric's latency (300-600
+// cycles an instruction against 66-190 for an L2 hit: NOTEBOOK §11.3).  Measured -4...-8 % on the encoder / decoder 3x3 layers, same box
+// (profiles/r05_run9_*).  The weight image keeps its K-step order kstep(ky, c, kx) = (ky*KW + kx) * nchunk + c; only the iterators changed.
+//
+// Numerics: the same products as conv_split.hip, accumulated in the order (chunk, ky, kx) instead of (ky, kx, chunk) — NOT bit-identical
 // to the other kernels (fp32 accumulation order), identical in error (tests/test_taps_gpu.py: both within 2e-5 of fp64 on the same split
 // operands).  Which kernel a layer runs on is therefore decided by its GEOMETRY alone (fgt_conv_taps_eligible), never by the autotuner: an
 // eligible split-input layer always runs here (the autotuner picks among THIS kernel's tiles, which are bit-identical to each other), so
@@ -103,7 +109,8 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     const int nch0 = p.Cg0 / 32, nch1 = p.Cg1 / 32, nchunk = nch0 + nch1;
     // ABI 7 (desc.ky_skip_n0, normal mode): the weights of this tile's columns are all zero for ky = 0 — its K walk starts at ky = 1
     const int ky0 = (!tr && d.ky_skip_n0 > 0 && bn0 >= d.ky_skip_n0) ? 1 : 0;
-    const int nss = ((tr ? d.kw : d.kh) - ky0) * nchunk;
+    const int n_o = (tr ? d.kw : d.kh) - ky0;             // outer taps walked (the axis that is not reused)
+    const int nss = n_o * nchunk;
     const long cstride = il ? 128 : 64;                  // bytes from one 32-channel chunk of a pixel to the next
 
     // ---- im2col source iterator (wave-uniform): the super-step whose A rows are requested next.  Byte pointers to chunk (ky, c) of pixel 0:
@@ -117,18 +124,18 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     const char* a_hi = src_hi(0);
     const char* a_lo = a_hi + src_lo_off(0);
     int a_ld = d.ld0, a_left = nch0, a_src = 0;
-    int a_dy = ky0 * d_o - p_o, a_dyW = a_dy * So;        // outer tap shift: in outer coordinates / in pixels
-    auto a_advance = [&]() {
+    const int a_dy0 = ky0 * d_o - p_o;
+    int a_dy = a_dy0, a_dyW = a_dy * So;                  // outer tap shift: in outer coordinates / in pixels
+    int a_o = 0;                                          // outer tap of the super-step the A stream is in
+    auto a_advance = [&]() {                              // next outer tap of the same chunk; behind the last one: the next chunk (never wraps)
+        a_dy += d_o; a_dyW += d_o * So;
+        if (++a_o < n_o) return;
+        a_o = 0; a_dy = a_dy0; a_dyW = a_dy0 * So;
         a_hi += cstride; a_lo += cstride;
-        if (--a_left == 0) {
-            if (a_src == 0 && nch1 > 0) {
-                a_src = 1; a_left = nch1; a_ld = d.ld1;
-            } else {
-                a_src = 0; a_left = nch0; a_ld = d.ld0;
-                a_dy += d_o; a_dyW += d_o * So;
-            }
-            a_hi = src_hi(a_src);
-            a_lo = a_hi + src_lo_off(a_src);
+        if (--a_left == 0 && a_src == 0 && nch1 > 0) {
+            a_src = 1; a_left = nch1; a_ld = d.ld1;
+            a_hi = src_hi(1);
+            a_lo = a_hi + src_lo_off(1);
         }
     };
 
@@ -160,7 +167,8 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     };
 
     // ---- weights: interleaved rows [Kpad/32][hi 32 | lo 32] (128 bytes per K-step of 32 channels); running pointers, K-step order
-    // kstep(ky, c, kx) = (ky*KW + kx) * nchunk + c: + nchunk inside a super-step, 1 - (KW-1) * nchunk to the next chunk, + 1 to the next ky
+    // kstep(ky, c, kx) = (ky*KW + kx) * nchunk + c; walked (chunk, ky, kx): + nchunk to the next kx AND from a ky's last kx to the next ky, and
+    // 1 - (n_o*KW - 1) * nchunk from a chunk's last step to the first step of the next chunk
     const char* wp[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
@@ -169,12 +177,13 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
         wp[it] = reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + brow) * (2 * d.Kpad) + plane * 32 + kc * 8);
     }
     // (transposed: the reused taps are ky: + kw * nchunk per tap, and the step to the next kx is the step to the next chunk)
-    const long dkx = (long)nchunk * (tr ? d.kw : 1) * 128, dss = 128 - (KW - 1) * dkx, dky = tr ? dss : 128;
+    const long dkx = (long)nchunk * (tr ? d.kw : 1) * 128;
+    const long dchunk = 128 - ((long)n_o * KW - 1) * dkx;  // from the last step of a chunk (last outer tap, last reused tap) to the first step of the next chunk
     if (ky0) {
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) wp[it] += (long)KW * dkx;      // the K-steps of ky = 0
     }
-    int b_c = 0;                                          // chunk (within its ky) of the super-step the B stream is in
+    int b_c = 0;                                          // outer tap (within its chunk) of the super-step the B stream is in
     auto issue_B = [&](int bs) {
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
@@ -183,11 +192,8 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
         }
     };
     auto advance_B = [&](bool last_kx) {                  // behind the B tile of a step with kx = KW-1 (last_kx) or kx < KW-1
-        long dlt = dkx;
-        if (last_kx) {
-            dlt = dss;
-            if (++b_c == nchunk) { b_c = 0; dlt = dky; }
-        }
+        long dlt = dkx;                                   // the next reused tap — and the next outer tap of the same chunk — is one tap's K-steps further
+        if (last_kx && ++b_c == n_o) { b_c = 0; dlt = dchunk; }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) wp[it] += dlt;
     };

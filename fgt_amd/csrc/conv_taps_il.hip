@@ -21,7 +21,7 @@
 // Tiles: BM x BN on BM / 32 wavefronts of 64 x 64 (BN = 128) or 128 x 64 (BN = 256):
 //   128 x 128, 4 wavefronts, 68 KB of LDS: two workgroups per CU        ("128x128it")
 //   256 x 128, 8 wavefronts, 100 KB; 256 x 256, 8 wavefronts, 132 KB: one workgroup per CU  ("256x128it", "256x256it")
-// Step (kx tap of a (ky, 32-channel chunk) super-step) of every wavefront:
+// Step (kx tap of a (32-channel chunk, ky) super-step) of every wavefront:
 //   (before the barrier: the first A fragments — their A buffer was published at least a barrier ago) | barrier | 4 B reads | 24 (48) MFMAs with
 //   AT MOST ONE filler behind each — a ds_read_b128 of the next sub-step, or one block of the next step's fragment addresses — and ONE LDS-DMA
 //   request behind every fourth (the B(s+1) pieces first, then A pieces of the next (ky, chunk)) | wait for this step's B requests | barrier
@@ -36,7 +36,7 @@
 // stay on conv_taps.hip's tiles (fgt_conv_taps_il_launch declines them).  The request path is written for few live scalars: its first version
 // kept conv_taps.hip's generality and executed ~200 v_readlane reloads of spilled SGPRs per step.
 //
-// Numerics: the products and the accumulation order of conv_taps.hip ((ky, chunk, kx); per accumulator and k-half lo*hi, hi*lo, hi*hi):
+// Numerics: the products and the accumulation order of conv_taps.hip ((chunk, ky, kx) since round 5; per accumulator and k-half lo*hi, hi*lo, hi*hi):
 // BIT-IDENTICAL to its tiles (tests/test_taps_gpu.py), so the autotuner chooses among all of them (routing stays by geometry).
 // LDS: B stages [2][hi BN | lo BN] x 64-byte rows, A buffers [2][hi: BM + 16 rows + zero row | lo: ...].
 //
@@ -153,7 +153,8 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     // ABI 7 (desc.ky_skip_n0): the weights of this tile's columns are all zero for ky = 0 — its K walk starts at ky = 1 (fold as a convolution:
     // the sub-pixel rows ry >= 1 of a token cell receive nothing from the token row above)
     const int ky0 = (d.ky_skip_n0 > 0 && bn0 >= d.ky_skip_n0) ? 1 : 0;
-    const int nss = (d.kh - ky0) * nchunk;
+    const int n_o = d.kh - ky0;                          // ky taps walked
+    const int nss = n_o * nchunk;
     const int cstride = il ? 128 : 64;                   // bytes from one 32-channel chunk of a pixel to the next
 
     // ---- im2col source iterator (wave-uniform): the super-step whose A rows are requested next (conv_taps.hip, normal mode)
@@ -166,18 +167,18 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     const char* a_hi = src_hi(0);
     const char* a_lo = a_hi + src_lo_off(0);
     int a_ld2 = 2 * d.ld0, a_left = nch0, a_src = 0;      // (a_ld2: bytes from one pixel of the source to the next)
-    int a_dy = ky0 * d.dh - d.ph, a_dyW = a_dy * W;       // ky tap shift: in rows / in pixels
-    auto a_advance = [&]() {
+    const int a_dy0 = ky0 * d.dh - d.ph;
+    int a_dy = a_dy0, a_dyW = a_dy * W;                   // ky tap shift: in rows / in pixels
+    int a_o = 0;                                          // ky tap of the super-step the A stream is in
+    auto a_advance = [&]() {                              // next ky of the same chunk; behind the last one: the next chunk (never wraps)
+        a_dy += d.dh; a_dyW += d.dh * W;
+        if (++a_o < n_o) return;
+        a_o = 0; a_dy = a_dy0; a_dyW = a_dy0 * W;
         a_hi += cstride; a_lo += cstride;
-        if (--a_left == 0) {
-            if (a_src == 0 && nch1 > 0) {
-                a_src = 1; a_left = nch1; a_ld2 = 2 * d.ld1;
-            } else {
-                a_src = 0; a_left = nch0; a_ld2 = 2 * d.ld0;
-                a_dy += d.dh; a_dyW += d.dh * W;
-            }
-            a_hi = src_hi(a_src);
-            a_lo = a_hi + src_lo_off(a_src);
+        if (--a_left == 0 && a_src == 0 && nch1 > 0) {
+            a_src = 1; a_left = nch1; a_ld2 = 2 * d.ld1;
+            a_hi = src_hi(1);
+            a_lo = a_hi + src_lo_off(1);
         }
     };
 
@@ -230,7 +231,7 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
         return 1;
     };
 
-    // ---- weights: interleaved rows [Kpad/32][hi 32 | lo 32], K-step order as in conv_taps.hip: kstep(ky, c, kx) = (ky*KW + kx) * nchunk + c.
+    // ---- weights: interleaved rows [Kpad/32][hi 32 | lo 32], K-step order as in conv_taps.hip: kstep(ky, c, kx) = (ky*KW + kx) * nchunk + c, walked (chunk, ky, kx).
     // One per-lane 64-bit base + a wave-uniform byte offset per piece; the K position is a scalar running offset (32 bits: it stays inside a row).
     // A wavefront requests the 16-row groups BPP * wave .. BPP * wave + BPP - 1 of both planes.
     // WIDE: 8-row groups of full 128-byte lines; wavefront w requests the groups 2 BPP w .. 2 BPP w + 2 BPP - 1 (request r: parity r & 1, which
@@ -238,9 +239,10 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     const int kcB = WIDE ? ((lane & 7) ^ (lane >> 4)) * 16 : kc16;
     const char* const w_lane = reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + bn0 + lrow) * (2 * d.Kpad)) + kcB;
     const int w_row16 = (WIDE ? 32 : 64) * d.Kpad;        // bytes from one 16-row (WIDE: 8-row) group of the weight image to the next
-    const int dkx = nchunk * 128, dss = 128 - (KW - 1) * dkx;      // to the next kx of a (ky, chunk) / from its last kx to the next chunk; to the next ky: + 128
+    const int dkx = nchunk * 128;                         // to the next kx of a (chunk, ky) and from its last kx to the next ky of the chunk
+    const int dchunk = 128 - (n_o * KW - 1) * dkx;        // from the last step of a chunk to the first step of the next chunk
     int w_k = ky0 * KW * dkx;                             // byte offset of the K-step the B stream is at
-    int b_c = 0;                                          // chunk (within its ky) of the super-step the B stream is in
+    int b_c = 0;                                          // ky tap (within its chunk) of the super-step the B stream is in
     const int npad_rows = d.Npad - bn0;                   // weight rows of this tile that exist (the rest reads the zero page)
     auto issue_B = [&](auto RQ, int bs) __attribute__((always_inline)) {           // request r of 2 BPP: (plane, group) / WIDE: 8-row group
         constexpr int r = decltype(RQ)::value;
@@ -259,10 +261,7 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     };
     auto advance_B = [&](bool last_kx) {                  // behind the B tile of a step with kx = KW-1 (last_kx) or kx < KW-1
         int dlt = dkx;
-        if (last_kx) {
-            dlt = dss;
-            if (++b_c == nchunk) { b_c = 0; dlt = 128; }
-        }
+        if (last_kx && ++b_c == n_o) { b_c = 0; dlt = dchunk; }
         w_k += dlt;
     };
 

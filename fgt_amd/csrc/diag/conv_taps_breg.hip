@@ -83,18 +83,16 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_tapsr_kernel(const Con
     const char* a_hi = src_hi(0);
     const char* a_lo = a_hi + src_lo_off(0);
     int a_ld = d.ld0, a_left = nch0, a_src = 0;
-    int a_dy = -d.ph, a_dyW = -d.ph * W;
-    auto a_advance = [&]() {
+    int a_dy = -d.ph, a_dyW = -d.ph * W, a_o = 0;
+    auto a_advance = [&]() {                              // K walks (chunk, ky, kx) as in conv_taps.hip (round 5)
+        a_dy += d.dh; a_dyW += d.dh * W;
+        if (++a_o < d.kh) return;
+        a_o = 0; a_dy = -d.ph; a_dyW = -d.ph * W;
         a_hi += cstride; a_lo += cstride;
-        if (--a_left == 0) {
-            if (a_src == 0 && nch1 > 0) {
-                a_src = 1; a_left = nch1; a_ld = d.ld1;
-            } else {
-                a_src = 0; a_left = nch0; a_ld = d.ld0;
-                a_dy += d.dh; a_dyW += d.dh * W;
-            }
-            a_hi = src_hi(a_src);
-            a_lo = a_hi + src_lo_off(a_src);
+        if (--a_left == 0 && a_src == 0 && nch1 > 0) {
+            a_src = 1; a_left = nch1; a_ld = d.ld1;
+            a_hi = src_hi(1);
+            a_lo = a_hi + src_lo_off(1);
         }
     };
     const int lrow = lane >> 2;
@@ -123,7 +121,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_tapsr_kernel(const Con
     // TN * 4 KB of consecutive memory; K-step order as in conv_taps.hip: kstep(ky, c, kx) = (ky*KW + kx) * nchunk + c
     const long kbytes = (long)(d.Npad / 32) * 4096;      // bytes per K-step
     const char* wq = reinterpret_cast<const char*>(p.w) + (long)g * (d.Kpad / 32) * kbytes + (long)(bn0 / 32 + wn * TN) * 4096 + lane * 16;
-    const long dkx = (long)nchunk * kbytes, dss = (1 - (long)(KW - 1) * nchunk) * kbytes;
+    const long dkx = (long)nchunk * kbytes, dchunk = (1 - ((long)d.kh * KW - 1) * nchunk) * kbytes;
     int b_c = 0;
     auto load_B = [&](bf16x8 (&b)[TN][4]) {
 #pragma unroll
@@ -134,10 +132,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_tapsr_kernel(const Con
     };
     auto advance_B = [&](bool last_kx) {
         long dlt = dkx;
-        if (last_kx) {
-            dlt = dss;
-            if (++b_c == nchunk) { b_c = 0; dlt = kbytes; }
-        }
+        if (last_kx && ++b_c == d.kh) { b_c = 0; dlt = dchunk; }
         wq += dlt;
     };
 
