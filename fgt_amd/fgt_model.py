@@ -490,8 +490,9 @@ class FGT(nn.Module):
         if padded:
             s = ops.pad_tokens(s, bt, th, tw, nh, nw)
         # bf16x3 mode: the QKV GEMM hands q, k, v over pre-split; the attention streams K / V tiles by LDS-DMA (csrc/attention_split.hip)
-        # (tile_order = 1: N-major — the 12 N tiles' 3.1 MB of weights: co-resident workgroups share one N tile's rows in the L2; -3...5 % on this GEMM)
-        qkv = ops.linear(s, P["qkv"], out_split="only" if (sc and SPLIT_ATTENTION) else None, tile_order=1)
+        # (N-major tile order — fgt_conv_desc.tile_order — measured -3...5 % on this GEMM, 3.1 MB of weights, but it streams the 200 MB input once per
+        #  N tile from beyond the L2: 2.9 GB of counter traffic per launch against 0.8 GB algorithmic; not used here)
+        qkv = ops.linear(s, P["qkv"], out_split="only" if (sc and SPLIT_ATTENTION) else None)
         a = ops.attention_temporal(qkv, b, t, nh, nw, cfg["heads"], G, c, out_split=sc and not padded, tq=tq)
         if tq is not None and tq < t:
             n = th * tw

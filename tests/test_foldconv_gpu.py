@@ -88,6 +88,9 @@ def test_fold_conv_vs_reference_formulation(geom, il, dev):
                 assert torch.equal(outs[g0], first), f"{name}: tap tile {t} differs from {TAPS[0]}"
         auto = ops.conv2d(xs, pc, ky_skip_n0=g0, **kw)
         assert torch.equal(auto, first), "tile = auto: the tap-reusing kernel"
+        # N-major tile walk inside an XCD (fgt_conv_desc.tile_order = 1: what the model passes for these layers): the order of tiles, not of any sum
+        for t in ("128x128it", "128x64t", "128x128"):
+            assert torch.equal(ops.conv2d(xs, pc, tile=t, ky_skip_n0=g0, tile_order=1, **kw), ops.conv2d(xs, pc, tile=t, ky_skip_n0=g0, tile_order=0, **kw)), t
         # the formulation it replaces: Linear (tap-major columns) + fgt_fold on the same operands
         w1p = w.view(cc, k * k, cin).permute(1, 0, 2).reshape(cc * k * k, cin)
         b1p = b.view(cc, k * k).permute(1, 0).reshape(-1)
