@@ -46,6 +46,7 @@ GEOMS = [
     ("ffn_6x8_cut_map", 3, 6, 8, 16, 24, 64, 40),          # 64x96 input: 3*6 = 18 > 16 rows — the last token row's sub-pixels 1, 2 fall off the map
     ("ffn_4x7_cut_cols", 2, 4, 7, 12, 20, 96, 40),          # 48x80 input: 3*7 = 21 > 20 columns
     ("ffn_20x36_bench_grid", 2, 20, 36, 60, 108, 512, 40),  # the benchmark's token grid and channel counts
+    ("ffn_22x36_tool_default_height", 1, 22, 36, 64, 108, 128, 40),   # 256 x 432 input (the tool's default): 22 x 3 = 66 > 64 feature rows
     ("ffn_1x1_grid", 5, 1, 1, 3, 3, 32, 8),
     ("v2p_5x9_c128", 2, 5, 9, 15, 26, 64, 128),             # Vec2Patch: 128 channels per pixel (g0 = 384: no padding columns)
 ]
