@@ -18,6 +18,7 @@ EPI = {"none": 0, None: 0, "mul": 1, "add": 2, "gru": 3, "affine": 4, "ps_add2":
 PREC = {"fp32": 0, None: 0, "bf16x3": 1, "f16": 2}
 TILE = {"auto": 0, None: 0, "128x128": 1, "128x64": 2, "64x64": 3, "128x32": 4, "256x128": 5, "128x128x8": 6, "256x128x16": 7, "256x64x8": 8, "256x128x8s3": 10, "256x128x16s3": 11, "128x128x8s4": 12, "256x128x8pp": 13, "128x128x8pp": 14, "256x128x8il": 16, "256x256p8": 17, "256x128p8": 18, "128x128ea": 26, "128x64ea": 27, "64x64ea": 28, "128x128x8ea": 29, "256x128x16ea": 30, "256x64x8ea": 31, "128x128x8lw": 32, "128x128lw": 33, "128x64lw": 34, "128x128x8xy": 35,
         "256x128ea": 38,      # f16 kernel only
+        "c4": 40,             # csrc/conv_c4.hip: bf16x3, fp32 4-channel input, square 3 / 5 / 7 kernel
         # f16 kernel only, FGT_TILE_* + 100: the same tiles on the wide LDS image (128-byte rows, full-line LDS-DMA pieces)
         "128x128w": 101, "128x64w": 102, "64x64w": 103, "128x32w": 104, "256x128w": 105, "128x128x8w": 106, "256x128x16w": 107, "256x64x8w": 108,
         "128x128eaw": 126, "128x64eaw": 127, "64x64eaw": 128, "128x128x8eaw": 129, "256x128x16eaw": 130, "256x64x8eaw": 131, "256x128eaw": 138,

@@ -471,6 +471,10 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     else if (taps && tile >= FGT_TILE_TAPS_BREG) rc = fgt_conv_taps_breg_launch(tile - FGT_TILE_TAPS_BREG, p, s);
 #endif
     else if (taps) rc = fgt_conv_taps_launch(tile - FGT_TILE_TAPS, p, s);
+    else if (tile == FGT_TILE_C4) {
+        if (!fgt_conv_c4_eligible(p)) { fgt_set_error("fgt_conv2d: tile %d (4-channel-input kernel) on a layer it does not serve", tile); rc = FGT_EINVAL; }
+        else rc = fgt_conv_c4_launch(p, s);
+    }
     else if (d.in_split == 2 && tile >= FGT_TILE_WIDE) {
         if (d.w_il != 1 || d.Kpad != p.K) { fgt_set_error("fgt_conv2d: the wide bf16x3 tiles need interleaved weights (w_il = 1) and K %% 32 == 0"); rc = FGT_EINVAL; }
         else rc = fgt_conv_wide_launch(tile - FGT_TILE_WIDE, p, s);

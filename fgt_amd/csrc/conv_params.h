@@ -51,6 +51,11 @@ int fgt_conv_taps_il_launch(int bm, int bn, const ConvP& p, hipStream_t s);
 // diag/conv_taps_breg.hip (diagnostic builds only): the same with the weight fragments loaded straight into registers (w_il = 2, tile code - 300)
 int fgt_conv_taps_breg_launch(int tile, const ConvP& p, hipStream_t s);
 
+// conv_c4.hip: bf16x3 for the 4-channel-input layers (fp32 input gathered straight into MFMA fragments, weights resident in the LDS): tile code
+// FGT_TILE_C4, an autotuner candidate (bit-identical to the register-staged kernel's tiles)
+bool fgt_conv_c4_eligible(const ConvP& p);
+int fgt_conv_c4_launch(const ConvP& p, hipStream_t s);
+
 // conv_f16.hip: FGT_PREC_F16 — fp16 inputs (one plane) through LDS-DMA, one MFMA per product
 int fgt_conv_f16_launch(int tile, const ConvP& p, hipStream_t s);
 

@@ -28,6 +28,7 @@ DEFAULT_ATTN_PRECISION = os.environ.get("FGT_ATTN_PRECISION", "fp32")
 # the same layer fed fp32 tensors; same products, different summation order.)
 AUTOTUNE = os.environ.get("FGT_AUTOTUNE", "1") != "0"
 TILE_CANDIDATES = ("128x128", "64x64", "128x64", "256x128", "128x32", "128x128x8", "256x128x16", "256x64x8",
+                   "c4",    # 4-channel fp32 inputs only (csrc/conv_c4.hip; rejected, hence skipped, elsewhere): bit-identical to the tiles above
                    # split inputs only (rejected, hence skipped, for fp32 inputs): the same tiles with early stage release
                    "128x128ea", "64x64ea", "128x64ea", "128x128x8ea", "256x128x16ea", "256x64x8ea",
                    # fp16 kernel only (csrc/conv_f16.hip): one more early-release tile, and every tile on the wide LDS image

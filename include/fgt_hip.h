@@ -163,6 +163,8 @@ typedef struct fgt_conv_desc {
 /* Codes 10-20, 32-35 (planes layout): schedule variants that were measured and NOT adopted.  They are rejected by the product library and exist
  * in diagnostic builds only (csrc/diag/conv_split_variants.hip, `fgt_amd.build.build(variant="diag")`); 17 / 18 + 100 are product tiles of the
  * wide kernel (csrc/conv_wide.hip). */
+#define FGT_TILE_C4 40          /* csrc/conv_c4.hip: FGT_PREC_BF16X3 on an fp32 single-source input with C0 = 4 and a square 3 / 5 / 7 kernel (the first conv of the
+                                * frame / flow encoders, of LAFC, of RAFT's motion encoder): input gathered straight into MFMA fragments, 128 x 64 tile */
 #define FGT_TILE_256x128x8_S3 10  /* split inputs only: 256x128 on 8 wavefronts, 3-stage LDS-DMA ring, one workgroup per CU */
 #define FGT_TILE_256x128x16_S3 11 /* split inputs only: 256x128 on 16 wavefronts, 3-stage ring */
 #define FGT_TILE_128x128x8_S4 12  /* split inputs only: 128x128 on 8 wavefronts, 4-stage ring */
