@@ -118,8 +118,13 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     //      in front of it.  (9 requests per wavefront in one step overrun the CU's DMA queue for a while; a third schedule — spread as in 0,
     //      the pieces of tap KW-2 first in their step and waited for at its end — was measured 3 % slower than this one (run 38), the A
     //      requests behind the step's last MFMA instead of in its request slots 1-3 % slower (run 41).)
-    // Default: 0 on the 64-byte image (narrow pieces: more requests in a step cost more than the early reads buy), 1 on the wide image.
-    constexpr int ASCHED = FGT_IL_A_EARLY != 2 ? FGT_IL_A_EARLY : (WIDE ? 1 : 0);
+    // Default: 0 on the 64-byte image (narrow pieces: more requests in a step cost more than the early reads buy), 1 on the wide image of the 256-row
+    // tiles.  NOT on the wide image of the 128 x 128 tile (4 wavefronts, two workgroups per CU): that instance is not reproducible when the GPU is
+    // shared — three processes running side by side see 1-5 of 150 launches of any layer on it differ from the first, while schedule 0 on the same
+    // image and tile (and schedule 1 on the 256-row tiles, and on the 64-byte image) never do (tools/layer_race_check.py, profiles/r05_run16_*,
+    // r05_run17_*).  The hazard was not found by inspection (every request of a step is waited for and published by a barrier before its
+    // first read on paper); until it is, the 128-row tile requests its A rows spread over the taps and reads them behind the barrier.
+    constexpr int ASCHED = FGT_IL_A_EARLY != 2 ? FGT_IL_A_EARLY : (WIDE && BM != 128 ? 1 : 0);
     constexpr bool A_EARLY = ASCHED != 0;                 // every step's first A fragments are read before the barrier in front of it
     constexpr int ASTEPS = ASCHED == 1 ? 1 : KW - 1;
     constexpr int MAXA = (APW + ASTEPS - 1) / ASTEPS;    // most A pieces a wavefront requests in one step
