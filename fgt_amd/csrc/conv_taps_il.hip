@@ -45,8 +45,8 @@
 // 128-byte pieces — the CU retires such a piece in 19 cycles against 37 for a 16-row x 64-byte one.  16-byte slots are XOR-swizzled by
 // (row >> 1) & 7 on the source side (a lane fetches the slot that belongs at its linear LDS position), which makes every ds_read_b128 lane
 // group hit 16 distinct slots of the 256-byte bank window for ANY tap shift.  Same values, same products: bit-identical to the plane image
-// (tests/test_taps_gpu.py runs both).  Measured +1 ... +13 % over the plane image (profiles/r04_run27_taps_il_wide_sweep.txt);
-// FGT_TAPS_WIDE=0 keeps interleaved inputs on the 64-byte image (A/B).
+// (tests/test_taps_gpu.py runs both).  Measured +1 ... +13 % over the plane image (profiles/r04_run27_taps_il_wide_sweep.txt) in a lone process —
+// and OFF by default since round 5 (FGT_TAPS_WIDE=1 enables it): not reproducible when the GPU is shared, see launch_kw below.
 // A GEMM mode of this kernel (KW = 1: 1 x 1 layers, A rows requested with the B tile of every step) was built, measured on the K = 512 / 768
 // linear layers of the transformer and dropped: 237-280 TFLOP/s against 253-309 of conv_split / conv_wide — with 16-24 steps per tile those
 // layers are bound by the tile's prologue and its 64 KB output, not by the step (NOTEBOOK §11).
@@ -481,7 +481,12 @@ int launch_kw_img(const ConvP& p, hipStream_t s) {
 // interleaved split inputs (in_split = 2; weights are always per-step interleaved lines): the wide LDS image; plane inputs: 64-byte rows
 template <int BM, int BN, int KW>
 int launch_kw(const ConvP& p, hipStream_t s) {
-    static const bool wide = [] { const char* e = getenv("FGT_TAPS_WIDE"); return !(e && e[0] == '0'); }();      // (0: A/B measurements)
+    // Round 5: the wide image is OFF unless FGT_TAPS_WIDE=1.  With three processes sharing the GPU its instances are not reproducible: the 128-row
+    // tile with the early request schedule in 1-5 of 150 launches (ASCHED above), and with that schedule gone still 1 pass of the FGT step in 450
+    // (a 256-row tile or the image itself: not resolved), against 0 of 450 on the 64-byte image, 0 of 450 with the static tiles, 0 of 450 without
+    // the tap kernels (profiles/r05_run16...18_*).  Without the early schedule on the 128-row tile the wide image measures no faster than the
+    // 64-byte one on the step (72.97 vs 72.98 ms of conv time), so nothing is lost by leaving it off.
+    static const bool wide = [] { const char* e = getenv("FGT_TAPS_WIDE"); return e && e[0] == '1'; }();
     return p.d.in_split == 2 && wide ? launch_kw_img<BM, BN, KW, true>(p, s) : launch_kw_img<BM, BN, KW, false>(p, s);
 }
 
