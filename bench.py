@@ -386,7 +386,7 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N>1 headline: strong = one clip sharded by frames/windows over the ranks (default); weak = one clip per rank")
     ap.add_argument("--window-batch", type=int, default=8, help="equal-length windows per transformer+decoder forward (bit-identical results)")
-    ap.add_argument("--encode-chunk", type=int, default=40, help="frames per call of the per-frame stages (conv encoders + soft split; 20 -> 40: +0.5 %, bit-identical)")
+    ap.add_argument("--encode-chunk", type=int, default=40, help="frames per call of the per-frame stages (conv encoders + soft split; 20 -> 40: +0.5 %%, bit-identical)")
     ap.add_argument("--graphs", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
                     help="replay each window group's launch sequence as a hipGraph (the roofline blocks are then measured on one extra eager step "
                          "after the timed region).  auto (default): on for N > 1 — a rank's share of the step is then shorter than the time the host "

@@ -33,7 +33,8 @@ constexpr int C4_BN = 64, C4_WM = 4;
 constexpr int C4_TM = FGT_C4_TM, C4_BM = C4_WM * 32 * C4_TM;
 
 template <int KS>
-__global__ void __launch_bounds__(256, C4_TM == 1 ? 3 : 2) conv_c4_kernel(const ConvP p) {
+// (KS = 7 stages 64 x 912 B = 58 KB of weights: two workgroups per CU whatever the register count, so it is not held to the 3-workgroup cap)
+__global__ void __launch_bounds__(256, C4_TM == 1 ? (KS == 7 ? 2 : 3) : 2) conv_c4_kernel(const ConvP p) {
     constexpr int BM = C4_BM, BN = C4_BN, WM = C4_WM, WN = 1, TM = C4_TM, TN = 2;
     constexpr int NTAP = KS * KS, K = NTAP * 4;
     constexpr int NK16 = (K + 15) / 16;                  // k16 steps that hold a tap (the padding of Kpad beyond them is zero weights: skipped)

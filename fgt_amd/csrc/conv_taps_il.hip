@@ -45,8 +45,8 @@
 // 128-byte pieces — the CU retires such a piece in 19 cycles against 37 for a 16-row x 64-byte one.  16-byte slots are XOR-swizzled by
 // (row >> 1) & 7 on the source side (a lane fetches the slot that belongs at its linear LDS position), which makes every ds_read_b128 lane
 // group hit 16 distinct slots of the 256-byte bank window for ANY tap shift.  Same values, same products: bit-identical to the plane image
-// (tests/test_taps_gpu.py runs both).  Measured +1 ... +13 % over the plane image (profiles/r04_run27_taps_il_wide_sweep.txt) in a lone process —
-// and OFF by default since round 5 (FGT_TAPS_WIDE=1 enables it): not reproducible when the GPU is shared, see launch_kw below.
+// (tests/test_taps_gpu.py runs both).  Measured +1 ... +13 % over the plane image (profiles/r04_run27_taps_il_wide_sweep.txt).  Off in round 5
+// (run-to-run differences on a shared GPU), on again since round 6: the cause was a compiler-placed register copy, see retire_pre_reads.
 // A GEMM mode of this kernel (KW = 1: 1 x 1 layers, A rows requested with the B tile of every step) was built, measured on the K = 512 / 768
 // linear layers of the transformer and dropped: 237-280 TFLOP/s against 253-309 of conv_split / conv_wide — with 16-24 steps per tile those
 // layers are bound by the tile's prologue and its 64 KB output, not by the step (NOTEBOOK §11).
@@ -118,13 +118,11 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     //      in front of it.  (9 requests per wavefront in one step overrun the CU's DMA queue for a while; a third schedule — spread as in 0,
     //      the pieces of tap KW-2 first in their step and waited for at its end — was measured 3 % slower than this one (run 38), the A
     //      requests behind the step's last MFMA instead of in its request slots 1-3 % slower (run 41).)
-    // Default: 0 on the 64-byte image (narrow pieces: more requests in a step cost more than the early reads buy), 1 on the wide image of the 256-row
-    // tiles.  NOT on the wide image of the 128 x 128 tile (4 wavefronts, two workgroups per CU): that instance is not reproducible when the GPU is
-    // shared — three processes running side by side see 1-5 of 150 launches of any layer on it differ from the first, while schedule 0 on the same
-    // image and tile (and schedule 1 on the 256-row tiles, and on the 64-byte image) never do (tools/layer_race_check.py, profiles/r05_run16_*,
-    // r05_run17_*).  The hazard was not found by inspection (every request of a step is waited for and published by a barrier before its
-    // first read on paper); until it is, the 128-row tile requests its A rows spread over the taps and reads them behind the barrier.
-    constexpr int ASCHED = FGT_IL_A_EARLY != 2 ? FGT_IL_A_EARLY : (WIDE && BM != 128 ? 1 : 0);
+    // Default: 0 on the 64-byte image (narrow pieces: more requests in a step cost more than the early reads buy), 1 on the wide image.
+    // (Round 5 saw schedule 1 differ from run to run when three processes shared the GPU — 1-5 of 150 launches on the 128-row tile, 1 of 450 passes
+    // of the step on the 256 x 128 one — and switched it and the wide image off without a cause.  The cause was not in the schedule: see
+    // retire_pre_reads below.)
+    constexpr int ASCHED = FGT_IL_A_EARLY != 2 ? FGT_IL_A_EARLY : (WIDE ? 1 : 0);
     constexpr bool A_EARLY = ASCHED != 0;                 // every step's first A fragments are read before the barrier in front of it
     constexpr int ASTEPS = ASCHED == 1 ? 1 : KW - 1;
     constexpr int MAXA = (APW + ASTEPS - 1) / ASTEPS;    // most A pieces a wavefront requests in one step
@@ -399,7 +397,18 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
 
     int bs = 0;                                           // B stage of this step
     frag_addr(0, (unsigned)(2 * B_BYTES), 0);
-    if constexpr (A_EARLY) loadA(std::integral_constant<int, 0>{}, fa_a0);
+    // Fragment reads in flight must never cross a loop edge.  hipcc counts an asm statement's VGPR destination as written at ;;#ASMEND: where the
+    // registers of A-fragment set 0 are loop-carried it places PHI copies (v_mov_b64 of the ds_read_b128 destinations) in the preheader and on the
+    // back-edge of the super-step loop — AHEAD of the s_waitcnt that covers the reads.  A copy takes whatever the register holds: the fragment when
+    // the LDS answered within the ~60 instructions in between (a lone process: every bit-equality test of two rounds), stale bits when other work
+    // shares the CU's LDS (1-5 of 150 launches with three processes on the GPU).  That was round 5's "not reproducible on a shared GPU" of the early
+    // schedule (NOTEBOOK §13.1; tools/asm_hazard_audit.py finds the copies in the ISA and tests/test_build_resources.py runs it over every object
+    // with asm reads).  So: the pre-loop reads and the pre-barrier reads of a super-step's LAST step are retired before the edge — they were
+    // issued four MFMAs and the request wait ago; the pre-barrier reads of the other steps cross straight-line code only.
+    auto retire_pre_reads = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Al[0][0]), "+v"(Al[0][1]), "+v"(Ah[0][0]), "+v"(Ah[0][1]));
+    };
+    if constexpr (A_EARLY) { loadA(std::integral_constant<int, 0>{}, fa_a0); retire_pre_reads(); }
     for (int ss = 0; ss < nss; ++ss) {
         const bool last = ss + 1 == nss;
         const unsigned Ab = (unsigned)(2 * B_BYTES + (ss & 1) * A_BYTES);          // byte offset of this super-step's A buffer in the LDS
@@ -441,6 +450,7 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
             if constexpr (kx >= ASTEPS) wait_vmcnt<0>();
             else wait_vmcnt_upto<MAXA>(na);
             PP_STAMP(3);
+            if constexpr (A_EARLY && kx == KW - 1) retire_pre_reads();                  // (the loop edge is behind this step: see above)
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -481,12 +491,10 @@ int launch_kw_img(const ConvP& p, hipStream_t s) {
 // interleaved split inputs (in_split = 2; weights are always per-step interleaved lines): the wide LDS image; plane inputs: 64-byte rows
 template <int BM, int BN, int KW>
 int launch_kw(const ConvP& p, hipStream_t s) {
-    // Round 5: the wide image is OFF unless FGT_TAPS_WIDE=1.  With three processes sharing the GPU its instances are not reproducible: the 128-row
-    // tile with the early request schedule in 1-5 of 150 launches (ASCHED above), and with that schedule gone still 1 pass of the FGT step in 450
-    // (a 256-row tile or the image itself: not resolved), against 0 of 450 on the 64-byte image, 0 of 450 with the static tiles, 0 of 450 without
-    // the tap kernels (profiles/r05_run16...18_*).  Without the early schedule on the 128-row tile the wide image measures no faster than the
-    // 64-byte one on the step (72.97 vs 72.98 ms of conv time), so nothing is lost by leaving it off.
-    static const bool wide = [] { const char* e = getenv("FGT_TAPS_WIDE"); return e && e[0] == '1'; }();
+    // FGT_TAPS_WIDE=0 selects the 64-byte image for interleaved inputs too (A/B measurements).  Round 5 shipped with the wide image off: its early
+    // request schedule was not reproducible on a shared GPU; round 6 found the cause in the compiler's placement of PHI copies (retire_pre_reads
+    // above), fixed it, and tools/asm_hazard_audit.py now proves the absence of that hazard class per build.
+    static const bool wide = [] { const char* e = getenv("FGT_TAPS_WIDE"); return !(e && e[0] == '0'); }();
     return p.d.in_split == 2 && wide ? launch_kw_img<BM, BN, KW, true>(p, s) : launch_kw_img<BM, BN, KW, false>(p, s);
 }
 

@@ -323,7 +323,7 @@ class FGT(nn.Module):
         self._zero_row(dev, self.cfg["c"] + self.cfg["cf"])
         return self
 
-    def _pack_encoder_layer(self, i):
+    def _pack_encoder_layer(self, i, merge=True):
         """Encoder conv i (model.py:32-51).  The 640 -> 256 layer has 8 groups of 32 + 48 = 80 input and 32 output channels: 32-wide output tiles and
         a 48-channel second source that no 32-channel K-step fits (it ran at 92 TFLOP/s, a quarter of its neighbours).  ENC_MERGE_GROUPS (default)
         packs it as 4 groups of 64 + 96 -> 64 with block-diagonal weights: twice the multiply-adds, all of them with a zero weight, on 64-wide
@@ -332,7 +332,7 @@ class FGT(nn.Module):
         cin, cout, _, g = EncoderParams.SPEC[i]
         conv = self.frame_endoder.layers[2 * i]
         w, b = conv.weight, conv.bias
-        if not (ENC_MERGE_GROUPS and g == 8 and cin is not None):
+        if not (merge and ENC_MERGE_GROUPS and g == 8 and cin is not None):
             return PackedConv(w, b, groups=g)
         c0 = EncoderParams.SPEC[3][1] // g                      # channels per group from the skip source x0 (the input of layer 4, model.py:58-59): 32
         c1 = w.shape[1] - c0                                    # ... from the previous layer: 48
@@ -411,6 +411,9 @@ class FGT(nn.Module):
     def _pack(self):
         P = {}
         P["enc"] = [self._pack_encoder_layer(i) for i in range(len(EncoderParams.SPEC))]
+        # the reference's grouping of the 8-group layer for the modes whose chain is not the interleaved bf16x3 one (fp32-exact, f16): there the
+        # merged packing only doubles that layer's multiply-adds
+        P["enc_ref"] = [self._pack_encoder_layer(i, merge=False) if (ENC_MERGE_GROUPS and EncoderParams.SPEC[i][3] == 8) else pc for i, pc in enumerate(P["enc"])]
         P["fenc"] = [self._pack_block(self.flow_encoder[i]) for i in range(1, 5)]
         P["p2v"] = PackedConv(self.patch2vec.weight, self.patch2vec.bias)
         P["fp2v"] = PackedConv(self.f_patch2vec.weight, self.f_patch2vec.bias)
@@ -591,7 +594,8 @@ class FGT(nn.Module):
             assert self.passmask and self.in_channels == 4, "packed inputs carry (masked frame | mask)"
         th, tw = self.token_grid(H, W)
         o_enc, o_tok, o_ftok = out if out is not None else (None, None, None)
-        E = P["enc"]
+        merged = ENC_MERGE_GROUPS and ops.DEFAULT_CONV_PRECISION == "bf16x3"
+        E = P["enc"] if merged else P["enc_ref"]
         strides = [sp[2] for sp in EncoderParams.SPEC]
         sc = "only" if self._split_chain() else None
         e = x_in
@@ -601,10 +605,10 @@ class FGT(nn.Module):
                 x0 = e                                                         # model.py:58-59
             osp = ("both" if sc else None) if i == 8 else sc                   # the last layer also feeds fold()'s fp32 residual
             dst = o_enc if i == 8 else None
-            # split outputs: interleaved where every consumer is a single-source conv (layers 0-2 and the last one, which feeds patch2vec);
-            # layers 3-7 feed the two-source grouped convs, whose 640 -> 256 g8 member has 48 channels per group from the second source (not
-            # a multiple of 32) and both sources of a conv share one layout: planes there
-            il = ops.split_il(E[i].Cout) and (i <= 2 or i == 8 or ENC_MERGE_GROUPS)
+            # split outputs: interleaved wherever the consumer's K-steps are whole 32-channel chunks of each source — every layer with the 8-group
+            # layer merged into 4 groups (bf16x3 chain); with the reference's grouping (48 channels per group from the second source) layers 3-7
+            # hand over planes, since both sources of a conv share one layout
+            il = ops.split_il(E[i].Cout) and (i <= 2 or i == 8 or merged)
             if i <= 4:
                 e = ops.conv2d(e, E[i], stride=strides[i], pad=1, act="lrelu", out_split=osp, out=dst, out_il=il)
             else:

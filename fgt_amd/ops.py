@@ -363,6 +363,19 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     if ps is not None:
         d.ps_r, d.ps_c, d.ps_g0, d.ps_H, d.ps_W = (int(v) for v in ps)
     d.ky_skip_n0, d.aux_per_image, d.n_alg = int(ky_skip_n0), int(bool(aux_per_image)), int(n_alg)
+    # the epilogue indexes its operands by tile row with no bounds of their own: a table of another grid (a stale cache key, another th / tw) would
+    # read out of bounds on the device
+    rows_out = N * Ho * Wo
+    for nm, a in (("aux1", aux1), ("aux2", aux2)):
+        if a is None:
+            continue
+        a4, aN, aH, aW, aC, _ = _as_map(a)
+        if nm == "aux2" and epi == "ps_add2":
+            assert ps is not None and (aN * aH * aW, aC) == (N * ps[3] * ps[4], ps[1]), f"conv2d: ps_add2 aux2 shape {tuple(a.shape)} is not the [N, {ps[3]}, {ps[4]}, {ps[1]}] map"
+        elif aux_per_image and (nm == "aux1" or epi == "affine"):
+            assert (aN * aH * aW, aC) == (Ho * Wo, pc.Cout), f"conv2d: per-image {nm} table shape {tuple(a.shape)} != ({Ho * Wo}, {pc.Cout})"
+        else:
+            assert aN * aH * aW >= rows_out and aC >= pc.Cout, f"conv2d: {nm} shape {tuple(a.shape)} is smaller than the output ({rows_out}, {pc.Cout})"
     d.tile_order = int(tile_order) if _FORCE_TILE_ORDER is None else _FORCE_TILE_ORDER
     bias = pc.bias
     if bias_map is not None:
@@ -406,7 +419,7 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     if d.tile == 0 and AUTOTUNE and pc.Cout // pc.groups > 4:
         key = (N, H, W, C0, C1, pc.Cout, pc.groups, pc.kh, pc.kw, sh, sw, ph, pw, dh, dw, d.upsample, d.epi, d.out_nchw, d.precision,
                d.in_split, d.out_split, d.w_il, int(bool(osp) and out_s.il) + 2 * int(bool(osp) and out_s.h), d.pad_mode, d.in_relu,
-               d.ps_r, d.ps_c, d.ps_H, d.ps_W, d.ky_skip_n0, int(d.ld_bias > 0), d.tile_order)
+               d.ps_r, d.ps_c, d.ps_H, d.ps_W, d.ky_skip_n0, int(d.ld_bias > 0), d.tile_order, d.aux_per_image)
         best = _tile_cache.get(key)
         if best is not None and key not in _tile_validated:
             # A cached / loaded tile must belong to the kernel family the GEOMETRY routes this layer to (taps-routed layers: codes 200-299,

@@ -32,3 +32,47 @@ def test_no_kernel_uses_scratch_or_spills():
         allowed = 40 if src == "conv_igemm.hip" else 0     # the register-staged 8-wave 128x128 bf16x3 tile is capped at 128 VGPRs (<= 10 dwords spill; the hot path runs on conv_split.hip)
         assert max(scratch) <= allowed and sum(1 for s in scratch if s) <= 1, f"{src}: scratch bytes/lane {scratch}"
         assert sum(spills) <= 10, f"{src}: VGPR spills {spills}"
+
+
+# ---- round 6: registers with an LDS read in flight must not be touched before the wait that retires the read (tools/asm_hazard_audit.py)
+ASM_READ_SOURCES = ["conv_taps_il.hip", "conv_taps_il_256x128.hip", "conv_taps_il_256x256.hip", "conv_wide.hip", "conv_igemm.hip", "conv_f16.hip",
+                    "attention.hip", "attention_split.hip"]
+
+
+def _audit(obj):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import asm_hazard_audit as A
+    total, report, _ = A.audit_file(obj, verbose=False)
+    return obj, total, {k: sorted(v.values())[:3] for k, v in report.items() if v}, len(report)
+
+
+def test_no_instruction_touches_a_register_with_an_lds_read_in_flight():
+    """hipcc may copy the destination of an inline-asm ds_read before the hand-counted s_waitcnt that covers it (PHI copies on a loop edge): the
+    cause of round 5's run-to-run differences on a shared GPU.  The ISA of every object with asm reads is walked (CFG x outstanding-read queue)."""
+    from concurrent.futures import ProcessPoolExecutor
+    B.build(verbose=False)                         # no-op when the objects are up to date
+    objs = [os.path.join(B.LIBDIR, "obj", s.replace(".hip", ".o")) for s in ASM_READ_SOURCES]
+    with ProcessPoolExecutor(max_workers=4) as ex:
+        res = list(ex.map(_audit, objs))
+    for obj, total, bad, nk in res:
+        assert nk > 0, f"{obj}: no kernels found in the disassembly"
+        assert total == 0, f"{obj}: {total} hazard sites, e.g. {bad}"
+
+
+def test_hazard_audit_finds_a_planted_copy():
+    """The audit's own check on a hand-written listing: a v_mov of a ds_read destination ahead of the wait is reported, behind it is not, and a
+    counted wait retires exactly the reads it covers."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import asm_hazard_audit as A
+    def run(body):
+        asm = "\t.amdhsa_kernel k\nk:\n" + "".join((l if l.endswith(":") else "\t" + l) + "\n" for l in body) + "\ts_endpgm\n.Lfunc_end0:\n"
+        hz, _ = A.audit_kernel("k", A.parse_kernels(asm)["k"])
+        return len(hz)
+    assert run(["ds_read_b128 v[4:7], v1", "v_mov_b64_e32 v[8:9], v[4:5]", "s_waitcnt lgkmcnt(0)"]) == 1
+    assert run(["ds_read_b128 v[4:7], v1", "s_waitcnt lgkmcnt(0)", "v_mov_b64_e32 v[8:9], v[4:5]"]) == 0
+    assert run(["ds_read_b128 v[4:7], v1", "ds_read_b128 v[8:11], v1", "s_waitcnt lgkmcnt(1)", "v_mov_b32_e32 v20, v5"]) == 0
+    assert run(["ds_read_b128 v[4:7], v1", "ds_read_b128 v[8:11], v1", "s_waitcnt lgkmcnt(1)", "v_mov_b32_e32 v20, v9"]) == 1
+    # across a loop edge: the read is issued at the end of the body, the copy sits at the top of the next iteration
+    assert run([".LBB0_1:", "v_mov_b32_e32 v20, v4", "s_waitcnt lgkmcnt(0)", "ds_read_b128 v[4:7], v1", "s_cbranch_scc1 .LBB0_1"]) == 1
