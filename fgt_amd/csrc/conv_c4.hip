@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256, C4_TM == 1 ? (KS == 7 ? 2 : 3) : 2) conv_
         __builtin_amdgcn_sched_barrier(0);               // (the next chunk's gathers are not hoisted above this chunk's MFMAs: registers)
     });
     __syncthreads();                                     // every wavefront has read its last weight fragment: the LDS becomes the epilogue's scratch
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, 0);
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, true, false>(p, acc, smem, bm0, bn0, 0);      // (fp32 inputs: no two-headed layers)
 }
 
 template <int KS>

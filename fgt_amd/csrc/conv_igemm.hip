@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_igemm_kernel(const Con
     }
     }
 
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, true, false>(p, acc, smem, bm0, bn0, g);      // (fp32 inputs: no two-headed layers, fgt_conv2d rejects them)
 }
 
 template <int BM, int BN, int WM, int WN, int PREC, int MINW = 2>
@@ -410,6 +410,19 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     FGT_REQUIRE(d.ld_bias >= 0 && (d.tile_order == 0 || d.tile_order == 1) && (d.ld_bias == 0 || (cbias != nullptr && p.Cout_g > 4 && d.ld_bias % 4 == 0 && d.ld_bias >= d.Cout && !d.ps_r && d.in_split != 3)),
                 "fgt_conv2d: a bias map (ld_bias > 0) needs cbias, Cout/groups > 4, ld_bias %% 4 == 0, ld_bias >= Cout, no sub-pixel output, no fp16 inputs");
     FGT_REQUIRE(d.ky_skip_n0 == 0 || (d.groups == 1 && d.kh >= 2 && d.upsample == 0), "fgt_conv2d: ky_skip_n0 needs groups = 1, kh >= 2, no upsampling");
+    // ---- ABI 8: two heads in one convolution; batched GEMM on the wide kernel
+    FGT_REQUIRE(d.dual_n0 >= 0 && d.reserved8 == 0, "fgt_conv2d: bad dual_n0 / reserved field");
+    if (d.dual_n0 > 0)
+        FGT_REQUIRE(d.epi == FGT_EPI_MUL && d.out_split == 2 && d.groups == 1 && d.Cout == 2 * d.dual_n0 && d.dual_n0 % 64 == 0 &&
+                    !d.ps_r && !d.aux_per_image && !d.out_nchw && (d.in_split == 1 || d.in_split == 2),
+                    "fgt_conv2d: two heads (dual_n0 = %d) need FGT_EPI_MUL, out_split = 2, groups = 1, Cout = 2 * dual_n0, dual_n0 %% 64 == 0, NHWC, split inputs (in_split = 1 or 2), no sub-pixel output", d.dual_n0);
+    const bool gb = d.gb_x0 != 0 || d.gb_w != 0 || d.gb_o != 0;
+    if (gb)
+        FGT_REQUIRE(d.gb_x0 > 0 && d.gb_w > 0 && d.gb_o > 0 && d.gb_x0 % 8 == 0 && d.gb_w % 8 == 0 && d.gb_o % 4 == 0 && d.in_split == 2 && d.w_il == 1 &&
+                    d.tile >= FGT_TILE_WIDE && d.tile < FGT_TILE_TAPS && d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && d.C1 == 0 && d.N == 1 &&
+                    d.out_split == 0 && !d.out_nchw && d.epi == FGT_EPI_NONE && !cscale && !cbias && !d.ps_r && !d.upsample && p.Cout_g % 8 == 0 && d.ldo % 4 == 0 && d.ooff % 4 == 0,
+                    "fgt_conv2d: the batched GEMM mode (gb_*) needs interleaved operands (in_split = 2, w_il = 1), an explicit wide tile (100..199), a 1 x 1 / stride 1 / single-source / "
+                    "single-image geometry, plain fp32 output without epilogue, scale or bias, Cout/groups %% 8 == 0 and strides that are multiples of 8 (gb_x0, gb_w) / 4 (gb_o, ldo, ooff)");
     const long M = (long)d.N * Ho * Wo;
     FGT_REQUIRE(M < (1l << 31), "fgt_conv2d: M too large");
     p.M = (int)M; p.HoWo = Ho * Wo; p.nk = d.Kpad / (d.in_split == 3 ? 64 : BK);
@@ -460,8 +473,10 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     const double aux1_vals = d.epi == FGT_EPI_NONE ? 0.0 : (d.aux_per_image ? (double)Ho * Wo * d.Cout : (double)M * d.Cout);
     const double aux2_vals = d.epi < FGT_EPI_GRU ? 0.0 : d.epi == FGT_EPI_PS_ADD2 ? out_vals : (d.epi == FGT_EPI_AFFINE && d.aux_per_image ? (double)Ho * Wo * d.Cout : (double)M * d.Cout);
     const double bmap_bytes = d.ld_bias > 0 ? 4.0 * (double)M * d.Cout : 0.0;
+    // (two heads: each output form and aux1 cover half of the columns)
     const double conv_bytes = bmap_bytes + in_b * ((double)d.N * d.H * d.W * (d.C0 + d.C1) + (double)d.Cout * p.K) +
-                              out_vals * ((d.out_split != 1 ? 4.0 : 0.0) + (d.out_split ? os_b : 0.0)) + 4.0 * (aux1_vals + aux2_vals);
+                              (d.dual_n0 > 0 ? out_vals * 0.5 * (4.0 + os_b) + 2.0 * aux1_vals
+                                             : out_vals * ((d.out_split != 1 ? 4.0 : 0.0) + (d.out_split ? os_b : 0.0)) + 4.0 * (aux1_vals + aux2_vals));
     // (Cout <= 4 VALU kernels: an HBM-bound pass over the input map — their own kind, bytes only)
     const int prof = direct ? fgt_prof_begin(FGT_PROF_CONV_SMALL, 0.0, conv_bytes, s) : fgt_prof_begin(FGT_PROF_CONV, 2.0 * (double)M * (d.n_alg > 0 ? d.n_alg : p.Cout_g) * (d.k_alg > 0 ? d.k_alg : p.K) * d.groups, conv_bytes, s);
     int rc;

@@ -103,8 +103,10 @@ __device__ __forceinline__ void conv_row_of(const ConvP& p, int mt, int ry, int 
 // loader consumes.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
 // STAGE = floats per LDS stage; the caller guarantees 2 stages are allocated and no longer in use.
 // BIAS_MAP = false: a kernel family that never sees desc.ld_bias > 0 (the fp16 kernels: the host rejects the combination) skips those instances.
-template <int BM, int BN, int WM, int WN, int STAGE, int TM, int TN, bool BIAS_MAP = true>
-__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], float* smem, int bm0, int bn0, int g) {
+// out_goff: element offset added to `out` (ABI 8, the batched GEMM mode of conv_wide.hip: group g's output block; the caller passes g = 0 then).
+// DUAL = false: a kernel family that never sees desc.dual_n0 > 0 (fp32 / fp16 inputs: the host requires split inputs for two heads).
+template <int BM, int BN, int WM, int WN, int STAGE, int TM, int TN, bool BIAS_MAP = true, bool DUAL = true>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], float* smem, int bm0, int bn0, int g, long out_goff = 0) {
     constexpr int NT = WM * WN * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     static_assert(TM == WTM / 32 && TN == WTN / 32, "accumulator shape");
@@ -145,6 +147,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         int ps_ry = 0, ps_rx = 0, och = co;
         bool ps_col = true;
         if (d.ps_r) ps_col = conv_ps_column(d, n, ps_ry, ps_rx, och);
+        // ABI 8, two heads (desc.dual_n0 > 0, FGT_EPI_MUL, groups = 1).  Head 0 = columns [0, n0): fp32 output, no combine;
+        // head 1 = [n0, 2 n0): times aux1[m, n - n0], split output at channel n - n0.
+        // (the host requires n0 % 64 == 0 and every wavefront's columns are 32 or 64 wide: which head a WAVEFRONT serves is a scalar)
+        const bool dual = DUAL && d.dual_n0 > 0;
+        const bool head1 = dual && __builtin_amdgcn_readfirstlane(bn0 + wn * WTN) >= d.dual_n0;
+        if (head1) och = co - d.dual_n0;
+        const bool st_f32 = want_f32 && !head1, st_split = want_split && (!dual || head1);
         // The body is instantiated per number of aux operands (AUX = 0: no epilogue operand, 1: mul / add, 2: GRU) and dispatched on desc.epi.
         // With desc.epi tested at run time inside ONE body, hipcc put `s_waitcnt vmcnt(0)` in front of every row group (the join of the
         // paths with and without aux loads) — and on gfx9 that counter also holds the STORES until they are acknowledged: every group of
@@ -176,7 +185,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 conv_row_of(p, mt, ps_ry, ps_rx, ps_col, m, rem, okr);
                 const long m1 = d.aux_per_image ? (long)rem : m;
                 // (out-of-range lanes read the zero page: the select is on the address, the loads stay back to back)
-                if constexpr (AUX >= 1) a1[u0] = *reinterpret_cast<const float4*>(okk ? p.aux1 + m1 * d.ld_aux1 + co : p.zero_page);
+                if constexpr (AUX >= 1) a1[u0] = *reinterpret_cast<const float4*>(okk && (!dual || head1) ? p.aux1 + m1 * d.ld_aux1 + (dual ? och : co) : p.zero_page);
                 if constexpr (AUX >= 2) {
                     const float* q2 = d.epi == FGT_EPI_PS_ADD2 ? p.aux2 + m * d.ld_aux2 + och : p.aux2 + (d.epi == FGT_EPI_AFFINE ? m1 : m) * d.ld_aux2 + co;
                     a2[u0] = *reinterpret_cast<const float4*>(okk && okr ? q2 : p.zero_page);
@@ -227,7 +236,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                     }
                     float x = fgt_act(pre, d.act, d.slope) * d.out_scale;
                     if constexpr (AUX == 1) {
-                        if (d.epi == FGT_EPI_MUL) x *= x1[u];
+                        if (d.epi == FGT_EPI_MUL) x *= (dual && !head1) ? 1.f : x1[u];
                         else x = fgt_act(x + x1[u], d.act2, d.slope);
                     }
                     if constexpr (AUX == 2) {
@@ -239,12 +248,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                     typedef float nt_f4 __attribute__((ext_vector_type(4)));
                     typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
                     const bool nt = p.nt_store != 0;
-                    if (want_f32) {
-                        float* o = p.out + m * d.ldo + d.ooff + och;
+                    if (st_f32) {
+                        float* o = p.out + out_goff + m * d.ldo + d.ooff + och;
                         if (nt) __builtin_nontemporal_store(nt_f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<nt_f4*>(o));
                         else *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
                     }
-                    if (want_split) {
+                    if (st_split) {
                         const int cs = d.ooff_s + och;      // pso == 32: interleaved layout, channel c -> (c/32)*64 + c%32, lo 32 further
                         if (p.pso < 0) {                    // pso == -1: one fp16 plane (in_split = 3 of the consumer)
                             const uint2 h = fgt_half4(make_float4(v[0], v[1], v[2], v[3]));
@@ -306,6 +315,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
             bool okr;
             long m;
             const bool ps_col = d.ps_r ? conv_ps_column(d, n, ps_ry, ps_rx, och) : true;     // (host: sub-pixel output implies vec_ok)
+            const bool dual = DUAL && d.dual_n0 > 0, head1 = dual && n >= d.dual_n0;                 // (host: two heads imply vec_ok)
+            if (head1) och = co - d.dual_n0;
             conv_row_of(p, mbase + row, ps_ry, ps_rx, ps_col, m, rem, okr);
             if (!okr) continue;
             const long m1 = d.aux_per_image ? (long)rem : m;
@@ -322,7 +333,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                     else if (d.epi == FGT_EPI_PS_ADD2) pre = pre + p.aux1[m1 * d.ld_aux1 + co + u] + p.aux2[m * d.ld_aux2 + och + u];
                     float x = fgt_act(pre, d.act, d.slope) * d.out_scale;
                     if (d.epi == FGT_EPI_MUL) {
-                        x *= p.aux1[m1 * d.ld_aux1 + co + u];
+                        if (!dual || head1) x *= p.aux1[m1 * d.ld_aux1 + (dual ? och : co) + u];
                     } else if (d.epi == FGT_EPI_ADD) {
                         x = fgt_act(x + p.aux1[m1 * d.ld_aux1 + co + u], d.act2, d.slope);
                     } else if (d.epi == FGT_EPI_GRU) {
@@ -334,8 +345,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 }
             }
             if (vec_ok) {
-                if (want_f32) *reinterpret_cast<float4*>(p.out + m * d.ldo + d.ooff + och) = make_float4(v[0], v[1], v[2], v[3]);
-                if (want_split) {       // validated by the host: vec_ok holds whenever out_split is set
+                if (want_f32 && !head1) *reinterpret_cast<float4*>(p.out + out_goff + m * d.ldo + d.ooff + och) = make_float4(v[0], v[1], v[2], v[3]);
+                if (want_split && (!dual || head1)) {       // validated by the host: vec_ok holds whenever out_split is set
                     const int cs = d.ooff_s + och;      // pso == 32: interleaved layout, channel c -> (c/32)*64 + c%32, lo 32 further
                     if (p.pso < 0) {                    // pso == -1: one fp16 plane
                         *reinterpret_cast<uint2*>(p.out_s + m * d.ldo_s + cs) = fgt_half4(make_float4(v[0], v[1], v[2], v[3]));
@@ -351,7 +362,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 const int n_img = m / p.HoWo, rem = m - n_img * p.HoWo;
                 for (int u = 0; u < nvalid; ++u) p.out[((long)n_img * d.Cout + co + u) * p.HoWo + rem] = v[u];
             } else {
-                for (int u = 0; u < nvalid; ++u) p.out[m * d.ldo + d.ooff + co + u] = v[u];
+                for (int u = 0; u < nvalid; ++u) p.out[out_goff + m * d.ldo + d.ooff + co + u] = v[u];
             }
         }
     }

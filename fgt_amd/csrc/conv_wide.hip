@@ -59,14 +59,17 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_wide_kernel(const Conv
     if (!conv_tile_index(p, m_idx, n_idx)) return;
     const int bm0 = m_idx * BM, bn0 = n_idx * BN, g = blockIdx.y;
 
-    const __bf16* const x0 = reinterpret_cast<const __bf16*>(p.x0);
+    // ABI 8, batched GEMM (desc.gb_o != 0): group g has its own rows, its own weight rows and its own output block — the channel offsets of the
+    // grouped-convolution form (g * Cin/groups, g * Npad weight rows, g * Cout/groups output channels) are replaced by three element strides
+    const bool gb = d.gb_o != 0;
+    const __bf16* const x0 = reinterpret_cast<const __bf16*>(p.x0) + (gb ? (long)g * d.gb_x0 : 0l);
     const __bf16* const x1 = reinterpret_cast<const __bf16*>(p.x1);
     // (copied out of the kernel-argument struct: see conv_split.hip)
     const int ld0 = d.ld0, ld1 = d.ld1;
     const int Cg0 = p.Cg0, Cg = p.Cg;
     // element offset of logical channel c of a pixel's interleaved row: (c / 32) * 64 + c % 32 (hi), + 32 (lo); a K-step starts at a
     // multiple of 32, so chunk column kc (0-3 hi, 4-7 lo) of the step that starts at channel c sits at 2 * c + kc * 8
-    const int chb0 = 2 * (d.off0 + g * p.Cg0), chb1 = 2 * (d.off1 + g * p.Cg1 - p.Cg0);
+    const int chb0 = 2 * (d.off0 + (gb ? 0 : g * p.Cg0)), chb1 = 2 * (d.off1 + g * p.Cg1 - p.Cg0);
 
     // ---- this lane's DMA rows: row (lane >> 3) of each of its 8-row pieces, chunk column kc of every K-step
     const int lrow = lane >> 3;
@@ -127,7 +130,9 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_wide_kernel(const Conv
 #pragma unroll
     for (int it = 0; it < PB; ++it) {
         const int brow = bn0 + (wave + it * NW) * 8 + lrow;          // rows past Npad (tiles wider than the 128-row padding): zeros
-        wrow[it] = brow < d.Npad ? reinterpret_cast<const __bf16*>(p.w) + ((long)g * d.Npad + brow) * (2 * d.Kpad) + kc * 8 : nullptr;
+        // (batched: a group's weight rows are the Cout/groups rows of its operand tensor — a multiple of 8, so a piece is all in or all out)
+        const __bf16* const wg = reinterpret_cast<const __bf16*>(p.w) + (gb ? (long)g * d.gb_w : (long)g * d.Npad * (2 * d.Kpad));
+        wrow[it] = brow < (gb ? p.Cout_g : d.Npad) ? wg + (long)brow * (2 * d.Kpad) + kc * 8 : nullptr;
     }
 
     char* const lds = reinterpret_cast<char*>(smem);
@@ -142,7 +147,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_wide_kernel(const Conv
         glds16(sel(a_base[it] + 2 * ci, ok), lds + slot * STAGE_B + (wave + it * NW) * 1024);
     };
     auto issue_B = [&](int it, int slot) {
-        const bool bok = BN <= 128 || wrow[it] != nullptr;
+        const bool bok = wrow[it] != nullptr;
         glds16(sel(wrow[it], bok), lds + slot * STAGE_B + BM * 128 + (wave + it * NW) * 1024);
         if (bok) wrow[it] += 2 * BK;
     };
@@ -372,7 +377,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_wide_kernel(const Conv
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, gb ? 0 : g, gb ? (long)g * d.gb_o : 0l);
 }
 
 template <int BM, int BN, int WM, int WN, int MINW = 2, int SCHED = 0>

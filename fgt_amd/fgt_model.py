@@ -29,6 +29,9 @@ SPLIT_ATTENTION = os.environ.get("FGT_SPLIT_ATTN", "1") != "0"
 FOLD_CONV = os.environ.get("FGT_FOLD_CONV", "1") != "0"
 # the encoder's 8-group layer packed as 4 groups with block-diagonal weights (FGT._pack_encoder_layer); 0: as the reference groups it (A/B)
 ENC_MERGE_GROUPS = os.environ.get("FGT_ENC_MERGE_GROUPS", "1") != "0"
+# SWMHSA on three HIP streams when a call is too small to fill the chip (see FGT._spatial_attention): at most this many token rows per call
+# (BASELINE config C2, t = 10: 7 200 rows; the benchmark's step batches 136 frames = 97 920 rows per call and stays on one stream).  0: never
+SPATIAL_STREAM_ROWS = int(os.environ.get("FGT_SPATIAL_STREAM_ROWS", "32768"))
 # tile order of the fold convolutions (fgt_conv_desc.tile_order): 1 = N-major inside an XCD (their 7 / 21 MB weight matrices do not fit the L2)
 FOLD_TILE_ORDER = int(os.environ.get("FGT_FOLD_TILE_ORDER", "1"))
 
@@ -525,7 +528,6 @@ class FGT(nn.Module):
         pad_r, pad_b = (ws - tw % ws) % ws, (ws - th % ws) % ws
         nh, nw = th + pad_b, tw + pad_r
         R = bt * th * tw
-        fw = ops.linear(x, P["rw"], x1=f, act="sigmoid", epi="mul", aux1=f)            # f * sigmoid(Linear([x|f]))
         ng = (nh // gd) * (nw // gd)
         dev = x.device
         sc = self._split_chain()
@@ -535,22 +537,57 @@ class FGT(nn.Module):
         kin, vin, q_ln = new(R + 1 + bt * ng, c + cf), new(R + 1 + bt * ng, c), new(R + 1, c + cf)
         gk = torch.empty(bt * ng, c + cf, dtype=torch.float32, device=dev)
         gv = torch.empty(bt * ng, c, dtype=torch.float32, device=dev)
-        ops.dw_pool(x, fw, bt, nh, nw, gd, *P["gk"], out=gk, h=th, w_real=tw)
-        ops.dw_pool(x, None, bt, nh, nw, gd, *P["gv"], out=gv, h=th, w_real=tw)
         z = self._zero_row(dev, c + cf)
-        ops.layernorm(x, *P["qn"], x1=fw, gB=P["kn"][0], bB=P["kn"][1], outA=q_ln[:R], outB=kin[:R])
-        ops.layernorm(z[:, :c], *P["qn"], x1=z[:, c:], gB=P["kn"][0], bB=P["kn"][1], outA=q_ln[R:R + 1], outB=kin[R:R + 1])
-        ops.layernorm(gk, *P["kn"], outA=kin[R + 1:])
-        ops.layernorm(x, *P["vn"], outA=vin[:R])
-        ops.layernorm(z[:, :c], *P["vn"], outA=vin[R:R + 1])
-        ops.layernorm(gv, *P["vn"], outA=vin[R + 1:])
         osp = "only" if (sc and SPLIT_ATTENTION) else None
+        # The module is a small dependency graph, not a chain: the value path (global-token pool of x, three LayerNorms, the v Linear) needs neither
+        # the flow re-weighting nor the q / k path, and the k path parts from the q path behind the shared LayerNorm.  A call that cannot fill the
+        # chip by itself (BASELINE config C2: 7 200 token rows = 224 tiles per 512-wide GEMM on 256 CUs x 2 workgroups) therefore runs on THREE
+        # HIP streams — main: re-weighting -> LN(q|k) -> q -> attention -> out-projection; k: global-token pool of [x | f w] -> LN -> k;
+        # v: the value path — so the under-filled launches share the chip (14 launches deep becomes 5).  Same kernels on the same data: bit-identical
+        # to the single-stream order (tests/test_fgt_gpu.py); capturable (fork / join on the capturing stream).  Large calls (the clip runner's
+        # 136-frame batches) fill the chip per launch and stay on one stream.
+        par = x.is_cuda and 0 < R <= SPATIAL_STREAM_ROWS
+        if par:
+            main = torch.cuda.current_stream()
+            s_k, s_v = self._side_streams(dev)
+            s_v.wait_stream(main)
+            ctx_v, ctx_k = torch.cuda.stream(s_v), torch.cuda.stream(s_k)
+        else:
+            import contextlib
+            ctx_v = ctx_k = contextlib.nullcontext()
+        with ctx_v:                                                                      # ---- value path (attention_flow.py:36, 94-96, 128-131)
+            ops.dw_pool(x, None, bt, nh, nw, gd, *P["gv"], out=gv, h=th, w_real=tw)
+            ops.layernorm(x, *P["vn"], outA=vin[:R])
+            ops.layernorm(z[:, :c], *P["vn"], outA=vin[R:R + 1])
+            ops.layernorm(gv, *P["vn"], outA=vin[R + 1:])
+            vv = ops.linear(vin, P["v"], out_split=osp)
+        fw = ops.linear(x, P["rw"], x1=f, act="sigmoid", epi="mul", aux1=f)            # f * sigmoid(Linear([x|f]))  (attention_flow.py:52-55, 116-118)
+        if par:
+            s_k.wait_stream(main)
+        with ctx_k:                                                                      # ---- global key tokens + the padded token's rows
+            ops.dw_pool(x, fw, bt, nh, nw, gd, *P["gk"], out=gk, h=th, w_real=tw)
+            ops.layernorm(gk, *P["kn"], outA=kin[R + 1:])
+            ops.layernorm(z[:, :c], *P["qn"], x1=z[:, c:], gB=P["kn"][0], bB=P["kn"][1], outA=q_ln[R:R + 1], outB=kin[R:R + 1])
+        ops.layernorm(x, *P["qn"], x1=fw, gB=P["kn"][0], bB=P["kn"][1], outA=q_ln[:R], outB=kin[:R])
+        if par:
+            s_k.wait_stream(main)                                                        # kin[:R] is written on the main stream
+            main.wait_stream(s_k)                                                        # q_ln[R] on the k stream
+        with ctx_k:
+            kk = ops.linear(kin, P["k"], out_split=osp)
         q = ops.linear(q_ln, P["q"], out_split=osp)
-        kk = ops.linear(kin, P["k"], out_split=osp)
-        vv = ops.linear(vin, P["v"], out_split=osp)
+        if par:
+            main.wait_stream(s_k)
+            main.wait_stream(s_v)
         a = ops.attention_spatial(q, kk[:R + 1], vv[:R + 1], kk[R + 1:], vv[R + 1:], bt, th, tw, nh, nw, cfg["heads"], ws, ng, out_split=sc,
                                   pad_row=R)
         return ops.linear(a, P["out"], epi="add", aux1=x)
+
+    def _side_streams(self, dev):
+        cache = self.__dict__.setdefault("_streams", {})
+        key = str(dev)
+        if key not in cache:
+            cache[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        return cache[key]
 
     def _zero_row(self, dev, ch):
         """One row of zeros (the reference's padded token before the LayerNorms), kept per device."""

@@ -308,12 +308,15 @@ def prepack_weights(pc, mode=None):
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
            epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None,
-           out_split=None, out_s=None, out_il=False, out_h=None, ps=None, ky_skip_n0=0, aux_per_image=False, n_alg=0, bias_map=None, tile_order=0):
+           out_split=None, out_s=None, out_il=False, out_h=None, ps=None, ky_skip_n0=0, aux_per_image=False, n_alg=0, bias_map=None, tile_order=0,
+           dual=False):
     """fgt_conv2d.  x (and optional x1) are channels-last maps (fp32 tensors, or `Split`s for the LDS-DMA bf16x3 path);
     returns/outputs a channels-last map (or NCHW).  out_split: None -> fp32 result; "only" -> a Split; "both" -> (fp32, Split).
     ps = (r, c, g0, Hf, Wf): sub-pixel output (fold as a convolution, fgt_conv_desc.ps_r): the result is the [N, Hf, Wf, c] map;
     ky_skip_n0 / aux_per_image / n_alg: the fields of the same name.  bias_map: an fp32 [N, Ho, Wo, Cout] (or [rows, Cout]) map added in front of
-    the activation INSTEAD of pc.bias (fgt_conv_desc.ld_bias; the caller folds the bias into it)."""
+    the activation INSTEAD of pc.bias (fgt_conv_desc.ld_bias; the caller folds the bias into it).
+    dual=True (fgt_conv_desc.dual_n0 = Cout / 2, with epi="mul", out_split="both"): two heads — columns [0, Cout/2) -> act(v) into the fp32 `out`
+    [.., Cout/2]; columns [Cout/2, Cout) -> act(v) * aux1 into the Split `out_s` [.., Cout/2]."""
     in_split = isinstance(x, Split)
     if in_split:
         assert x1 is None or (isinstance(x1, Split) and x1.il == x.il and x1.h == x.h), "conv2d: both sources must be split the same way"
@@ -338,6 +341,9 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     Wo = (Win + 2 * pw - dw * (pc.kw - 1) - 1) // sw + 1
     osp = {None: 0, False: 0, "only": 1, "both": 2}[out_split]
     oshape = (N, Ho, Wo, pc.Cout) if ps is None else (N, ps[3], ps[4], ps[1])       # (sub-pixel output: the folded map)
+    if dual:
+        assert epi == "mul" and out_split == "both" and ps is None and pc.groups == 1 and pc.Cout % 8 == 0, "conv2d: dual needs epi='mul', out_split='both', groups = 1"
+        oshape = (N, Ho, Wo, pc.Cout // 2)
     if out is None and osp != 1:
         out = torch.empty((N, pc.Cout, Ho, Wo) if out_nchw else oshape, dtype=torch.float32, device=x.device)
     ldo = 0
@@ -375,8 +381,9 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
         elif aux_per_image and (nm == "aux1" or epi == "affine"):
             assert (aN * aH * aW, aC) == (Ho * Wo, pc.Cout), f"conv2d: per-image {nm} table shape {tuple(a.shape)} != ({Ho * Wo}, {pc.Cout})"
         else:
-            assert aN * aH * aW >= rows_out and aC >= pc.Cout, f"conv2d: {nm} shape {tuple(a.shape)} is smaller than the output ({rows_out}, {pc.Cout})"
+            assert aN * aH * aW >= rows_out and aC >= (pc.Cout // 2 if dual else pc.Cout), f"conv2d: {nm} shape {tuple(a.shape)} is smaller than the output ({rows_out}, {pc.Cout})"
     d.tile_order = int(tile_order) if _FORCE_TILE_ORDER is None else _FORCE_TILE_ORDER
+    d.dual_n0 = pc.Cout // 2 if dual else 0
     bias = pc.bias
     if bias_map is not None:
         b4, bN, bH, bW, bC, d.ld_bias = _as_map(bias_map)
@@ -419,7 +426,7 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     if d.tile == 0 and AUTOTUNE and pc.Cout // pc.groups > 4:
         key = (N, H, W, C0, C1, pc.Cout, pc.groups, pc.kh, pc.kw, sh, sw, ph, pw, dh, dw, d.upsample, d.epi, d.out_nchw, d.precision,
                d.in_split, d.out_split, d.w_il, int(bool(osp) and out_s.il) + 2 * int(bool(osp) and out_s.h), d.pad_mode, d.in_relu,
-               d.ps_r, d.ps_c, d.ps_H, d.ps_W, d.ky_skip_n0, int(d.ld_bias > 0), d.tile_order, d.aux_per_image)
+               d.ps_r, d.ps_c, d.ps_H, d.ps_W, d.ky_skip_n0, int(d.ld_bias > 0), d.tile_order, d.aux_per_image, d.dual_n0)
         best = _tile_cache.get(key)
         if best is not None and key not in _tile_validated:
             # A cached / loaded tile must belong to the kernel family the GEOMETRY routes this layer to (taps-routed layers: codes 200-299,
@@ -506,6 +513,43 @@ def _autotune(d, args, candidates=None):
             best, best_ms = TILE[name], ms
     d.tile = 0
     return best
+
+
+_bgemm_tiles = {}
+BGEMM_CANDIDATES = ["128x128w", "128x128eaw", "128x128x8w", "128x128x8eaw", "256x128w", "256x128eaw", "256x128x16w", "256x128x16eaw"]
+
+
+def batched_gemm_nt(a, b, out, scale=1.0):
+    """out[g] = scale * a[g] @ b[g]^T for interleaved Splits a [G, M, K], b [G, N, K] and an fp32 out [G, M, N]: ONE fgt_conv2d launch in the batched
+    GEMM mode of ABI 8 (fgt_conv_desc.gb_*; csrc/conv_wide.hip) — b is used as it lies, as the weight image of its group.  bf16x3 products, fp32
+    accumulation over K in 32-channel steps.  RAFT's all-pairs correlation volume (RAFT/corr.py:52-60) for a whole pair batch."""
+    assert isinstance(a, Split) and isinstance(b, Split) and a.il and b.il, "batched_gemm_nt: interleaved Splits"
+    G, M, K = a.shape
+    Gb, N, Kb = b.shape
+    assert (Gb, Kb) == (G, K) and tuple(out.shape) == (G, M, N) and out.is_contiguous() and out.dtype == torch.float32
+    assert a.data.is_contiguous() and b.data.is_contiguous() and K % 32 == 0 and N % 8 == 0
+    _require_dev(out)
+    d = ConvDesc()
+    d.N, d.H, d.W = 1, 1, M
+    d.C0, d.ld0, d.off0 = G * K, 2 * K, 0
+    d.Cout, d.groups = G * N, G
+    d.kh = d.kw = d.sh = d.sw = d.dh = d.dw = 1
+    d.Ho, d.Wo, d.ldo = 1, M, N
+    d.slope, d.out_scale = 0.2, float(scale)
+    d.Kpad, d.Npad = K, ceil_to(N, 128)
+    d.precision, d.in_split, d.w_il = PREC["bf16x3"], 2, 1
+    d.gb_x0, d.gb_w, d.gb_o = M * 2 * K, N * 2 * K, M * N
+    args = (C.byref(d), _ptr(a.data), _ptr(None), _ptr(b.data), _ptr(None), _ptr(None), _ptr(None), _ptr(None), _ptr(out), _ptr(None))
+    key = (G, M, N, K)
+    best = _bgemm_tiles.get(key)
+    if best is None:
+        if torch.cuda.is_current_stream_capturing():
+            best = TILE["128x128eaw"]
+        else:
+            best = _bgemm_tiles[key] = _autotune(d, args, BGEMM_CANDIDATES) or TILE["128x128w"]
+    d.tile = best
+    check(_lib.lib().fgt_conv2d(*args, _stream()), "fgt_conv2d (batched GEMM)")
+    return out
 
 
 def linear(x, pc, **kw):

@@ -121,6 +121,8 @@ class RAFT(nn.Module):
         self._packed, self._key = None, None
         self.use_graph = os.environ.get("FGT_GRAPHS", "0") == "1"
         self.hoist_context = os.environ.get("FGT_RAFT_HOIST", "1") != "0"
+        self.fuse_zr = os.environ.get("FGT_RAFT_ZR", "1") != "0"                 # z || r of a GRU half as one two-headed conv (needs the hoisted context)
+        self.batched_corr = os.environ.get("FGT_RAFT_BCORR", "1") != "0"         # the pair batch's correlation volumes as ONE batched GEMM launch
         self._graphs = {}
 
     # ------------------------------------------------------------------ packing
@@ -169,6 +171,15 @@ class RAFT(nn.Module):
                 P["gru"][n] = self._pk(cv)
                 P["gru_it"][n] = PackedConv(torch.cat([w[:, :hd], w[:, 2 * hd:]], 1), None)
                 P["gru_ctx"][n] = PackedConv(w[:, hd:2 * hd], b)
+            # z and r of a GRU half read the same hx (update.py:46-49, 53-56): ONE conv with the output channels [z | r] and a two-headed epilogue
+            # (fgt_conv_desc.dual_n0: sigmoid -> z as fp32, sigmoid * h -> r * h as a split tensor) instead of two Cout = 128 launches — the im2col
+            # rows are fetched once and the tiles are 256 channels wide.  FGT_RAFT_ZR=0: the two launches.
+            for s_ in ("1", "2"):
+                wz, wr = getattr(u.gru, "convz" + s_).weight.detach(), getattr(u.gru, "convr" + s_).weight.detach()
+                bz, br = getattr(u.gru, "convz" + s_).bias.detach(), getattr(u.gru, "convr" + s_).bias.detach()
+                wzr = torch.cat([wz, wr], 0)
+                P["gru_it"]["convzr" + s_] = PackedConv(torch.cat([wzr[:, :hd], wzr[:, 2 * hd:]], 1), None)
+                P["gru_ctx"]["convzr" + s_] = PackedConv(wzr[:, hd:2 * hd], torch.cat([bz, br], 0))
             P["fh"] = (self._pk(u.flow_head.conv1), self._pk(u.flow_head.conv2))
             P["mask"] = (self._pk(u.mask[0]), self._pk(u.mask[2]))
             self._packed, self._key = P, key
@@ -239,9 +250,16 @@ class RAFT(nn.Module):
         # all-pairs correlation volume (corr.py:52-60) as a GEMM against fmap2, then the avg-pool pyramid
         n = h8 * w8
         vol = torch.empty(B * n, n, dtype=torch.float32, device=dev)
-        for b in range(B):
-            pc = PackedConv(fmap2[b].reshape(n, 256), None)
-            ops.linear(fmap1[b].reshape(n, 256), pc, out=vol[b * n:(b + 1) * n], out_scale=1.0 / 16.0)
+        if self.batched_corr and ops.DEFAULT_CONV_PRECISION != "fp32" and n % 8 == 0:
+            # bf16x3: both feature maps split once (the same hi / lo values the per-pair GEMM derived from them), then ONE launch for the batch:
+            # group b multiplies fmap1[b] with fmap2[b] as it lies (fgt_conv_desc.gb_*): no per-pair weight packing, B x the tiles per launch
+            f1s = ops.split(fmap1.reshape(B * n, 256), interleave=True, h=False)
+            f2s = ops.split(fmap2.reshape(B * n, 256), interleave=True, h=False)
+            ops.batched_gemm_nt(f1s.view(B, n, 256), f2s.view(B, n, 256), vol.view(B, n, n), scale=1.0 / 16.0)
+        else:
+            for b in range(B):
+                pc = PackedConv(fmap2[b].reshape(n, 256), None)
+                ops.linear(fmap1[b].reshape(n, 256), pc, out=vol[b * n:(b + 1) * n], out_scale=1.0 / 16.0)
         pyr = [vol]
         hh, ww = h8, w8
         for _ in range(self.corr_levels - 1):
@@ -276,12 +294,14 @@ class RAFT(nn.Module):
             ops.split(net, out=net_s)
             motion_s, flow_s = xbuf_s.channels(128, 256), xbuf_s.channels(254, 256)
         hoist = self.hoist_context
+        zr = False
         pads = {"1": (0, 2), "2": (2, 0)}
         if hoist:
             # the context term of every GRU conv, once per pair: conv over inp + bias, fp32 maps [rows, 128] (update.py:45-58 restricted to hx[:, 128:256])
             GI, GC = P["gru_it"], P["gru_ctx"]
             inp_in = s4(xbuf_s.channels(0, 128)) if sc else m4(xbuf)[..., :128]
-            ctx = {g_ + s_: ops.conv2d(inp_in, GC["conv" + g_ + s_], pad=pads[s_]) for s_ in ("1", "2") for g_ in ("z", "r", "q")}
+            zr = self.fuse_zr and sc
+            ctx = {g_ + s_: ops.conv2d(inp_in, GC["conv" + g_ + s_], pad=pads[s_]) for s_ in ("1", "2") for g_ in (("zr", "q") if zr else ("z", "r", "q"))}
             x_it = s4(motion_s) if sc else m4(xbuf)[..., 128:]
         ups = []
         for it in range(iters):
@@ -301,9 +321,14 @@ class RAFT(nn.Module):
                 # SepConvGRU (update.py:36-60): horizontal then vertical pass; z stays fp32 (an epilogue operand), r * h goes on split, the new
                 # hidden state is written in both forms (fp32: the next pass's epilogue operands and the heads; split: the next convs' input)
                 for s_, pad in (("1", (0, 2)), ("2", (2, 0))):
-                    gz, gr, gq = ((GI["conv" + g_ + s_], dict(x1=x_it, bias_map=ctx[g_ + s_])) if hoist else (G["conv" + g_ + s_], dict(x1=s4(xbuf_s))) for g_ in "zrq")
-                    z = ops.conv2d(s4(net_s), gz[0], pad=pad, act="sigmoid", **gz[1])
-                    ops.conv2d(s4(net_s), gr[0], pad=pad, act="sigmoid", epi="mul", aux1=net, out_split="only", out_s=rh_s, **gr[1])
+                    if zr:
+                        gq = (GI["convq" + s_], dict(x1=x_it, bias_map=ctx["q" + s_]))
+                        z, _ = ops.conv2d(s4(net_s), GI["convzr" + s_], x1=x_it, bias_map=ctx["zr" + s_], pad=pad, act="sigmoid", epi="mul", aux1=net,
+                                          out_split="both", out_s=s4(rh_s), dual=True)
+                    else:
+                        gz, gr, gq = ((GI["conv" + g_ + s_], dict(x1=x_it, bias_map=ctx[g_ + s_])) if hoist else (G["conv" + g_ + s_], dict(x1=s4(xbuf_s))) for g_ in "zrq")
+                        z = ops.conv2d(s4(net_s), gz[0], pad=pad, act="sigmoid", **gz[1])
+                        ops.conv2d(s4(net_s), gr[0], pad=pad, act="sigmoid", epi="mul", aux1=net, out_split="only", out_s=rh_s, **gr[1])
                     net, _ = ops.conv2d(s4(rh_s), gq[0], pad=pad, act="tanh", epi="gru", aux1=z, aux2=net, out_split="both", out_s=net_s, **gq[1])
                     net = net.view(rows, 128)
                 d = ops.conv2d(s4(net_s), P["fh"][0], pad=1, act="relu")

@@ -145,6 +145,20 @@ typedef struct fgt_conv_desc {
                              * read the SAME weight rows (one N tile's K x 128 weights stay in the 4 MB L2) at the price of streaming the input once
                              * per N tile.  For layers whose whole weight matrix does not fit the L2 (the fold convolutions: 7 and 21 MB).  Results
                              * are identical (the order of tiles, not of any sum) */
+    /* ---- ABI 8 */
+    int dual_n0;            /* 0: off | n0 > 0 (with FGT_EPI_MUL, out_split = 2, groups = 1, split inputs, Cout = 2*n0, n0 % 64 == 0: a wavefront's columns lie in one head):
+                             * TWO heads in one convolution.  Columns [0, n0): act(v) -> fp32 `out` channel ooff + n, no combine; columns [n0, 2*n0):
+                             * act(v) * aux1[m, n - n0] -> split `out_s` channel ooff_s + n - n0.  RAFT's SepConvGRU: z = sigmoid(convz(hx)) and
+                             * r * h = sigmoid(convr(hx)) * h read the same hx (RAFT/update.py:46-49, 53-56): one Cout = 256 launch per GRU half
+                             * instead of two of 128, the im2col rows fetched once. */
+    int reserved8;          /* 0 (keeps the 8-byte fields below aligned without implicit padding)                                                    */
+    long long gb_x0, gb_w, gb_o;
+                            /* all 0: off | BATCHED GEMM (needs in_split = 2, w_il = 1, a "wide" tile code, 1 x 1, stride 1, one source, N = 1, fp32 output,
+                             * no epilogue / bias / scale, Cout/groups % 8 == 0): group g multiplies ITS OWN rows and ITS OWN weights,
+                             *   out[g*gb_o + m*ldo + ooff + n] = out_scale * sum_k x0[g*gb_x0 + m*ld0 + k] * w[g*gb_w + n*2*Kpad + k]     (m < H*W, n < Cout/groups)
+                             * gb_x0 / gb_w in bf16 elements, gb_o in floats; C0 = groups * K.  The weight operand of a group is any [Cout/groups, 2*Kpad]
+                             * interleaved split tensor — e.g. the OTHER frame's feature map as a conv epilogue wrote it: RAFT's all-pairs correlation
+                             * corr[b] = fmap1[b] . fmap2[b]^T / sqrt(256) (RAFT/corr.py:52-60) for a whole pair batch in one launch, no weight packing. */
 } fgt_conv_desc;
 
 #define FGT_PREC_FP32 0

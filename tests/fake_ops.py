@@ -86,9 +86,24 @@ def _dense_weight(pc):
 
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
            epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None,
-           out_split=None, out_s=None, out_il=False, out_h=None, ps=None, ky_skip_n0=0, aux_per_image=False, n_alg=0, bias_map=None, tile_order=0):
+           out_split=None, out_s=None, out_il=False, out_h=None, ps=None, ky_skip_n0=0, aux_per_image=False, n_alg=0, bias_map=None, tile_order=0,
+           dual=False):
     """ps = (r, c, g0, Hf, Wf): the sub-pixel output of fgt_conv_desc.ps_r (fold as a convolution); ky_skip_n0 / n_alg change no value;
-    bias_map replaces pc.bias by an [N, Ho, Wo, Cout] map (fgt_conv_desc.ld_bias)."""
+    bias_map replaces pc.bias by an [N, Ho, Wo, Cout] map (fgt_conv_desc.ld_bias).
+    dual (fgt_conv_desc.dual_n0 = Cout / 2): head 0 = act(v) of the first half of the columns (fp32), head 1 = act(v) * aux1 of the second (Split)."""
+    if dual:
+        assert epi == "mul" and out_split == "both" and ps is None and pc.groups == 1
+        y = conv2d(x, pc, x1, stride, pad, dil, upsample, pad_mode, in_relu, act, slope, None, None, None, act2, out_scale, None, bias_map=bias_map)
+        h = pc.Cout // 2
+        y0 = y[..., :h].contiguous()
+        y1 = y[..., h:] * aux1.reshape(y.shape[0], y.shape[1], y.shape[2], h)
+        if out is not None:
+            out.copy_(y0.reshape(out.shape))
+            y0 = out
+        if out_s is not None:
+            out_s.put(y1.reshape(out_s.x.shape))
+            return y0, out_s
+        return y0, Split(y1.contiguous(), out_h)
     if out_split:
         assert not out_nchw
         y = conv2d(x, pc, x1, stride, pad, dil, upsample, pad_mode, in_relu, act, slope, epi, aux1, aux2, act2, out_scale, out,
@@ -170,6 +185,12 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     if out is None:
         return y.contiguous()
     out.copy_(y.reshape(out.shape))
+    return out
+
+
+def batched_gemm_nt(a, b, out, scale=1.0):
+    """out[g] = scale * a[g] @ b[g]^T (fgt_conv_desc.gb_*: ops.batched_gemm_nt)."""
+    out.copy_(torch.matmul(a.x, b.x.transpose(1, 2)) * scale)
     return out
 
 

@@ -154,6 +154,30 @@ def test_config2_spatial_block_t10_order_one_tokens(prec, blk_tol, att_tol, dev,
     assert ea < att_tol and eb < blk_tol
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_config2_spatial_mhsa_three_streams_equal_one_stream_and_graph_replay(prec, dev, monkeypatch):
+    """The C2-sized SWMHSA call runs its value / key / query paths on three HIP streams (fgt_model.SPATIAL_STREAM_ROWS): the same kernels on
+    the same data — bit-identical to the single-stream order, repeatably (20 calls), and as a captured hipGraph (fork / join inside the capture)."""
+    from fgt_amd import fgt_model, ops
+    from fgt_amd.graph import GraphedCall
+    monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", prec)
+    monkeypatch.setattr(ops, "DEFAULT_ATTN_PRECISION", prec)
+    m, sd = _model(dev)
+    net = m.net
+    P = net.packed()
+    t, th, tw = 10, 20, 36
+    g = torch.Generator().manual_seed(99)
+    x, f = torch.randn(t * th * tw, 512, generator=g).to(dev), torch.randn(t * th * tw, 256, generator=g).to(dev)
+    monkeypatch.setattr(fgt_model, "SPATIAL_STREAM_ROWS", 0)
+    one = net._spatial_attention(x, f, P["s0"], t, th, tw).clone()
+    monkeypatch.setattr(fgt_model, "SPATIAL_STREAM_ROWS", 32768)
+    for _ in range(20):
+        assert torch.equal(net._spatial_attention(x, f, P["s0"], t, th, tw), one)
+    gc = GraphedCall(lambda a, b: net._spatial_attention(a, b, P["s0"], t, th, tw), [x, f])
+    for _ in range(5):
+        assert torch.equal(gc(x, f), one)
+
+
 def test_config2_temporal_block_t10_bf16x3(dev, monkeypatch):
     """The temporal counterpart at the same shape (TMHSA t = 10: zone length 1800, below the 8-wavefront switch)."""
     from fgt_amd import ops

@@ -282,3 +282,76 @@ def test_flow_stages_at_bench_batch_sizes_equal_small_batches(prec, dev, monkeyp
     rep = ops.solver_report("laplace_fill")
     print(f"[parity] RAFT batch 64 == batch 4 and LAFC 16 == 4 pivots at {W}x{H} ({prec}): identical; fill {rep}")
     assert rep["solver"] == "onchip" and rep["nan_filled"] == 0
+
+
+# ---- round 6 (ABI 8): the pair batch's correlation volumes as one batched GEMM; z || r of a GRU half as one two-headed conv
+@pytest.mark.parametrize("B,n", [(3, 6480), (2, 320), (5, 1624)])
+def test_batched_correlation_gemm_equals_per_pair_gemm(B, n, dev, monkeypatch):
+    """RAFT/corr.py:52-60: corr[b] = fmap1[b] . fmap2[b]^T / 16.  ops.batched_gemm_nt (fgt_conv_desc.gb_*: group b multiplies its own rows with the
+    other frame's feature map AS IT LIES — an interleaved split tensor is a valid weight image) against the per-pair fgt_conv2d GEMM with packed
+    weights: the same bf16x3 products in the same order — bit for bit; and against fp64 on the fp32 inputs within the bf16x3 bound."""
+    from fgt_amd import ops
+    from fgt_amd.ops import PackedConv
+    monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", "bf16x3")
+    g = torch.Generator().manual_seed(B * 1000 + n)
+    f1, f2 = torch.randn(B, n, 256, generator=g).to(dev), torch.randn(B, n, 256, generator=g).to(dev)
+    vol = torch.full((B, n, n), float("nan"), device=dev)
+    ops.batched_gemm_nt(ops.split(f1.view(B * n, 256), interleave=True, h=False).view(B, n, 256),
+                        ops.split(f2.view(B * n, 256), interleave=True, h=False).view(B, n, 256), vol, scale=1.0 / 16.0)
+    ref = torch.empty_like(vol)
+    for b in range(B):
+        ops.linear(f1[b], PackedConv(f2[b], None), out=ref[b], out_scale=1.0 / 16.0)
+    assert torch.equal(vol, ref)
+    r64 = torch.matmul(f1[0].double(), f2[0].double().t()) / 16.0
+    assert (vol[0].double() - r64).abs().max().item() < 2e-5 * r64.abs().max().item()
+    # every wide tile: same values
+    for t in ops.BGEMM_CANDIDATES:
+        monkeypatch.setattr(ops, "_bgemm_tiles", {(B, n, n, 256): ops.TILE[t]})
+        v2 = torch.full((B, n, n), float("nan"), device=dev)
+        ops.batched_gemm_nt(ops.split(f1.view(B * n, 256), interleave=True, h=False).view(B, n, 256),
+                            ops.split(f2.view(B * n, 256), interleave=True, h=False).view(B, n, 256), v2, scale=1.0 / 16.0)
+        assert torch.equal(v2, vol), t
+
+
+@pytest.mark.parametrize("k,pad", [((1, 5), (0, 2)), ((5, 1), (2, 0)), ((3, 3), (1, 1))])
+def test_two_headed_conv_equals_two_convs(k, pad, dev, monkeypatch):
+    """fgt_conv_desc.dual_n0: [z | r] output channels in one launch, head 0 -> sigmoid as fp32, head 1 -> sigmoid * h as a split tensor, with a
+    bias MAP and two sources (RAFT's GRU: update.py:46-49, 53-56).  Against the two separate launches: torch.equal (the tap family's tiles are
+    bit-identical to each other; columns are independent)."""
+    from fgt_amd import ops
+    from fgt_amd.ops import PackedConv
+    monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", "bf16x3")
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 30, 54
+    rows = B * H * W
+    h = torch.randn(rows, 128, generator=g).to(dev)
+    m = torch.randn(rows, 128, generator=g).to(dev)
+    wz, wr = (torch.randn(128, 256, *k, generator=g) * 0.03).to(dev), (torch.randn(128, 256, *k, generator=g) * 0.03).to(dev)
+    bm = torch.randn(rows, 256, generator=g).to(dev)
+    hs, ms = ops.split(h, h=False), ops.split(m, h=False)
+    v4 = lambda s: s.view(B, H, W, 128)
+    z_ref = ops.conv2d(v4(hs), PackedConv(wz, None), x1=v4(ms), bias_map=bm[:, :128].contiguous(), pad=pad, act="sigmoid")
+    rh_ref = ops.conv2d(v4(hs), PackedConv(wr, None), x1=v4(ms), bias_map=bm[:, 128:].contiguous(), pad=pad, act="sigmoid", epi="mul", aux1=h, out_split="only")
+    z, rh = ops.conv2d(v4(hs), PackedConv(torch.cat([wz, wr], 0), None), x1=v4(ms), bias_map=bm, pad=pad, act="sigmoid", epi="mul", aux1=h,
+                       out_split="both", dual=True)
+    assert z.shape == (B, H, W, 128) and rh.shape[-1] == 128
+    assert torch.equal(z, z_ref)
+    assert torch.equal(rh.data, rh_ref.data)
+    zt = torch.sigmoid(F.conv2d(torch.cat([h, m], 1).view(B, H, W, 256).permute(0, 3, 1, 2).double(), wz.double(), None, 1, pad).permute(0, 2, 3, 1) + bm[:, :128].view(B, H, W, 128).double())
+    assert (z.double() - zt).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("prec", ["bf16x3"])
+def test_raft_fused_zr_and_batched_correlation_equal_the_separate_launches(prec, dev, monkeypatch):
+    from fgt_amd import ops
+    monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", prec)
+    g = load_golden("raft_128x160_it6.npz")
+    outs = {}
+    for new in (True, False):
+        m = raft_model.RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).eval()
+        m.load_state_dict(_sd("raft_state_keys.json"), strict=True)
+        m = m.to(dev)
+        m.fuse_zr = m.batched_corr = new
+        outs[new] = m(g["image1"].to(dev), g["image2"].to(dev), iters=6, test_mode=True)
+        assert report(f"raft flow_up zr/bcorr={new} {prec}", outs[new][1], g["flow_up"])[1] < 1e-3
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
