@@ -285,8 +285,7 @@ def _optional_blocks(full, line):
             c2 = c4.get("c2_spatial_mhsa")
             if c2:
                 cc["c2_spatial_mhsa"] = {k: c2[k] for k in ("ms_per_module", "mfma_frac_module_wall", "mfma_frac_mfma_kernels_only", "mfma_frac_attention_kernel",
-                                                            "hbm_frac_attention_kernel", "linears_share_of_flops", "error", "streams", "mfma_frac_module_wall_graph_replay",
-                                                            "mfma_frac_module_wall_one_stream") if k in c2}
+                                                            "hbm_frac_attention_kernel", "linears_share_of_flops", "error", "streams_in_graph_replay", "mfma_frac_module_wall_graph_replay") if k in c2}
                 if "fp32_exact" in c2:
                     cc["c2_spatial_mhsa"]["fp32_exact_mfma_frac_module_wall"] = c2["fp32_exact"].get("mfma_frac_module_wall")
                     cc["c2_spatial_mhsa"]["fp32_exact_mfma_frac_module_wall_graph_replay"] = c2["fp32_exact"].get("mfma_frac_module_wall_graph_replay")

@@ -133,16 +133,13 @@ def c2_spatial_mhsa(dev, model, prec, t=10, reps=5):
     f = torch.randn(t * th * tw, 256, generator=g).to(dev)
     fn = lambda: net._spatial_attention(x, f, P["s0"], t, th, tw)
     dt, _ = _timed(fn, reps=reps, warm=2)
-    # the same call on ONE stream (the launch order of rounds 1-5) and as a captured hipGraph (the three-stream fork / join inside the capture):
-    # a module call this small is a dependency graph of under-filled launches — what the wall time measures is how much of it runs side by side
+    # ... and as a captured hipGraph (inside a capture the module forks its value / key paths onto two more streams: a call this small is a
+    # dependency graph of under-filled launches, and enqueued eagerly it is bound by the host: profiles/r06_run6_*)
     from fgt_amd import fgt_model as _fm
     from fgt_amd.graph import GraphedCall
     variants = {}
+    rows_saved = _fm.SPATIAL_STREAM_ROWS
     try:
-        rows_saved = _fm.SPATIAL_STREAM_ROWS
-        _fm.SPATIAL_STREAM_ROWS = 0
-        variants["one_stream_ms"] = round(_timed(fn, reps=reps, warm=2)[0] * 1e3, 4)
-        _fm.SPATIAL_STREAM_ROWS = rows_saved
         gcall = GraphedCall(lambda a, b: net._spatial_attention(a, b, P["s0"], t, th, tw), [x, f])
         gfn = lambda: gcall.graph.replay()
         variants["graph_replay_ms"] = round(_timed(gfn, reps=max(reps, 5), warm=2)[0] * 1e3, 4)
@@ -169,9 +166,8 @@ def c2_spatial_mhsa(dev, model, prec, t=10, reps=5):
             "mfma_frac_linears": round(tf(cfl, cms) / peak, 4), "mfma_frac_attention_kernel": round(tf(afl, ams) / peak, 4),
             "hbm_frac_attention_kernel": round(aby / max(ams * 1e-3, 1e-12) / 1e9 / PEAK_HBM, 4),
             "launches": {"linear_gemm": cn, "attention": an}, "peak_tflops": peak,
-            "streams": 3 if 0 < t * th * tw <= _fm.SPATIAL_STREAM_ROWS else 1, **variants,
-            **({"mfma_frac_module_wall_graph_replay": round(tf(cfl + afl, variants["graph_replay_ms"]) / peak, 4)} if "graph_replay_ms" in variants else {}),
-            **({"mfma_frac_module_wall_one_stream": round(tf(cfl + afl, variants["one_stream_ms"]) / peak, 4)} if "one_stream_ms" in variants else {})}
+            "streams_in_graph_replay": 3 if 0 < t * th * tw <= _fm.SPATIAL_STREAM_ROWS else 1, **variants,
+            **({"mfma_frac_module_wall_graph_replay": round(tf(cfl + afl, variants["graph_replay_ms"]) / peak, 4)} if "graph_replay_ms" in variants else {})}
 
 
 def run_stages(dev, prec="bf16x3", frames=80, H=240, W=432, fgt_ms=None, with_cpu=True, reps=2, fill_iters=None, blend_iters=None, fgt_model=None):

@@ -32,6 +32,7 @@ ENC_MERGE_GROUPS = os.environ.get("FGT_ENC_MERGE_GROUPS", "1") != "0"
 # SWMHSA on three HIP streams when a call is too small to fill the chip (see FGT._spatial_attention): at most this many token rows per call
 # (BASELINE config C2, t = 10: 7 200 rows; the benchmark's step batches 136 frames = 97 920 rows per call and stays on one stream).  0: never
 SPATIAL_STREAM_ROWS = int(os.environ.get("FGT_SPATIAL_STREAM_ROWS", "32768"))
+SPATIAL_STREAMS_EAGER = os.environ.get("FGT_SPATIAL_STREAMS_EAGER", "0") == "1"      # (tests / measurements: the three streams outside a capture too)
 # tile order of the fold convolutions (fgt_conv_desc.tile_order): 1 = N-major inside an XCD (their 7 / 21 MB weight matrices do not fit the L2)
 FOLD_TILE_ORDER = int(os.environ.get("FGT_FOLD_TILE_ORDER", "1"))
 
@@ -546,7 +547,9 @@ class FGT(nn.Module):
         # v: the value path — so the under-filled launches share the chip (14 launches deep becomes 5).  Same kernels on the same data: bit-identical
         # to the single-stream order (tests/test_fgt_gpu.py); capturable (fork / join on the capturing stream).  Large calls (the clip runner's
         # 136-frame batches) fill the chip per launch and stay on one stream.
-        par = x.is_cuda and 0 < R <= SPATIAL_STREAM_ROWS
+        # Only inside a stream capture: enqueued eagerly the module is bound by the host (15 launches + 6 cross-stream waits at 5-10 us each:
+        # 0.38 ms on three streams against 0.30 on one, profiles/r06_run6_*), as a replayed graph by the GPU (0.26 -> 0.22 ms).
+        par = x.is_cuda and 0 < R <= SPATIAL_STREAM_ROWS and (SPATIAL_STREAMS_EAGER or torch.cuda.is_current_stream_capturing())
         if par:
             main = torch.cuda.current_stream()
             s_k, s_v = self._side_streams(dev)

@@ -171,6 +171,7 @@ def test_config2_spatial_mhsa_three_streams_equal_one_stream_and_graph_replay(pr
     monkeypatch.setattr(fgt_model, "SPATIAL_STREAM_ROWS", 0)
     one = net._spatial_attention(x, f, P["s0"], t, th, tw).clone()
     monkeypatch.setattr(fgt_model, "SPATIAL_STREAM_ROWS", 32768)
+    monkeypatch.setattr(fgt_model, "SPATIAL_STREAMS_EAGER", True)
     for _ in range(20):
         assert torch.equal(net._spatial_attention(x, f, P["s0"], t, th, tw), one)
     gc = GraphedCall(lambda a, b: net._spatial_attention(a, b, P["s0"], t, th, tw), [x, f])
