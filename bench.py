@@ -294,7 +294,7 @@ def _optional_blocks(full, line):
                     cc["c2_spatial_mhsa"]["t136_hbm_frac_attention_kernel"] = c2["at_step_size_t136"].get("hbm_frac_attention_kernel")
             line["c4"] = cc
     for k in ("phases_ms", "weak_scaling_clip_per_rank", "strong_scaling_same_clip", "strong_scaling_ideal", "pipeline_sharded", "feature_exchange",
-              "strong_scaling_modes", "host_launch_us_probe"):
+              "strong_scaling_modes", "host_launch_us_probe", "rccl_preflight"):
         if k in full:
             v = full[k]
             if k == "strong_scaling_ideal":
@@ -323,7 +323,7 @@ def compact_line(full, detail_path=None):
         line["detail"] = detail_path
     # safety net: never exceed the limit — drop optional blocks from the least important end, then fall back to the contract keys alone
     for k in ("phases_ms", "f16", "rooflines", "strong_scaling_ideal", "c4", "fp32_exact", "parity_vs_cpu_oracle", "pipeline_sharded", "strong_scaling_same_clip",
-              "weak_scaling_clip_per_rank", "feature_exchange", "strong_scaling_modes"):
+              "weak_scaling_clip_per_rank", "feature_exchange", "strong_scaling_modes", "rccl_preflight"):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
         if k in line:
@@ -651,7 +651,30 @@ def main():
     # hangs, the line goes out with the first one's result as the headline instead of the clip-per-rank number.
     strong_err = None
     strong_modes = {}
+    preflight = None
     if world > 1:
+        # ---- collective pre-flight (fgt_amd/preflight.py): the sharded clip's three collectives at its sizes, 3 reps each, every call under a 10-s
+        # watchdog — a first run on RCCL that hangs or fails still yields a line that says WHICH collective it was
+        from fgt_amd.preflight import collective_preflight
+        per = -(-args.frames // world)
+
+        def preflight_hang(name, partial):
+            if rank == 0:
+                partial["failed"] = name
+                partial["checks"][name] = {"error": "no completion within the watchdog (collective hung)"}
+                emit(dict(assemble(weak_res, weak=True, strong_error=f"collective pre-flight: {name} hung"), rccl_preflight=partial))
+            os._exit(0)
+
+        preflight = collective_preflight(dev, rank, world, frame_floats=(args.height // 4) * (args.width // 4) * 128, frames_per_rank=min(per, args.encode_chunk),
+                                         u8_bytes_per_rank=2 * 6 * 3 * args.height * args.width, reps=3, timeout_s=10.0, on_hang=preflight_hang)
+        if preflight["failed"] and not os.environ.get("FGT_EXCHANGE"):
+            # the all-to-all failed but the all-gathers work: only the all-gather exchange is attempted (the conservative path); an all-gather
+            # failure leaves nothing to shard with — the clip-per-rank line goes out with the reason
+            if preflight["failed"].startswith("all_to_all"):
+                os.environ["FGT_EXCHANGE"] = "allgather"
+            else:
+                strong_err = f"collective pre-flight failed: {preflight['failed']}: {preflight['checks'][preflight['failed']].get('error')}"
+    if world > 1 and not (preflight and preflight["failed"] and not preflight["failed"].startswith("all_to_all")):
         modes = [os.environ["FGT_EXCHANGE"].lower()] if os.environ.get("FGT_EXCHANGE") else ["allgather", "a2a"]
         for mode in modes:
             def give_up(mode=mode):
@@ -711,6 +734,11 @@ def main():
         if world > 1:
             out["feature_exchange"] = getattr(strong_res["runner"], "exchange", None) if strong_res is not None else None
             out["strong_scaling_modes"] = strong_modes        # the sharded clip per feature exchange (the headline is the faster one)
+            out["rccl_preflight"] = preflight
+            if not headline_weak:
+                # (the headline of an N > 1 run is the FASTER of the two exchanges — say which one in the contract keys)
+                out["config"]["feature_exchange"] = strong_res.get("exchange")
+                out["config"]["headline_is_best_of_exchanges"] = sorted(strong_modes)
             bound = ideal_speedup(n_sched, world)
             per = -(-args.frames // world)
             side = lambda res, weak: {"value": round(args.frames * args.steps / res["dt"] * (world if weak else 1), 3), "unit": "frames/s",
