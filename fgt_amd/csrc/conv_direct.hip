@@ -91,16 +91,28 @@ int launch_direct(const ConvP& p, int lpp_log2, hipStream_t s) {
 // staged through LDS 16 channels at a time ([pixel][16 + 4 pad] floats: conflict-free float4 reads), every thread
 // accumulates its pixel's COUT outputs with weights fetched through the scalar cache (uniform addresses).
 // Input bytes are read from HBM/L2 once per tile (halo overhead 1.33x) instead of 9x.
-constexpr int TH = 8, TW = 32, CCH = 16, PLD = CCH + 4;
+// Round 6: rocprofv3 counted 2.05 x the algorithmic bytes for this kernel (round 5; 1.33 x is the halo).  Two causes, two changes: (i) neighbouring
+// tiles sat on different XCDs, each fetching the shared halo into its own L2 -> XCD-contiguous tile order (below): RAFT's flow head 96.7 -> 78.2 us
+// per launch, decoder.final 474 -> 447; (ii) a 16-channel chunk uses HALF of each 128-byte line per pass -> a 32-channel chunk variant
+// (FGT_CONV_SMALL_C32=1): counter traffic 1.00 x the algorithmic bytes, but 49 KB of LDS per workgroup instead of 27 — 116 vs 78 us and 472 vs 447:
+// the kernel is bound by its per-chunk barrier chain, not by the bytes, so the variant stays off (profiles/r06_run7_*).
+constexpr int TH = 8, TW = 32;
 
 // XH: the input map is an fp16 tensor (fgt_conv_desc.in_split = 3: ld / off in fp16 elements) — the f16 mode hands the decoder's last
 // feature map (64 channels at full resolution: the largest activation of the path) over at 2 B per value; weights and arithmetic stay fp32.
-template <int COUT, bool XH>
+template <int COUT, bool XH, int CCH>
 __global__ void __launch_bounds__(256) conv3x3_tiled_kernel(const ConvP p) {
+    constexpr int PLD = CCH + 4;
     __shared__ __attribute__((aligned(16))) float tile[(TH + 2) * (TW + 2) * PLD];
     const fgt_conv_desc& d = p.d;
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, n_img = blockIdx.z;
+    // XCD-contiguous tile order (1-D grid, a multiple of 8 workgroups): workgroup i runs on XCD i % 8; XCD x takes the x-th eighth of the tiles in
+    // (image, tile row, tile column) order, so the halo rows / columns two neighbouring tiles share are fetched into ONE L2 instead of two
+    const int ntx = (d.W + TW - 1) / TW, nty = (d.H + TH - 1) / TH;
+    const int lt = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (lt >= ntx * nty * d.N) return;
+    const int n_img = lt / (ntx * nty), r_ = lt - n_img * (ntx * nty);
+    const int x0 = (r_ % ntx) * TW, y0 = (r_ / ntx) * TH;
     const float* __restrict__ wgt = p.w;
     float acc[COUT];
 #pragma unroll
@@ -115,7 +127,7 @@ __global__ void __launch_bounds__(256) conv3x3_tiled_kernel(const ConvP p) {
             const int idx = tid + l * 256;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < (TH + 2) * (TW + 2) * (CCH / 4)) {
-                const int pix = idx >> 2, c4 = idx & 3;
+                const int pix = idx / (CCH / 4), c4 = idx % (CCH / 4);
                 const int py = pix / (TW + 2), px = pix - py * (TW + 2);
                 const int gy = y0 + py - 1, gx = x0 + px - 1;
                 if ((unsigned)gy < (unsigned)d.H && (unsigned)gx < (unsigned)d.W) {
@@ -142,7 +154,7 @@ __global__ void __launch_bounds__(256) conv3x3_tiled_kernel(const ConvP p) {
 #pragma unroll
         for (int l = 0; l < NLD; ++l) {
             const int idx = tid + l * 256;
-            if (idx < (TH + 2) * (TW + 2) * (CCH / 4)) *reinterpret_cast<float4*>(tile + (idx >> 2) * PLD + (idx & 3) * 4) = pre[l];
+            if (idx < (TH + 2) * (TW + 2) * (CCH / 4)) *reinterpret_cast<float4*>(tile + (idx / (CCH / 4)) * PLD + (idx % (CCH / 4)) * 4) = pre[l];
         }
         __syncthreads();
         if (c0 + CCH < p.Cg) fetch(c0 + CCH);
@@ -178,16 +190,19 @@ __global__ void __launch_bounds__(256) conv3x3_tiled_kernel(const ConvP p) {
 
 template <int COUT>
 int launch_tiled(const ConvP& p, hipStream_t s) {
-    dim3 grid(cdiv(p.d.W, TW), cdiv(p.d.H, TH), p.d.N);
-    if (p.d.in_split == 3) hipLaunchKernelGGL((conv3x3_tiled_kernel<COUT, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv3x3_tiled_kernel<COUT, false>), grid, dim3(256), 0, s, p);
+    dim3 grid((unsigned)(((long)cdiv(p.d.W, TW) * cdiv(p.d.H, TH) * p.d.N + 7) / 8 * 8));
+    static const bool c32_env = [] { const char* e = getenv("FGT_CONV_SMALL_C32"); return e && e[0] == '1'; }();      // (measurement switch: see above)
+    const bool c32 = c32_env && p.Cg % 32 == 0 && p.Cg0 % 32 == 0 && p.d.off0 % 4 == 0;
+    if (p.d.in_split == 3) hipLaunchKernelGGL((conv3x3_tiled_kernel<COUT, true, 16>), grid, dim3(256), 0, s, p);      // (fp16 maps: 32 channels are 64 bytes — already half a line per pass; unchanged)
+    else if (c32) hipLaunchKernelGGL((conv3x3_tiled_kernel<COUT, false, 32>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_tiled_kernel<COUT, false, 16>), grid, dim3(256), 0, s, p);
     return fgt_check_launch("conv3x3_tiled");
 }
 
 bool tiled_eligible(const ConvP& p) {
     const fgt_conv_desc& d = p.d;
     return d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.dh == 1 && d.dw == 1 && d.ph == 1 && d.pw == 1 && !d.upsample &&
-           d.pad_mode == 0 && p.Cg % CCH == 0 && d.N <= 65535 && d.H >= TH && d.W >= TW;
+           d.pad_mode == 0 && p.Cg % 16 == 0 && d.N <= 65535 && d.H >= TH && d.W >= TW;
 }
 
 }  // namespace

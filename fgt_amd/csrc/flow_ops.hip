@@ -10,6 +10,20 @@ inline int grid_for(long total, int block = 256) {
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
 }
 
+// XCD-contiguous work order for the gather kernels whose neighbouring work items read the SAME source rows (warp, forward-backward check).
+// Workgroup i is dispatched to XCD i % 8, each XCD has a private L2: with the plain order the three workgroups that touch an image row sit on
+// three XCDs and each fetches it from the fabric — rocprofv3 counted 2.66 x the algorithmic bytes for the clip's warps (round 5).  Here XCD x walks
+// a CONTIGUOUS eighth of every grid-stride pass, so a row's re-reads hit that XCD's L2.  (grids are multiples of 8: grid_for8)
+__device__ __forceinline__ long xcd_first_item() {
+    const int per = gridDim.x >> 3;
+    return ((long)(blockIdx.x & 7) * per + (blockIdx.x >> 3)) * blockDim.x + threadIdx.x;
+}
+inline int grid_for8(long total, int block = 256) {
+    long g = (total + block - 1) / block;
+    g = (g + 7) / 8 * 8;
+    return (int)(g < 8 ? 8 : (g > 16384 ? 16384 : g));
+}
+
 // Source pixel coordinate of output pixel (x, y), following the reference's arithmetic in fp32.
 //  align_corners = 0 / relative flow : LAFC/models/utils/fbConsistencyCheck.py:15-25 then grid_sample's
 //      unnormalise ((g + 1) * size - 1) / 2                      (linspace base grid is float64 -> float32)
@@ -54,7 +68,7 @@ __global__ void __launch_bounds__(256) warp_kernel(const float* __restrict__ img
     typedef float vec __attribute__((ext_vector_type(V)));
     const int cpv = C / V;
     const long total = (long)B * H * W * cpv;
-    for (long item = (long)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (long)gridDim.x * blockDim.x) {
+    for (long item = xcd_first_item(); item < total; item += (long)gridDim.x * blockDim.x) {
         const long pix = item / cpv;
         const int c = (int)(item - pix * cpv) * V;
         const int x = (int)(pix % W); const long r = pix / W;
@@ -94,7 +108,7 @@ __global__ void __launch_bounds__(256) warp_c2x2_kernel(const float* __restrict_
                                                         int align_corners, int absolute, float* __restrict__ out) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const long total = (long)B * H * W / 2;
-    for (long item = (long)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (long)gridDim.x * blockDim.x) {
+    for (long item = xcd_first_item(); item < total; item += (long)gridDim.x * blockDim.x) {
         const long pix = item * 2;
         const int x = (int)(pix % W); const long r = pix / W;
         const int y = (int)(r % H); const long b = r / H;
@@ -154,7 +168,7 @@ __device__ __forceinline__ void warp2(const float* src, const float* flw, long b
 __global__ void __launch_bounds__(256) fb_kernel(const float* ffw, const float* fbw, int B, int H, int W, float a1, float a2,
                                                  float* occ_fw, float* occ_bw) {
     const long total = (long)B * H * W;
-    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long)gridDim.x * blockDim.x) {
+    for (long pix = xcd_first_item(); pix < total; pix += (long)gridDim.x * blockDim.x) {
         const int x = (int)(pix % W); const long r = pix / W;
         const int y = (int)(r % H); const long b = r / H;
         float bwx, bwy, fwx, fwy;
@@ -355,7 +369,7 @@ extern "C" int fgt_warp(const float* img, int ldi, const float* flow, int B, int
     FGT_REQUIRE(al(flow, 4) && al(img, 4) && al(out, 4), "fgt_warp: pointers must be 4-byte aligned");
     const bool flow8 = al(flow, 8);                    // (a contiguous view at an odd float offset is legal: scalar flow loads then)
     if (C == 2 && ldi == 2 && ldo == 2 && W % 2 == 0 && al(img, 8) && al(flow, 16) && al(out, 16)) {
-        hipLaunchKernelGGL(warp_c2x2_kernel, dim3(grid_for((long)B * H * W / 2)), dim3(256), 0, (hipStream_t)stream, img, flow, B, H, W, align_corners,
+        hipLaunchKernelGGL(warp_c2x2_kernel, dim3(grid_for8((long)B * H * W / 2)), dim3(256), 0, (hipStream_t)stream, img, flow, B, H, W, align_corners,
                            absolute_coords, out);
         return fgt_check_launch("warp");
     }
@@ -363,7 +377,7 @@ extern "C" int fgt_warp(const float* img, int ldi, const float* flow, int B, int
                 : (C % 2 == 0 && ldi % 2 == 0 && ldo % 2 == 0 && al(img, 8) && al(out, 8)) ? 2 : 1;
     const long items = (long)B * H * W * (C / V);
     auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, img, ldi, flow, B, H, W, C, align_corners, absolute_coords, out, ldo);
+        hipLaunchKernelGGL(kern, dim3(grid_for8(items)), dim3(256), 0, (hipStream_t)stream, img, ldi, flow, B, H, W, C, align_corners, absolute_coords, out, ldo);
     };
     if (!flow8) { if (V == 4) go(warp_kernel<4, false>); else if (V == 2) go(warp_kernel<2, false>); else go(warp_kernel<1, false>); }
     else if (V == 4) go(warp_kernel<4>); else if (V == 2) go(warp_kernel<2>); else go(warp_kernel<1>);
@@ -373,7 +387,7 @@ extern "C" int fgt_warp(const float* img, int ldi, const float* flow, int B, int
 extern "C" int fgt_fb_consistency(const float* flow_fw, const float* flow_bw, int B, int H, int W, float alpha1, float alpha2,
                                   float* occ_fw, float* occ_bw, void* stream) {
     FGT_REQUIRE(flow_fw && flow_bw && occ_fw && occ_bw && H > 1 && W > 1, "fgt_fb_consistency: bad arguments");
-    hipLaunchKernelGGL(fb_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, flow_fw, flow_bw, B, H, W,
+    hipLaunchKernelGGL(fb_kernel, dim3(grid_for8((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, flow_fw, flow_bw, B, H, W,
                        alpha1, alpha2, occ_fw, occ_bw);
     return fgt_check_launch("fb_consistency");
 }
