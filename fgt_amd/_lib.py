@@ -76,7 +76,6 @@ SIGNATURES = {
     "fgt_avgpool2": [_P, _L, _I, _I, _P, _P],
     "fgt_corr_lookup": [C.POINTER(_P), _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "fgt_corr_lookup_split": [C.POINTER(_P), _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, C.c_long, _I, _P],
-    "fgt_corr_motion": [C.POINTER(_P), _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, C.c_longlong, _P],
     "fgt_convex_upsample": [_P, _I, _P, _I, _I, _I, _I, _P, _P],
     "fgt_instnorm_stats": [_P, _I, _I, _I, _I, _P, _P],
     "fgt_instnorm_apply": [_P, _I, _I, _I, _I, _P, _F, _I, _P, _I, _I, _P, _I, _P],

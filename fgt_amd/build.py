@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfgt_hip.so")
-SOURCES = ["runtime.hip", "conv_igemm.hip", "conv_split.hip", "conv_wide.hip", "conv_taps.hip", "conv_taps_il.hip", "conv_taps_il_256x128.hip", "conv_taps_il_256x256.hip", "conv_f16.hip", "conv_c4.hip", "conv_direct.hip", "attention.hip", "attention_split.hip", "pointwise.hip", "flow_ops.hip", "corr_motion.hip", "laplace_fill.hip", "propagate.hip", "poisson_blend.hip", "solve_onchip.hip"]
+SOURCES = ["runtime.hip", "conv_igemm.hip", "conv_split.hip", "conv_wide.hip", "conv_taps.hip", "conv_taps_il.hip", "conv_taps_il_256x128.hip", "conv_taps_il_256x256.hip", "conv_f16.hip", "conv_c4.hip", "conv_direct.hip", "attention.hip", "attention_split.hip", "pointwise.hip", "flow_ops.hip", "laplace_fill.hip", "propagate.hip", "poisson_blend.hip", "solve_onchip.hip"]
 # diagnostic builds only (build(variant=...)): measured-and-not-adopted schedule variants, trace instrumentation.  The product library never contains them.
 DIAG_SOURCES = ["diag/conv_split_variants.hip", "diag/conv_taps_breg.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
@@ -38,7 +38,7 @@ def build(force=False, verbose=True, variant=None, extra_flags=(), swap=None):
     objdir = os.path.join(LIBDIR, "obj" + (f"_{variant}" if variant else ""))
     lib = os.path.join(LIBDIR, f"libfgt_hip_{variant}.so") if variant else LIB
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(CSRC, "conv_tile.h"), os.path.join(CSRC, "flow_common.h"), os.path.join(CSRC, "conv_taps_il.hip"), os.path.join(HERE, "..", "include", "fgt_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(CSRC, "conv_tile.h"), os.path.join(CSRC, "conv_taps_il.hip"), os.path.join(HERE, "..", "include", "fgt_hip.h")]
     hipcc = _hipcc()
     jobs = []
     objs = []
@@ -75,7 +75,7 @@ def usage_report(src):
     """The compiler's kernel-resource-usage remarks of a product source as the last build() recorded them, or None when the object is missing
     or older than the source / headers (the caller compiles then)."""
     obj = os.path.join(LIBDIR, "obj", src.replace("/", "_").replace(".hip", ".o"))
-    headers = [os.path.join(CSRC, h) for h in ("common.h", "conv_params.h", "conv_tile.h", "flow_common.h", "conv_taps_il.hip")] + [os.path.join(HERE, "..", "include", "fgt_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "conv_params.h", "conv_tile.h", "conv_taps_il.hip")] + [os.path.join(HERE, "..", "include", "fgt_hip.h")]
     if not os.path.exists(obj + ".usage") or _stale(obj, [os.path.join(CSRC, src)] + headers) or os.path.getmtime(obj + ".usage") < os.path.getmtime(obj):
         return None
     return open(obj + ".usage").read()

@@ -794,33 +794,6 @@ def corr_lookup(pyr, B, H1, W1, radius, coords, out=None, out_s=None):
     return out if out_s is None else (out_s if out is None else (out, out_s))
 
 
-def pack_corr_motion_weights(w, levels=4, radius=4):
-    """convc1's weight [256, levels*(2r+1)^2(, 1, 1)] -> the bf16 fragment-order image fgt_corr_motion reads (include/fgt_hip.h): each level's taps
-    padded to 96, hi = bf16_rne(w), lo = bf16_rne(w - hi), laid out [12 K-steps][4][2][hi | lo][2 k-halves][64 lanes][8]."""
-    per = (2 * radius + 1) ** 2
-    w = w.detach().float().reshape(w.shape[0], levels, per)
-    assert w.shape[0] == 256 and levels == 4 and per <= 96
-    wp = torch.zeros(256, levels, 96, dtype=torch.float32, device=w.device)
-    wp[:, :, :per] = w
-    wp = wp.reshape(256, levels * 96)
-    hi = wp.to(torch.bfloat16)
-    lo = (wp - hi.float()).to(torch.bfloat16)
-    img = torch.stack([hi, lo], 0).reshape(2, 4, 2, 32, 12, 2, 2, 8)          # [p, wn, j, l31, s, ks, lh, e]
-    return img.permute(4, 1, 2, 0, 5, 6, 3, 7).contiguous().reshape(-1)       # [s, wn, j, p, ks, lh, l31, e]
-
-
-def corr_motion(pyr, B, H1, W1, radius, coords, w_frag, bias, out_s):
-    """relu(convc1(corr_lookup(...))) in one launch (fgt_corr_motion; RAFT/corr.py:29-50 + update.py:64,73): out_s a Split [B*H1*W1, 256] (planes or interleaved)."""
-    _require_dev(coords, bias, *pyr)
-    assert isinstance(out_s, Split) and not out_s.h and w_frag.dtype == torch.bfloat16 and w_frag.numel() == 12 * 4 * 2 * 2 * 2 * 64 * 8
-    arr = (C.c_void_p * len(pyr))(*[p.data_ptr() for p in pyr])
-    _, sN, sH, sW, sC, ld_s = _as_map(out_s.hi)
-    assert sN * sH * sW == B * H1 * W1 and sC == 256 * (2 if out_s.il else 1)
-    check(_lib.lib().fgt_corr_motion(arr, len(pyr), B, H1, W1, radius, _ptr(coords.contiguous()), _ptr(w_frag), _ptr(bias), _ptr(out_s.data), ld_s, out_s.ps,
-                                     _stream()), "fgt_corr_motion")
-    return out_s
-
-
 def convex_upsample(flow, mask):
     """flow [B,H,W,2(+pad)] channels-last view, mask [B,H,W,576] -> [B,2,8H,8W] NCHW."""
     _require_dev(flow, mask)

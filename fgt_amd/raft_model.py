@@ -123,7 +123,6 @@ class RAFT(nn.Module):
         self.hoist_context = os.environ.get("FGT_RAFT_HOIST", "1") != "0"
         self.fuse_zr = os.environ.get("FGT_RAFT_ZR", "1") != "0"                 # z || r of a GRU half as one two-headed conv (needs the hoisted context)
         self.batched_corr = os.environ.get("FGT_RAFT_BCORR", "1") != "0"         # the pair batch's correlation volumes as ONE batched GEMM launch
-        self.fused_lookup = os.environ.get("FGT_RAFT_FUSED_LOOKUP", "1") != "0"  # correlation lookup + convc1 as one launch (csrc/corr_motion.hip)
         self._graphs = {}
 
     # ------------------------------------------------------------------ packing
@@ -160,8 +159,6 @@ class RAFT(nn.Module):
             c1w, c1b = u.encoder.convc1.weight.detach(), u.encoder.convc1.bias.detach()
             cpad = (-c1w.shape[1]) % 32
             P["enc"]["convc1p"] = PackedConv(torch.cat([c1w, torch.zeros(c1w.shape[0], cpad, 1, 1, device=c1w.device, dtype=c1w.dtype)], 1), c1b)
-            # ... or the lookup and convc1 as ONE launch (fgt_corr_motion: the taps never leave the chip): the weights in MFMA fragment order
-            P["enc"]["convc1_frag"] = (ops.pack_corr_motion_weights(c1w, self.corr_levels, self.corr_radius), c1b.float().contiguous())
             # SepConvGRU (update.py:36-60): hx = [h | inp | motion]; `inp` = relu(cnet[:, 128:]) does not change over the refinement loop
             # (raft.py:112-115, 126-128), so each conv is split into the per-iteration part over [h | motion] (256 of the 384 input channels)
             # and the context part over `inp` (+ bias), which iterate() evaluates ONCE per pair and hands to the per-iteration conv as a
@@ -308,18 +305,14 @@ class RAFT(nn.Module):
             x_it = s4(motion_s) if sc else m4(xbuf)[..., 128:]
         ups = []
         for it in range(iters):
-            fused = sc and self.fused_lookup
-            if fused:
-                ops.corr_motion(pyr, B, h8, w8, self.corr_radius, coords1, *E["convc1_frag"], out_s=cor1_s)
-            elif sc:
+            if sc:
                 ops.corr_lookup(pyr, B, h8, w8, self.corr_radius, coords1, out_s=s4(corr_s))
             else:
                 ops.corr_lookup(pyr, B, h8, w8, self.corr_radius, coords1, m4(corr))
             ops.axpby(coords1, 1.0, coords0, -1.0, out=flow4[:, :2])               # flow = coords1 - coords0
             if sc:
                 # BasicMotionEncoder (update.py:62-76)
-                if not fused:
-                    ops.conv2d(s4(corr_s), E["convc1p"], act="relu", out_split="only", out_s=cor1_s)
+                ops.conv2d(s4(corr_s), E["convc1p"], act="relu", out_split="only", out_s=cor1_s)
                 ops.conv2d(s4(cor1_s), E["convc2"], pad=1, act="relu", out_split="only", out_s=cor2_s)
                 ops.conv2d(m4(flow4), E["convf1"], pad=3, act="relu", out_split="only", out_s=flo1_s)
                 ops.conv2d(s4(flo1_s), E["convf2"], pad=1, act="relu", out_split="only", out_s=flo2_s)

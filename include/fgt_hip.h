@@ -353,17 +353,6 @@ int fgt_corr_lookup(const float* const* pyr, int levels, int B, int H1, int W1, 
 int fgt_corr_lookup_split(const float* const* pyr, int levels, int B, int H1, int W1, int radius, const float* coords,
                           float* out, int ldo, void* out_s, int ld_s, long ps, int nch_pad, void* stream);
 
-/* ABI 8.  The lookup FUSED with RAFT's 1 x 1 convolution behind it (RAFT/corr.py:29-50 + RAFT/update.py:64,73: cor = relu(convc1(corr))): the
- * 4 x (2r+1)^2 taps of a pixel never leave the chip — a workgroup computes them for 64 pixels level by level (the arithmetic of fgt_corr_lookup, tap
- * for tap), splits them to bf16 hi / lo in LDS and multiplies them with the convolution's 256 x 4(2r+1)^2 weights on the matrix cores (bf16x3,
- * fp32 accumulate; K walked level by level with each level's taps padded to 96).  w_frag: the weights re-packed by the caller into MFMA fragment
- * order, bf16 [12 K-steps][4 blocks of 64 output channels][2 x 32 channels][hi | lo][2 k-halves][64 lanes][8]: lane L of block (wn, j) holds, for
- * K-step s and k-half ks, W'[wn*64 + j*32 + L%32][s*32 + ks*16 + (L/32)*8 + 0..7], W'[n][l*96 + t] = w[n][l*(2r+1)^2 + t] for t < (2r+1)^2, else 0
- * (fgt_amd/raft_model.py: pack_corr_motion_weights).  Output: relu(. + bias) as a split tensor [B*H1*W1, 256] (planes: lo `ps` elements behind hi;
- * ps = 32: interleaved per 32 channels), row stride ld_s.  levels = 4, radius <= 4. */
-int fgt_corr_motion(const float* const* pyr, int levels, int B, int H1, int W1, int radius, const float* coords, const void* w_frag,
-                    const float* bias, void* out_s, int ld_s, long long ps, void* stream);
-
 /* RAFT convex upsampling (RAFT/raft.py:73-84): flow [B,H,W,2] (ld), mask [B,H,W,576] (ld) -> up [B,2,8H,8W] NCHW */
 int fgt_convex_upsample(const float* flow, int ldf, const float* mask, int ldm, int B, int H, int W, float* out,
                         void* stream);

@@ -411,19 +411,6 @@ def corr_lookup(pyr, B, H1, W1, radius, coords, out=None, out_s=None):
     return out if out_s is None else (out_s if out is None else (out, out_s))
 
 
-def pack_corr_motion_weights(w, levels=4, radius=4):
-    return w.detach().float().reshape(w.shape[0], -1)
-
-
-def corr_motion(pyr, B, H1, W1, radius, coords, w_frag, bias, out_s):
-    """relu(convc1(corr_lookup)) (fgt_corr_motion): the CPU spec carries the plain [256, 324] weight as `w_frag`."""
-    taps = torch.empty(B, H1, W1, len(pyr) * (2 * radius + 1) ** 2)
-    corr_lookup(pyr, B, H1, W1, radius, coords, out=taps)
-    y = F.relu(taps.reshape(B * H1 * W1, -1) @ w_frag.t() + bias)
-    out_s.put(y.reshape(out_s.x.shape))
-    return out_s
-
-
 def convex_upsample(flow, mask):
     f4, B, H, W, _, _ = _as_map(flow)
     fl = f4[..., :2].permute(0, 3, 1, 2)

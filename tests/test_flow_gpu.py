@@ -355,43 +355,3 @@ def test_raft_fused_zr_and_batched_correlation_equal_the_separate_launches(prec,
         outs[new] = m(g["image1"].to(dev), g["image2"].to(dev), iters=6, test_mode=True)
         assert report(f"raft flow_up zr/bcorr={new} {prec}", outs[new][1], g["flow_up"])[1] < 1e-3
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
-
-
-@pytest.mark.parametrize("B,H1,W1,il", [(2, 30, 54, False), (1, 60, 108, True), (3, 16, 20, False)])
-def test_fused_lookup_and_motion_conv_equals_the_two_launches(B, H1, W1, il, dev, monkeypatch):
-    """fgt_corr_motion (RAFT/corr.py:29-50 + update.py:64,73 in one launch) against fgt_corr_lookup_split + the 1x1 fgt_conv2d it replaces: the
-    same taps (the lookup's arithmetic, tap for tap) and the same bf16x3 products, summed level by level instead of channel by channel — equal
-    to fp32 rounding of the K = 324 sum; and against fp64 on the fp32 taps within the bf16x3 bound.  The last pixels of a ragged 64-pixel tile and
-    coordinates outside the map (zero taps) are in the sample."""
-    from fgt_amd import ops
-    from fgt_amd.ops import PackedConv
-    monkeypatch.setattr(ops, "DEFAULT_CONV_PRECISION", "bf16x3")
-    g = torch.Generator().manual_seed(5)
-    n = H1 * W1
-    rows = B * n
-    vol = torch.randn(rows, H1, W1, generator=g).to(dev)
-    pyr = [vol]
-    hh, ww = H1, W1
-    for _ in range(3):
-        pyr.append(ops.avgpool2(pyr[-1], rows, hh, ww))
-        hh, ww = hh // 2, ww // 2
-    ys, xs = torch.meshgrid(torch.arange(H1), torch.arange(W1), indexing="ij")
-    coords = (torch.stack([xs, ys], -1).float().unsqueeze(0).repeat(B, 1, 1, 1) + torch.randn(B, H1, W1, 2, generator=g) * 6.0).reshape(rows, 2).contiguous().to(dev)
-    w = (torch.randn(256, 324, 1, 1, generator=g) * 0.05).to(dev)
-    b = torch.randn(256, generator=g).to(dev)
-    # the two launches
-    taps_s = ops.Split.empty((rows, 352), dev, h=False)
-    ops.corr_lookup(pyr, B, H1, W1, 4, coords, out_s=taps_s.view(B, H1, W1, 352))
-    wpad = torch.cat([w, torch.zeros(256, 28, 1, 1, device=dev)], 1)
-    ref = ops.conv2d(taps_s.view(B, H1, W1, 352), PackedConv(wpad, b), act="relu", out_split="only", out_s=ops.Split.empty((B, H1, W1, 256), dev, h=False))
-    out = ops.Split.empty((rows, 256), dev, interleaved=il, h=False)
-    out.data.fill_(float("nan"))
-    ops.corr_motion(pyr, B, H1, W1, 4, coords, ops.pack_corr_motion_weights(w), b, out)
-    got, want = out.float().view(rows, 256), ref.float().view(rows, 256)
-    assert torch.isfinite(got).all()
-    scale = want.abs().max().item()
-    assert (got - want).abs().max().item() < 2e-5 * scale + 2 ** -15 * 0, f"{(got - want).abs().max().item()} vs scale {scale}"
-    taps = torch.empty(B, H1, W1, 324, device=dev)
-    ops.corr_lookup(pyr, B, H1, W1, 4, coords, out=taps)
-    r64 = torch.relu(taps.view(rows, 324).double() @ w.view(256, 324).double().t() + b.double())
-    assert (got.double() - r64).abs().max().item() < 3e-5 * r64.abs().max().item()
