@@ -34,7 +34,7 @@ for _ in range(2):
     r.iterate(fmap[i1], fmap[i2], cmap[i1], iters=a.iters, test_mode=True)
 torch.cuda.synchronize()
 recs = []
-NAMES = ["conv2d", "linear", "corr_lookup", "axpby", "avgpool2", "convex_upsample", "nhwc_to_nchw", "instnorm"]
+NAMES = ["conv2d", "linear", "corr_lookup", "batched_gemm_nt", "split", "axpby", "avgpool2", "convex_upsample", "nhwc_to_nchw", "instnorm"]
 real = {k: getattr(ops, k) for k in NAMES}
 
 
@@ -62,6 +62,10 @@ def wrap(name):
                 M *= d_
             flops = 2.0 * M * (pc.Cout // pc.groups) * pc.k_alg * pc.groups
             key = f"{name} {tuple(x.shape)} +{0 if x1 is None else x1.shape[-1]} -> {pc.Cout} k{pc.kh}x{pc.kw} {kw.get('act') or '-'} {kw.get('epi') or '-'}"
+        elif name == "batched_gemm_nt":
+            G, M, K = x.shape
+            flops = 2.0 * G * M * args[1].shape[1] * K
+            key = f"batched_gemm_nt {tuple(x.shape)} x {tuple(args[1].shape)}"
         elif hasattr(x, "shape"):
             key = f"{name} {tuple(x.shape)}"
         recs.append((key, e0, e1, flops))
