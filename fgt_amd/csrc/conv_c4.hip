@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256, C4_TM == 1 ? (KS == 7 ? 2 : 3) : 2) conv_
         __builtin_amdgcn_sched_barrier(0);               // (the next chunk's gathers are not hoisted above this chunk's MFMAs: registers)
     });
     __syncthreads();                                     // every wavefront has read its last weight fragment: the LDS becomes the epilogue's scratch
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, true, false>(p, acc, smem, bm0, bn0, 0);      // (fp32 inputs: no two-headed layers)
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, false, false>(p, acc, smem, bm0, bn0, 0);      // (the 4-channel input layers: no bias maps, no two heads)
 }
 
 template <int KS>
@@ -163,7 +163,7 @@ int launch(const ConvP& p, hipStream_t s) {
 bool fgt_conv_c4_eligible(const ConvP& p) {
     const fgt_conv_desc& d = p.d;
     return d.precision == FGT_PREC_BF16X3 && d.in_split == 0 && d.w_il == 1 && d.groups == 1 && d.C1 == 0 && d.C0 == 4 && d.ld0 % 4 == 0 && d.off0 % 4 == 0 &&
-           d.kh == d.kw && (d.kh == 3 || d.kh == 5 || d.kh == 7) && !d.upsample && p.Cout_g > 4 && d.Kpad >= ((d.kh * d.kw * 4 + 31) / 32) * 32;
+           d.kh == d.kw && (d.kh == 3 || d.kh == 5 || d.kh == 7) && !d.upsample && p.Cout_g > 4 && d.Kpad >= ((d.kh * d.kw * 4 + 31) / 32) * 32 && d.ld_bias == 0 && d.dual_n0 == 0;
 }
 
 int fgt_conv_c4_launch(const ConvP& p, hipStream_t s) {

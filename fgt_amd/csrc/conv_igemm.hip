@@ -283,13 +283,16 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_igemm_kernel(const Con
     }
     }
 
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, true, false>(p, acc, smem, bm0, bn0, g);      // (fp32 inputs: no two-headed layers, fgt_conv2d rejects them)
+    // (fp32 inputs: no two-headed layers, fgt_conv2d rejects them; bias maps reach this kernel in the exact-fp32 mode only — RAFT's GRU convs on
+    //  fp32 maps — so the bf16x3-on-fp32-inputs instances are built without those bodies and launch() declines)
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, PREC == 0, false>(p, acc, smem, bm0, bn0, g);
 }
 
 template <int BM, int BN, int WM, int WN, int PREC, int MINW = 2>
 int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr size_t smem = 2ul * (PREC == 0 ? (BM + BN) * LDS_LD : (BM + BN) * LDB) * sizeof(float);
+    if (PREC != 0 && p.d.ld_bias > 0) { fgt_set_error("fgt_conv2d: bias maps on fp32 inputs are built for FGT_PREC_FP32 only (bf16x3 takes them on split inputs)"); return FGT_EINVAL; }
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, PREC, MINW>), (int)smem, lds_set, "conv_igemm")) return rc;
     ConvP q = p;

@@ -277,7 +277,10 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
+    // (epilogue diet, round 6: bias-map / two-headed bodies only in the two tiles the static fallback routes to when the tap kernels are switched
+    //  off — 128x128 on 4 wavefronts and 64x64, plain schedule; the launcher declines such layers on the other tiles)
+    constexpr bool OPS = EA == 0 && WM * WN == 4 && ((BM == 128 && BN == 128) || (BM == 64 && BN == 64));
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, OPS, OPS>(p, acc, smem, bm0, bn0, g);
 }
 
 template <int BM, int BN, int WM, int WN, int MINW = 2, int EA = 0>
@@ -285,6 +288,8 @@ int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr size_t smem = (size_t)2 * (BM + BN) * LDB * sizeof(float);
     static_assert(smem <= 160 * 1024, "LDS stages do not fit");
+    constexpr bool OPS = EA == 0 && WM * WN == 4 && ((BM == 128 && BN == 128) || (BM == 64 && BN == 64));
+    if (!OPS && (p.d.ld_bias > 0 || p.d.dual_n0 > 0)) { fgt_set_error("fgt_conv2d: this conv_split tile is built without bias-map / two-headed epilogues (use 128x128 or 64x64)"); return FGT_EINVAL; }
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, EA>), (int)smem, lds_set, "conv_split")) return rc;
     ConvP q = p;

@@ -313,8 +313,10 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    // (the 7-tap instance of the 80-register tile has no register left for the two-headed epilogue: launch_kw declines such layers on it)
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, true, !(MINW == 6 && KW == 7)>(p, acc, smem, bm0, bn0, g);
+    // Epilogue diet (round 6): the bias-map bodies (fgt_conv_desc.ld_bias) and the two-headed epilogue (dual_n0) are instantiated for the 5-tap
+    // instances only — their one caller is RAFT's SepConvGRU (1 x 5 and 5 x 1 convolutions, RAFT/update.py:36-58); launch_kw declines other layers.
+    // The bias-map bodies were half of every instance's code (the library went from 22 to 45 MB when round 5 added them to every kernel).
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, KW == 5, KW == 5>(p, acc, smem, bm0, bn0, g);
 }
 
 template <int BM, int BN, int WM, int WN, int MINW, int KW>
@@ -322,7 +324,7 @@ int launch_kw(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr size_t smem = (size_t)2 * (2 * BN * 64) + (size_t)2 * (2 * (BM + HALO + 1) * 64);
     static_assert(smem <= 160 * 1024, "LDS buffers do not fit");
-    if (MINW == 6 && KW == 7 && p.d.dual_n0 > 0) { fgt_set_error("fgt_conv2d: tile 128x64x8t does not serve two-headed layers with 7 taps"); return FGT_EINVAL; }
+    if (KW != 5 && (p.d.dual_n0 > 0 || p.d.ld_bias > 0)) { fgt_set_error("fgt_conv2d: bias maps / two-headed epilogues are built for layers with 5 reused taps (got %d)", KW); return FGT_EINVAL; }
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_taps_kernel<BM, BN, WM, WN, MINW, KW>), (int)smem, lds_set, "conv_taps")) return rc;
     ConvP q = p;

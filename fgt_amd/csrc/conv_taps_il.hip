@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, g);
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, KW == 5, KW == 5>(p, acc, smem, bm0, bn0, g);      // (bias maps / two heads: the 5-tap instances only, see conv_taps.hip)
 }
 
 template <int BM, int BN, int KW, bool WIDE>
@@ -477,6 +477,7 @@ int launch_kw_img(const ConvP& p, hipStream_t s) {
 #else
     constexpr size_t smem = smem0;
 #endif
+    if (KW != 5 && (p.d.dual_n0 > 0 || p.d.ld_bias > 0)) { fgt_set_error("fgt_conv2d: bias maps / two-headed epilogues are built for layers with 5 reused taps (got %d)", KW); return FGT_EINVAL; }
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_taps_il_kernel<BM, BN, KW, WIDE>), (int)smem, lds_set, "conv_taps_il")) return rc;
     ConvP q = p;

@@ -377,7 +377,8 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_wide_kernel(const Conv
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN>(p, acc, smem, bm0, bn0, gb ? 0 : g, gb ? (long)g * d.gb_o : 0l);
+    // (no bias-map / two-headed instances: interleaved-input layers with those operands are tap-routed or run conv_split.hip; the launcher declines)
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, false, false>(p, acc, smem, bm0, bn0, gb ? 0 : g, gb ? (long)g * d.gb_o : 0l);
 }
 
 template <int BM, int BN, int WM, int WN, int MINW = 2, int SCHED = 0>
@@ -400,6 +401,7 @@ int launch(const ConvP& p, hipStream_t s) {
 
 // called by fgt_conv2d (conv_igemm.hip) for desc.in_split == 2 with a tile code >= 100 (`tile` = code - 100)
 int fgt_conv_wide_launch(int tile, const ConvP& p, hipStream_t s) {
+    if (p.d.ld_bias > 0 || p.d.dual_n0 > 0) { fgt_set_error("fgt_conv2d: the wide bf16x3 tiles are built without bias-map / two-headed epilogues"); return FGT_EINVAL; }
     switch (tile) {
         case FGT_TILE_128x128: return launch<128, 128, 2, 2>(p, s);
         case FGT_TILE_128x64: return launch<128, 64, 2, 2>(p, s);
