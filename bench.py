@@ -294,7 +294,7 @@ def _optional_blocks(full, line):
                     cc["c2_spatial_mhsa"]["t136_hbm_frac_attention_kernel"] = c2["at_step_size_t136"].get("hbm_frac_attention_kernel")
             line["c4"] = cc
     for k in ("phases_ms", "weak_scaling_clip_per_rank", "strong_scaling_same_clip", "strong_scaling_ideal", "pipeline_sharded", "feature_exchange",
-              "strong_scaling_modes", "host_launch_us_probe", "rccl_preflight"):
+              "strong_scaling_modes", "host_launch_us_probe", "rccl_preflight", "step_profile"):
         if k in full:
             v = full[k]
             if k == "strong_scaling_ideal":
@@ -487,12 +487,31 @@ def main():
         if prof:
             ops.prof_collect("all")
             ops.prof_enable(True, kinds=list(KERNELS))      # the timed steps carry event pairs on the MFMA launches only (~250 per step)
+        # the shader clock under full matrix load right before and right after the timed region, and an event at every step boundary: a step that is
+        # power-limited slows down over a long timed region (the driver's 20 steps against the 3-5 of a quick A/B) — the line shows it instead of hiding it
+        clk = {}
+        try:
+            clk["before_timed_region"] = round(ops.mfma_probe(f32=(prec == "fp32"), device=dev)[1], 3)
+        except Exception:  # noqa: BLE001
+            pass
+        barrier()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        marks[0].record()
+        for i in range(args.steps):
             comp = runner.run()
+            marks[i + 1].record()
         host_dt = time.perf_counter() - t0      # time the host needed to enqueue everything (launch-bound if close to dt)
         barrier()
         dt = time.perf_counter() - t0
+        try:
+            clk["after_timed_region"] = round(ops.mfma_probe(f32=(prec == "fp32"), device=dev)[1], 3)
+        except Exception:  # noqa: BLE001
+            pass
+        per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+        k3 = max(1, min(3, args.steps // 2))
+        runner.step_profile = {"first_steps_ms": round(sum(per_step[:k3]) / k3, 3), "last_steps_ms": round(sum(per_step[-k3:]) / k3, 3),
+                               "min_ms": round(min(per_step), 3), "max_ms": round(max(per_step), 3), "averaged_over": k3, "mfma_probe_clock_ghz": clk}
         kinds, scale = {}, 1
         if prof:
             if runner.use_graphs:     # graph replays bypass the per-launch events: measure the same kernels on one eager step
@@ -614,6 +633,8 @@ def main():
         }
         if getattr(runner, "graph_probe", None):
             line["config"]["graph_probe"] = runner.graph_probe
+        if getattr(runner, "step_profile", None):
+            line["step_profile"] = runner.step_profile
         if clip_flops:
             line["effective_tflops"] = round(clip_flops * args.steps * mult / dt / 1e12, 2)
         rl = rooflines(res["kinds"], prec, dt)
