@@ -26,6 +26,7 @@ host cores on a bounded sample, median of 3 runs.
 import argparse
 import json
 import os
+import subprocess
 import statistics
 import sys
 import threading
@@ -71,6 +72,17 @@ def kernel_traffic(prec):
     out = dict(json.load(open(p)).get(prec, {}))
     out["_source"] = {"file": "profiles/kernel_traffic.json", "git_head": out.get("git_head", ""), "command": out.get("command", ""),
                       "note": "PMC counters cannot be read in-process: last profiled value of this configuration (tools/gpu_check.sh pmc stage)"}
+    # the profile's commit against the tree that runs (tools/gpu.sh writes .git_head into the snapshot; in a checkout: git): a kernel change after the
+    # PMC visit makes the traffic figure stale, and the line says so instead of quoting it silently
+    here = ""
+    try:
+        hp = os.path.join(ROOT, ".git_head")
+        here = open(hp).read().strip() if os.path.exists(hp) else subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:  # noqa: BLE001
+        pass
+    out["_source"]["tree"] = here
+    if here and out["_source"]["git_head"] and here.split("-")[0] != out["_source"]["git_head"].split("-")[0]:
+        out["_source"]["warning"] = f"traffic profiled on {out['_source']['git_head']}, this tree is {here}: re-run tools/gpu_check.sh pmc if a kernel changed in between"
     return out
 
 
@@ -227,7 +239,9 @@ def _optional_blocks(full, line):
             rr["traffic_over_algorithmic"] = round(rr["traffic"] / hb["bytes_per_launch"], 3)
         ts = r.get("traffic_source") or {}
         if ts:
-            rr["traffic_source"] = {"file": ts.get("file"), "git_head": ts.get("git_head")}
+            rr["traffic_source"] = {"file": ts.get("file"), "git_head": ts.get("git_head"), "tree": ts.get("tree")}
+            if ts.get("warning"):
+                rr["traffic_source"]["stale"] = True
         su = r.get("sustained") or {}
         if su:
             rr["sustained"] = {k: su.get(k) for k in ("peak", "clock_ghz", "frac") if k in su}
