@@ -535,10 +535,29 @@ class FGT(nn.Module):
         # (GEMM operands written by fgt_layernorm: interleaved hi/lo rows in bf16x3 mode — one 128-byte line per 32 channels for the wide kernel)
         new = (lambda r, ch: ops.Split.empty((r, ch), dev, interleaved=ops.split_il(ch))) if sc else (lambda r, ch: torch.empty(r, ch, dtype=torch.float32, device=dev))
         # LN outputs = GEMM operands: rows [0, R) real tokens, row R the padded token, rows R+1.. the frames' global tokens
-        kin, vin, q_ln = new(R + 1 + bt * ng, c + cf), new(R + 1 + bt * ng, c), new(R + 1, c + cf)
+        # Small calls (<= SPATIAL_STREAM_ROWS rows) keep their three operand buffers per shape with the padded token's rows written ONCE — the padded
+        # token is a zero vector in front of the LayerNorms, so its rows are constants of the weights (LayerNorm(0) = beta): two of the module's 15
+        # launches per call go, which is what a 7 200-row call is bound by.  Large calls allocate per call and write the rows with the two 1-row launches.
+        pad_cached = x.is_cuda and 0 < R <= SPATIAL_STREAM_ROWS
+        z = self._zero_row(dev, c + cf)
+        pad_done = False
+        if pad_cached:
+            # (keyed by the calling stream too: ClipRunner may run window groups on concurrent streams, FGT_STREAMS > 1 — they must not share buffers)
+            ck = (id(P), str(dev), torch.cuda.current_stream().cuda_stream, R, bt * ng, bool(sc), ops.mode_key())
+            cache = self.__dict__.setdefault("_spatial_bufs", {})
+            if ck not in cache:
+                if len(cache) >= 32:
+                    cache.clear()
+                bufs = (new(R + 1 + bt * ng, c + cf), new(R + 1 + bt * ng, c), new(R + 1, c + cf))
+                ops.layernorm(z[:, :c], *P["qn"], x1=z[:, c:], gB=P["kn"][0], bB=P["kn"][1], outA=bufs[2][R:R + 1], outB=bufs[0][R:R + 1])
+                ops.layernorm(z[:, :c], *P["vn"], outA=bufs[1][R:R + 1])
+                cache[ck] = (P, bufs)                # (P is held so that id(P) cannot be reused by another pack while the entry lives)
+            kin, vin, q_ln = cache[ck][1]
+            pad_done = True
+        else:
+            kin, vin, q_ln = new(R + 1 + bt * ng, c + cf), new(R + 1 + bt * ng, c), new(R + 1, c + cf)
         gk = torch.empty(bt * ng, c + cf, dtype=torch.float32, device=dev)
         gv = torch.empty(bt * ng, c, dtype=torch.float32, device=dev)
-        z = self._zero_row(dev, c + cf)
         osp = "only" if (sc and SPLIT_ATTENTION) else None
         # The module is a small dependency graph, not a chain: the value path (global-token pool of x, three LayerNorms, the v Linear) needs neither
         # the flow re-weighting nor the q / k path, and the k path parts from the q path behind the shared LayerNorm.  A call that cannot fill the
@@ -561,7 +580,8 @@ class FGT(nn.Module):
         with ctx_v:                                                                      # ---- value path (attention_flow.py:36, 94-96, 128-131)
             ops.dw_pool(x, None, bt, nh, nw, gd, *P["gv"], out=gv, h=th, w_real=tw)
             ops.layernorm(x, *P["vn"], outA=vin[:R])
-            ops.layernorm(z[:, :c], *P["vn"], outA=vin[R:R + 1])
+            if not pad_done:
+                ops.layernorm(z[:, :c], *P["vn"], outA=vin[R:R + 1])
             ops.layernorm(gv, *P["vn"], outA=vin[R + 1:])
             vv = ops.linear(vin, P["v"], out_split=osp)
         fw = ops.linear(x, P["rw"], x1=f, act="sigmoid", epi="mul", aux1=f)            # f * sigmoid(Linear([x|f]))  (attention_flow.py:52-55, 116-118)
@@ -570,7 +590,8 @@ class FGT(nn.Module):
         with ctx_k:                                                                      # ---- global key tokens + the padded token's rows
             ops.dw_pool(x, fw, bt, nh, nw, gd, *P["gk"], out=gk, h=th, w_real=tw)
             ops.layernorm(gk, *P["kn"], outA=kin[R + 1:])
-            ops.layernorm(z[:, :c], *P["qn"], x1=z[:, c:], gB=P["kn"][0], bB=P["kn"][1], outA=q_ln[R:R + 1], outB=kin[R:R + 1])
+            if not pad_done:
+                ops.layernorm(z[:, :c], *P["qn"], x1=z[:, c:], gB=P["kn"][0], bB=P["kn"][1], outA=q_ln[R:R + 1], outB=kin[R:R + 1])
         ops.layernorm(x, *P["qn"], x1=fw, gB=P["kn"][0], bB=P["kn"][1], outA=q_ln[:R], outB=kin[:R])
         if par:
             s_k.wait_stream(main)                                                        # kin[:R] is written on the main stream
