@@ -1,9 +1,10 @@
 #!/bin/bash
 # Same-box A/B of an environment switch over the FGT stage of the bench: tools/ab_env.sh VAR val_a val_b [kinds...]   (run on the GPU box)
+# (round 6: at the driver's settings by default, --steps 20 --warmup 5: AB_STEPS / AB_WARMUP override)
 # Prints fps, ms/step and the per-kernel ms of the named roofline kinds for both values, two rounds each (box drift shows as the spread).
 VAR=$1; A=$2; B=$3; shift 3
 for round in 1 2; do for v in $A $B; do
-  env $VAR=$v FGT_TUNING_FILE=$PWD/gpurun_out/tuning.json python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-fp32-exact --no-c4 > /tmp/ab.log 2>&1
+  env $VAR=$v FGT_TUNING_FILE=$PWD/gpurun_out/tuning.json python bench.py --steps ${AB_STEPS:-20} --warmup ${AB_WARMUP:-5} --no-cpu-baseline --no-fp32-exact --no-c4 > /tmp/ab.log 2>&1
   python - "$VAR=$v" "$@" <<'P'
 import json, sys
 d = json.load(open('gpurun_out/bench_detail.json'))
