@@ -195,6 +195,7 @@ int launch_tiled(const ConvP& p, hipStream_t s) {
     const bool c32 = c32_env && p.Cg % 32 == 0 && p.Cg0 % 32 == 0 && p.d.off0 % 4 == 0;
     if (p.d.in_split == 3) hipLaunchKernelGGL((conv3x3_tiled_kernel<COUT, true, 16>), grid, dim3(256), 0, s, p);      // (fp16 maps: 32 channels are 64 bytes — already half a line per pass; unchanged)
     else if (c32) hipLaunchKernelGGL((conv3x3_tiled_kernel<COUT, false, 32>), grid, dim3(256), 0, s, p);
+    else if (p.Cg % 16 != 0) hipLaunchKernelGGL((conv3x3_tiled_kernel<COUT, false, 8>), grid, dim3(256), 0, s, p);   // (Cin = 24: LAFC's flow output conv, lafc.py:80 — it ran the one-pixel-per-lane-group kernel at 0.36 TB/s)
     else hipLaunchKernelGGL((conv3x3_tiled_kernel<COUT, false, 16>), grid, dim3(256), 0, s, p);
     return fgt_check_launch("conv3x3_tiled");
 }
@@ -202,7 +203,7 @@ int launch_tiled(const ConvP& p, hipStream_t s) {
 bool tiled_eligible(const ConvP& p) {
     const fgt_conv_desc& d = p.d;
     return d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.dh == 1 && d.dw == 1 && d.ph == 1 && d.pw == 1 && !d.upsample &&
-           d.pad_mode == 0 && p.Cg % 16 == 0 && d.N <= 65535 && d.H >= TH && d.W >= TW;
+           d.pad_mode == 0 && p.Cg % 8 == 0 && (p.Cg % 16 == 0 || (p.Cg0 % 8 == 0 && d.in_split != 3)) && d.N <= 65535 && d.H >= TH && d.W >= TW;
 }
 
 }  // namespace
