@@ -293,13 +293,13 @@ def _optional_blocks(full, line):
                 # per stage: the CPU time of its unit in ms (absolute: ms per flow / pair / map / frame, or per clip where the sample was
                 # extrapolated) next to the GPU speed-up over it
                 unit_ms = lambda v: next((v[k] for k in ("ms_per_flow", "ms_per_pair", "ms_per_map", "ms_per_frame", "ms_per_clip_extrapolated") if k in v), None)
+                # (the GPU speed-ups are the ratio of this to the stage's ms per unit above: in the detail file only, the line is at its size limit)
                 cc["cpu_baseline"] = {"cores": cpu.get("cores"), "kind": cpu.get("kind"),
-                                      "cpu_ms_per_unit": {k: unit_ms(v) for k, v in cpu.items() if isinstance(v, dict)},
-                                      "gpu_speedup": {k: v.get("gpu_speedup") for k, v in cpu.items() if isinstance(v, dict)}}
+                                      "cpu_ms_per_unit": {k: unit_ms(v) for k, v in cpu.items() if isinstance(v, dict)}}
             c2 = c4.get("c2_spatial_mhsa")
             if c2:
-                cc["c2_spatial_mhsa"] = {k: c2[k] for k in ("ms_per_module", "mfma_frac_module_wall", "mfma_frac_mfma_kernels_only", "mfma_frac_attention_kernel",
-                                                            "hbm_frac_attention_kernel", "linears_share_of_flops", "error", "streams_in_graph_replay", "mfma_frac_module_wall_graph_replay") if k in c2}
+                cc["c2_spatial_mhsa"] = {k: c2[k] for k in ("ms_per_module", "mfma_frac_module_wall", "mfma_frac_attention_kernel",
+                                                            "hbm_frac_attention_kernel", "error", "streams_in_graph_replay", "mfma_frac_module_wall_graph_replay") if k in c2}
                 if "fp32_exact" in c2:
                     cc["c2_spatial_mhsa"]["fp32_exact_mfma_frac_module_wall"] = c2["fp32_exact"].get("mfma_frac_module_wall")
                     cc["c2_spatial_mhsa"]["fp32_exact_mfma_frac_module_wall_graph_replay"] = c2["fp32_exact"].get("mfma_frac_module_wall_graph_replay")
