@@ -220,9 +220,10 @@ __device__ __forceinline__ float corr_tap_global(const float* vol, int Hl, int W
 // replaces issued 4 scattered 4-byte loads per output (adjacent lanes = adjacent map ROWS): 0.43 ms per call at 864x480 x 32 pairs.
 constexpr int CL_PB = 8, CL_WIN = 12, CL_ROWS = 10, CL_PITCH = 13, CL_WSZ = CL_ROWS * CL_PITCH;
 __global__ void __launch_bounds__(256) corr_lookup_kernel(PyrPtrs pyr, int levels, long npix, int H1, int W1, int radius, const float* coords,
-                                                          float* out, int ldo, __bf16* out_s, int ld_s, long ps, int nch_pad) {
+                                                          float* out, int ldo, __bf16* out_s, int ld_s, long ps, int nch_pad, int deep, int table) {
     __shared__ float win[CL_PB * 4 * CL_WSZ];
     __shared__ int wbase[CL_PB * 4][2];
+    __shared__ float ctab[CL_PB * 4][2][CL_ROWS];       // un-normalised sample coordinates per (pixel, level): [x | y][tap index 0..2r]
     const int tid = threadIdx.x;
     const long q0 = (long)blockIdx.x * CL_PB;
     const int npx = (int)min((long)CL_PB, npix - q0);
@@ -233,8 +234,22 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(PyrPtrs pyr, int level
         wbase[tid][0] = (int)floorf(coords[(q0 + pl) * 2] / scale) - radius - 1;
         wbase[tid][1] = (int)floorf(coords[(q0 + pl) * 2 + 1] / scale) - radius;
     }
+    // The sample coordinate of tap (a, b) is separable: ix depends on (pixel, level, a), iy on (pixel, level, b) — 2 x 9 values per (pixel, level) where
+    // the tap loop evaluated 2 x 81 (each: two fp32 divisions through the reference's normalise / un-normalise round trip; ~40 % of the kernel's time
+    // was this arithmetic).  The same expressions, evaluated once: bit-identical taps (tests/test_flow_gpu.py: FGT_LOOKUP_TABLE=0 is the old loop).
+    if (table) {
+        for (int i = tid; i < npx * levels * side; i += 256) {
+            const int w = i / side, k = i - w * side;
+            const int pl = w / levels, lvl = w - pl * levels;
+            const float scale = (float)(1 << lvl);
+            float ix, iy;
+            sample_coord(coords[(q0 + pl) * 2] / scale + (float)(k - radius), coords[(q0 + pl) * 2 + 1] / scale + (float)(k - radius), 0, 0, W1 >> lvl, H1 >> lvl, 1, 1, ix, iy);
+            ctab[w][0][k] = ix;
+            ctab[w][1][k] = iy;
+        }
+    }
     __syncthreads();
-    for (int idx = tid; idx < npx * levels * CL_ROWS * CL_WIN; idx += 256) {
+    auto stage1 = [&](int idx) -> float {
         const int w = idx / (CL_ROWS * CL_WIN), e = idx - w * (CL_ROWS * CL_WIN);
         const int j = e / CL_WIN, i = e - j * CL_WIN;
         const int pl = w / levels, lvl = w - pl * levels;
@@ -242,7 +257,24 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(PyrPtrs pyr, int level
         const int gx = wbase[w][0] + i, gy = wbase[w][1] + j;
         float v = 0.f;
         if (gx >= 0 && gx < Wl && gy >= 0 && gy < Hl) v = pyr.p[lvl][(q0 + pl) * Hl * Wl + (long)gy * Wl + gx];
+        return v;
+    };
+    auto put1 = [&](int idx, float v) {
+        const int w = idx / (CL_ROWS * CL_WIN), e = idx - w * (CL_ROWS * CL_WIN);
+        const int j = e / CL_WIN, i = e - j * CL_WIN;
         win[w * CL_WSZ + j * CL_PITCH + i] = v;
+    };
+    constexpr int FULL = CL_PB * 4 * CL_ROWS * CL_WIN / 256;      // 15 values per thread for a full block of 8 pixels x 4 levels
+    if (deep && npx == CL_PB && levels == 4) {
+        // all of a thread's window values requested before the first is used: the kernel is bound by outstanding misses x HBM latency (269 MB of counter
+        // traffic in 0.43 ms), and the rolled loop kept 2-4 loads per thread in flight
+        float v[FULL];
+#pragma unroll
+        for (int l = 0; l < FULL; ++l) v[l] = stage1(tid + l * 256);
+#pragma unroll
+        for (int l = 0; l < FULL; ++l) put1(tid + l * 256, v[l]);
+    } else {
+        for (int idx = tid; idx < npx * levels * CL_ROWS * CL_WIN; idx += 256) put1(idx, stage1(idx));
     }
     __syncthreads();
     const int quads = (out_s ? nch_pad : nch) / 4;         // 4 consecutive channels per thread (nch % 4 == 0)
@@ -260,12 +292,19 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(PyrPtrs pyr, int level
             const int a = t / side, b = t - a * side;
             const int Hl = H1 >> lvl, Wl = W1 >> lvl;
             const float scale = (float)(1 << lvl);
-            const float cx = X / scale + (float)(a - radius);
-            const float cy = Y / scale + (float)(b - radius);
-            float ix, iy;
-            sample_coord(cx, cy, 0, 0, Wl, Hl, 1, 1, ix, iy);
-            const Bilin bl = bilin(ix, iy);
             const int w = pl * levels + lvl;
+            float ix, iy;
+            if (table) {
+                ix = ctab[w][0][a];
+                iy = ctab[w][1][b];
+            } else {
+                const float cx = X / scale + (float)(a - radius);
+                const float cy = Y / scale + (float)(b - radius);
+                sample_coord(cx, cy, 0, 0, Wl, Hl, 1, 1, ix, iy);
+            }
+            // (the bilinear factors stay per tap: tabulating them per axis as well measured no faster and lost bit-equality with the per-tap loop —
+            //  hipcc contracts `ix - floor(ix)` with the multiplication that produced ix in one context and not in the other)
+            const Bilin bl = bilin(ix, iy);
             const int rx = bl.x0 - wbase[w][0], ry = bl.y0 - wbase[w][1];
             if ((unsigned)rx < (unsigned)(CL_WIN - 1) && (unsigned)ry < (unsigned)(CL_ROWS - 1)) {
                 const float* wv = win + w * CL_WSZ + ry * CL_PITCH + rx;
@@ -415,8 +454,10 @@ extern "C" int fgt_corr_lookup_split(const float* const* pyr, int levels, int B,
     FGT_REQUIRE(nblk <= 0x7fffffffl, "fgt_corr_lookup: too many query pixels");
     // unique bytes: per (pixel, level) the (2r+2)^2 window, every output form once, the coordinates
     FgtProfScope prof(FGT_PROF_CORR_LOOKUP, 0.0, (double)npix * (4.0 * levels * (2 * radius + 2) * (2 * radius + 2) + 4.0 * nch * ((out ? 1 : 0) + (out_s ? 1 : 0)) + 8.0), stream);
+    static const int deep = [] { const char* e = getenv("FGT_LOOKUP_DEEP"); return e ? atoi(e) : 1; }();      // (A/B: 0 = the rolled staging loop)
+    static const int table = [] { const char* e = getenv("FGT_LOOKUP_TABLE"); return e ? atoi(e) : 1; }();    // (A/B: 0 = per-tap coordinate arithmetic)
     hipLaunchKernelGGL(corr_lookup_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, pp, levels, npix, H1, W1, radius,
-                       coords, out, ldo, static_cast<__bf16*>(out_s), ld_s, ps, nch_pad);
+                       coords, out, ldo, static_cast<__bf16*>(out_s), ld_s, ps, nch_pad, deep, table);
     return fgt_check_launch("corr_lookup");
 }
 

@@ -359,3 +359,41 @@ def test_raft_fused_zr_and_batched_correlation_equal_the_separate_launches(prec,
         outs[new] = m(g["image1"].to(dev), g["image2"].to(dev), iters=6, test_mode=True)
         assert report(f"raft flow_up zr/bcorr={new} {prec}", outs[new][1], g["flow_up"])[1] < 1e-3
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+
+
+def test_lookup_coordinate_table_and_deep_staging_are_bit_identical_to_the_per_tap_loop(dev):
+    """Round 6: fgt_corr_lookup evaluates the (separable) sample coordinates once per (pixel, level, axis, tap index) and requests a thread's whole share of
+    the windows before using it.  Same expressions, same order: the taps must equal the per-tap loop's bit for bit (child processes: the switches are
+    read once per process), incl. coordinates far outside the map and a ragged last block."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, ".")
+from fgt_amd import ops
+torch.set_grad_enabled(False)
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(3)
+B, H1, W1 = 3, 30, 54
+rows = B * H1 * W1 - 5
+vol = torch.randn(B * H1 * W1, H1, W1, generator=g).to(dev)
+pyr, hh, ww = [vol], H1, W1
+for _ in range(3):
+    pyr.append(ops.avgpool2(pyr[-1], B * H1 * W1, hh, ww)); hh, ww = hh // 2, ww // 2
+ys, xs = torch.meshgrid(torch.arange(H1), torch.arange(W1), indexing="ij")
+coords = (torch.stack([xs, ys], -1).float().unsqueeze(0).repeat(B, 1, 1, 1) + torch.randn(B, H1, W1, 2, generator=g) * 20.0).contiguous().to(dev)
+out = torch.empty(B, H1, W1, 324, device=dev)
+ops.corr_lookup(pyr, B, H1, W1, 4, coords, out)
+torch.save(out.cpu(), sys.argv[1])
+'''
+    import os
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({"FGT_LOOKUP_TABLE": "0", "FGT_LOOKUP_DEEP": "0"}, {"FGT_LOOKUP_TABLE": "1", "FGT_LOOKUP_DEEP": "1"}):
+        f = tempfile.NamedTemporaryFile(suffix=".pt", delete=False).name
+        r = subprocess.run([sys.executable, "-c", code, f], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f))
+        os.remove(f)
+    assert torch.equal(outs[0], outs[1])
