@@ -219,7 +219,10 @@ __device__ __forceinline__ float corr_tap_global(const float* vol, int Hl, int W
 // are bit-identical; a tap whose corner falls outside the staged window takes the global path).  The one-thread-per-tap kernel this
 // replaces issued 4 scattered 4-byte loads per output (adjacent lanes = adjacent map ROWS): 0.43 ms per call at 864x480 x 32 pairs.
 constexpr int CL_PB = 8, CL_WIN = 12, CL_ROWS = 10, CL_PITCH = 13, CL_WSZ = CL_ROWS * CL_PITCH;
-__global__ void __launch_bounds__(256) corr_lookup_kernel(PyrPtrs pyr, int levels, long npix, int H1, int W1, int radius, const float* coords,
+// RT = the radius as a compile-time constant (4: RAFT's), 0 = run-time radius: channel -> (level, a, b) are two integer divisions per tap, ~30 instructions
+// each when the divisor is a kernel argument
+template <int RT>
+__global__ void __launch_bounds__(256) corr_lookup_kernel(PyrPtrs pyr, int levels, long npix, int H1, int W1, int radius_rt, const float* coords,
                                                           float* out, int ldo, __bf16* out_s, int ld_s, long ps, int nch_pad, int deep, int table) {
     __shared__ float win[CL_PB * 4 * CL_WSZ];
     __shared__ int wbase[CL_PB * 4][2];
@@ -227,6 +230,7 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(PyrPtrs pyr, int level
     const int tid = threadIdx.x;
     const long q0 = (long)blockIdx.x * CL_PB;
     const int npx = (int)min((long)CL_PB, npix - q0);
+    const int radius = RT > 0 ? RT : radius_rt;
     const int side = 2 * radius + 1, per_lvl = side * side, nch = levels * per_lvl;
     if (tid < npx * levels) {
         const int pl = tid / levels, lvl = tid - pl * levels;
@@ -264,15 +268,41 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(PyrPtrs pyr, int level
         const int j = e / CL_WIN, i = e - j * CL_WIN;
         win[w * CL_WSZ + j * CL_PITCH + i] = v;
     };
-    constexpr int FULL = CL_PB * 4 * CL_ROWS * CL_WIN / 256;      // 15 values per thread for a full block of 8 pixels x 4 levels
     if (deep && npx == CL_PB && levels == 4) {
-        // all of a thread's window values requested before the first is used: the kernel is bound by outstanding misses x HBM latency (269 MB of counter
-        // traffic in 0.43 ms), and the rolled loop kept 2-4 loads per thread in flight
-        float v[FULL];
+        // A full block (8 pixels x 4 levels): a thread takes GROUPS of 4 consecutive window values of one row — one row address per group instead of
+        // one per value (the per-value index arithmetic of the rolled loop was as many instructions as the taps themselves) — and requests all of its
+        // groups before using any: the kernel is latency-bound (269 MB of counter traffic in 0.43 ms), the rolled loop kept 2-4 loads per thread in flight.
+        constexpr int GPR = CL_WIN / 4, NGRP = CL_PB * 4 * CL_ROWS * GPR, NGT = (NGRP + 255) / 256;      // 3 groups per row, 960 groups, 4 per thread
+        float v[NGT][4];
 #pragma unroll
-        for (int l = 0; l < FULL; ++l) v[l] = stage1(tid + l * 256);
+        for (int l = 0; l < NGT; ++l) {
+            const int gi = tid + l * 256;
 #pragma unroll
-        for (int l = 0; l < FULL; ++l) put1(tid + l * 256, v[l]);
+            for (int u = 0; u < 4; ++u) v[l][u] = 0.f;
+            if (gi < NGRP) {
+                const int w = gi / (CL_ROWS * GPR), e = gi - w * (CL_ROWS * GPR);
+                const int j = e / GPR, i0 = (e - j * GPR) * 4;
+                const int pl = w >> 2, lvl = w & 3;
+                const int Hl = H1 >> lvl, Wl = W1 >> lvl;
+                const int gx0 = wbase[w][0] + i0, gy = wbase[w][1] + j;
+                if (gy >= 0 && gy < Hl) {
+                    const float* row = pyr.p[lvl] + (q0 + pl) * Hl * Wl + (long)gy * Wl;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (gx0 + u >= 0 && gx0 + u < Wl) v[l][u] = row[gx0 + u];
+                }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < NGT; ++l) {
+            const int gi = tid + l * 256;
+            if (gi < NGRP) {
+                const int w = gi / (CL_ROWS * GPR), e = gi - w * (CL_ROWS * GPR);
+                const int j = e / GPR, i0 = (e - j * GPR) * 4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) win[w * CL_WSZ + j * CL_PITCH + i0 + u] = v[l][u];
+            }
+        }
     } else {
         for (int idx = tid; idx < npx * levels * CL_ROWS * CL_WIN; idx += 256) put1(idx, stage1(idx));
     }
@@ -456,8 +486,12 @@ extern "C" int fgt_corr_lookup_split(const float* const* pyr, int levels, int B,
     FgtProfScope prof(FGT_PROF_CORR_LOOKUP, 0.0, (double)npix * (4.0 * levels * (2 * radius + 2) * (2 * radius + 2) + 4.0 * nch * ((out ? 1 : 0) + (out_s ? 1 : 0)) + 8.0), stream);
     static const int deep = [] { const char* e = getenv("FGT_LOOKUP_DEEP"); return e ? atoi(e) : 1; }();      // (A/B: 0 = the rolled staging loop)
     static const int table = [] { const char* e = getenv("FGT_LOOKUP_TABLE"); return e ? atoi(e) : 1; }();    // (A/B: 0 = per-tap coordinate arithmetic)
-    hipLaunchKernelGGL(corr_lookup_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, pp, levels, npix, H1, W1, radius,
-                       coords, out, ldo, static_cast<__bf16*>(out_s), ld_s, ps, nch_pad, deep, table);
+    if (radius == 4)
+        hipLaunchKernelGGL(corr_lookup_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, pp, levels, npix, H1, W1, radius,
+                           coords, out, ldo, static_cast<__bf16*>(out_s), ld_s, ps, nch_pad, deep, table);
+    else
+        hipLaunchKernelGGL(corr_lookup_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, pp, levels, npix, H1, W1, radius,
+                           coords, out, ldo, static_cast<__bf16*>(out_s), ld_s, ps, nch_pad, deep, table);
     return fgt_check_launch("corr_lookup");
 }
 
