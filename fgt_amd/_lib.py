@@ -79,6 +79,7 @@ SIGNATURES = {
     "fgt_convex_upsample": [_P, _I, _P, _I, _I, _I, _I, _P, _P],
     "fgt_instnorm_stats": [_P, _I, _I, _I, _I, _P, _P],
     "fgt_instnorm_apply": [_P, _I, _I, _I, _I, _P, _F, _I, _P, _I, _I, _P, _I, _P],
+    "fgt_instnorm_apply_split": [_P, _I, _I, _I, _I, _P, _F, _I, _P, _I, _I, _P, _I, _P, _I, C.c_longlong, _P],
     "fgt_axpby": [_P, _I, _F, _P, _I, _F, _L, _I, _I, _F, _P, _I, _P],
     "fgt_compose_blend": [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P],
     "fgt_compose_blend_u8": [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P],

@@ -391,43 +391,6 @@ __global__ void __launch_bounds__(256) convex_up_kernel(const float* flow, int l
     }
 }
 
-// ---- instance norm: double atomics into stats[N][C][2] = (sum, sumsq)
-__global__ void __launch_bounds__(256) in_stats_kernel(const float* x, int ld, int HW, int C, int chunk, double* stats) {
-    // grid: (pixel chunks, N).  Consecutive threads own consecutive channels (coalesced); when C < 256 the
-    // remaining threads split the chunk's pixels ("sub" lanes).
-    const int n = blockIdx.y;
-    const long p0 = (long)blockIdx.x * chunk, p1 = min((long)HW, p0 + chunk);
-    const int cpb = min(C, 256), lpc = 256 / cpb;
-    const int t = threadIdx.x;
-    if (t >= cpb * lpc) return;
-    const int c0 = t % cpb, sub = t / cpb;
-    for (int c = c0; c < C; c += cpb) {
-        double s = 0.0, ss = 0.0;
-        for (long p = p0 + sub; p < p1; p += lpc) {
-            const float v = x[((long)n * HW + p) * ld + c];
-            s += v; ss += (double)v * v;
-        }
-        atomicAdd(&stats[((long)n * C + c) * 2], s);
-        atomicAdd(&stats[((long)n * C + c) * 2 + 1], ss);
-    }
-}
-
-__global__ void __launch_bounds__(256) in_apply_kernel(const float* x, int ld, int N, int HW, int C, const double* stats, float eps,
-                                                       int act, const float* res, int ldres, int act2, float* out, int ldo) {
-    const long total = (long)N * HW * C;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C); const long pix = idx / C;
-        const long n = pix / HW;
-        const double mean = stats[(n * C + c) * 2] / HW;
-        const double var = stats[(n * C + c) * 2 + 1] / HW - mean * mean;
-        const float rstd = (float)(1.0 / sqrt((var > 0 ? var : 0.0) + (double)eps));
-        float v = (x[pix * ld + c] - (float)mean) * rstd;
-        v = fgt_act(v, act, 0.2f);
-        if (res) { v += res[pix * ldres + c]; v = fgt_act(v, act2, 0.2f); }
-        out[pix * ldo + c] = v;
-    }
-}
-
 }  // namespace
 
 extern "C" int fgt_warp(const float* img, int ldi, const float* flow, int B, int H, int W, int C, int align_corners,
@@ -508,20 +471,3 @@ extern "C" int fgt_convex_upsample(const float* flow, int ldf, const float* mask
     return fgt_check_launch("convex_upsample");
 }
 
-extern "C" int fgt_instnorm_stats(const float* x, int ld, int N, int HW, int C, double* stats, void* stream) {
-    FGT_REQUIRE(x && stats && N > 0 && HW > 0 && C > 0 && C <= 1024, "fgt_instnorm_stats: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * N * C, s) != hipSuccess) { fgt_set_error("fgt_instnorm_stats: memset failed"); return FGT_ELAUNCH; }
-    const int chunk = 512;
-    dim3 grid(cdiv(HW, chunk), N);
-    hipLaunchKernelGGL(in_stats_kernel, grid, dim3(256), 0, s, x, ld, HW, C, chunk, stats);
-    return fgt_check_launch("instnorm_stats");
-}
-
-extern "C" int fgt_instnorm_apply(const float* x, int ld, int N, int HW, int C, const double* stats, float eps, int act,
-                                  const float* res, int ldres, int act2, float* out, int ldo, void* stream) {
-    FGT_REQUIRE(x && stats && out, "fgt_instnorm_apply: bad arguments");
-    hipLaunchKernelGGL(in_apply_kernel, dim3(grid_for((long)N * HW * C)), dim3(256), 0, (hipStream_t)stream, x, ld, N, HW, C, stats,
-                       eps, act, res, ldres, act2, out, ldo);
-    return fgt_check_launch("instnorm_apply");
-}

@@ -471,6 +471,122 @@ __global__ void split2_kernel(const float* __restrict__ x, long rows, int C2, in
     }
 }
 
+// ---- instance norm: double atomics into stats[N][C][2] = (sum, sumsq)
+__global__ void __launch_bounds__(256) in_stats_kernel(const float* x, int ld, int HW, int C, int chunk, double* stats) {
+    // grid: (pixel chunks, N).  Consecutive threads own consecutive channels (coalesced); when C < 256 the
+    // remaining threads split the chunk's pixels ("sub" lanes).
+    const int n = blockIdx.y;
+    const long p0 = (long)blockIdx.x * chunk, p1 = min((long)HW, p0 + chunk);
+    const int cpb = min(C, 256), lpc = 256 / cpb;
+    const int t = threadIdx.x;
+    if (t >= cpb * lpc) return;
+    const int c0 = t % cpb, sub = t / cpb;
+    for (int c = c0; c < C; c += cpb) {
+        double s = 0.0, ss = 0.0;
+        for (long p = p0 + sub; p < p1; p += lpc) {
+            const float v = x[((long)n * HW + p) * ld + c];
+            s += v; ss += (double)v * v;
+        }
+        atomicAdd(&stats[((long)n * C + c) * 2], s);
+        atomicAdd(&stats[((long)n * C + c) * 2 + 1], ss);
+    }
+}
+
+__global__ void __launch_bounds__(256) in_apply_kernel(const float* x, int ld, int N, int HW, int C, const double* stats, float eps,
+                                                       int act, const float* res, int ldres, int act2, float* out, int ldo) {
+    const long total = (long)N * HW * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C); const long pix = idx / C;
+        const long n = pix / HW;
+        const double mean = stats[(n * C + c) * 2] / HW;
+        const double var = stats[(n * C + c) * 2 + 1] / HW - mean * mean;
+        const float rstd = (float)(1.0 / sqrt((var > 0 ? var : 0.0) + (double)eps));
+        float v = (x[pix * ld + c] - (float)mean) * rstd;
+        v = fgt_act(v, act, 0.2f);
+        if (res) { v += res[pix * ldres + c]; v = fgt_act(v, act2, 0.2f); }
+        out[pix * ldo + c] = v;
+    }
+}
+
+
+// ---- round 6: the vectorised pair for C % 4 == 0 (RAFT's fnet: 64 / 96 / 128 channels).  The kernels above handle one 4-byte element per work item
+// with two 64-bit integer divisions, two fp64 divisions, an fp64 square root and an fp64 reciprocal PER ELEMENT: 1.4 TB/s, half of fnet's time
+// (tools/raft_encode_breakdown.py).  Same arithmetic — fp64 sums of x and x * x per (image, channel); mean = s / HW, var = ss / HW - mean^2 in fp64,
+// rstd = (float)(1 / sqrt(max(var, 0) + eps)), y = (x - (float)mean) * rstd — with the per-channel part done once per workgroup.
+// Block = 256 threads = (C / 4 channel quads) x (256 / (C / 4) pixel lanes); grid (pixel chunks, N).
+// Pixels per workgroup: enough workgroups to fill the chip on the small maps too (16 images of 60x108 at 2048 pixels per workgroup were 64 workgroups)
+inline int in_chunk(int N, int HW) {
+    long c = ((long)N * HW + 2047) / 2048;
+    return (int)(c < 64 ? 64 : (c > 2048 ? 2048 : c));
+}
+__global__ void __launch_bounds__(256) in_stats4_kernel(const float* x, int ld, int HW, int C, int chunk, double* stats) {
+    __shared__ double red[256][8];
+    const int n = blockIdx.y, c4n = C >> 2, lpc = 256 / c4n, t = threadIdx.x;
+    const long p0 = (long)blockIdx.x * chunk, p1 = min((long)HW, p0 + chunk);
+    const int cq = t % c4n, sub = t / c4n;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+    if (sub < lpc) {
+        const float* xp = x + (long)n * HW * ld + cq * 4;
+#pragma unroll 4
+        for (long p = p0 + sub; p < p1; p += lpc) {
+            const float4 v = *reinterpret_cast<const float4*>(xp + p * ld);
+            s[0] += v.x; ss[0] += (double)v.x * v.x;
+            s[1] += v.y; ss[1] += (double)v.y * v.y;
+            s[2] += v.z; ss[2] += (double)v.z * v.z;
+            s[3] += v.w; ss[3] += (double)v.w * v.w;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { red[t][u] = s[u]; red[t][4 + u] = ss[u]; }
+    __syncthreads();
+    if (t < c4n) {                                   // fixed-order sum over the pixel lanes of this quad, then ONE atomic per (channel, moment) and block
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = red[t][u];
+        for (int k = 1; k < lpc; ++k)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += red[t + k * c4n][u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            atomicAdd(&stats[((long)n * C + t * 4 + u) * 2], a[u]);
+            atomicAdd(&stats[((long)n * C + t * 4 + u) * 2 + 1], a[4 + u]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) in_apply4_kernel(const float* x, int ld, int HW, int C, const double* stats, float eps, int act,
+                                                        const float* res, int ldres, int act2, float* out, int ldo, float* out_s, int ldo_s, long ps_s, int chunk) {
+    __shared__ float mr[1024][2];
+    const int n = blockIdx.y, c4n = C >> 2, lpc = 256 / c4n, t = threadIdx.x;
+    for (int c = t; c < C; c += 256) {
+        const double mean = stats[((long)n * C + c) * 2] / HW;
+        const double var = stats[((long)n * C + c) * 2 + 1] / HW - mean * mean;
+        mr[c][0] = (float)mean;
+        mr[c][1] = (float)(1.0 / sqrt((var > 0 ? var : 0.0) + (double)eps));
+    }
+    __syncthreads();
+    const int cq = t % c4n, sub = t / c4n;
+    if (sub >= lpc) return;
+    const int c = cq * 4;
+    const float m0 = mr[c][0], m1 = mr[c + 1][0], m2 = mr[c + 2][0], m3 = mr[c + 3][0];
+    const float r0 = mr[c][1], r1 = mr[c + 1][1], r2 = mr[c + 2][1], r3 = mr[c + 3][1];
+    const long p0 = (long)blockIdx.x * chunk, p1 = min((long)HW, p0 + chunk);
+    const long base = (long)n * HW;
+#pragma unroll 4
+    for (long p = p0 + sub; p < p1; p += lpc) {
+        const long pix = base + p;
+        const float4 v = *reinterpret_cast<const float4*>(x + pix * ld + c);
+        float4 y = make_float4(fgt_act((v.x - m0) * r0, act, 0.2f), fgt_act((v.y - m1) * r1, act, 0.2f), fgt_act((v.z - m2) * r2, act, 0.2f),
+                               fgt_act((v.w - m3) * r3, act, 0.2f));
+        if (res) {
+            const float4 q = *reinterpret_cast<const float4*>(res + pix * ldres + c);
+            y = make_float4(fgt_act(y.x + q.x, act2, 0.2f), fgt_act(y.y + q.y, act2, 0.2f), fgt_act(y.z + q.z, act2, 0.2f), fgt_act(y.w + q.w, act2, 0.2f));
+        }
+        if (out) *reinterpret_cast<float4*>(out + pix * ldo + c) = y;
+        if (out_s) store_f32_or_split<false>(out_s, pix * ldo_s + c, ps_s, y, c);
+    }
+}
+
 }  // namespace
 
 extern "C" int fgt_layernorm(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, long rows, float eps,
@@ -645,4 +761,45 @@ extern "C" int fgt_split(const float* x, long rows, int C, int ldx, void* out_s,
     hipLaunchKernelGGL(split_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, rows, C / 4, ldx,
                        static_cast<__bf16*>(out_s), ld_s, (long)ps, relu);
     return fgt_check_launch("split");
+}
+
+extern "C" int fgt_instnorm_stats(const float* x, int ld, int N, int HW, int C, double* stats, void* stream) {
+    FGT_REQUIRE(x && stats && N > 0 && HW > 0 && C > 0 && C <= 1024, "fgt_instnorm_stats: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * N * C, s) != hipSuccess) { fgt_set_error("fgt_instnorm_stats: memset failed"); return FGT_ELAUNCH; }
+    if (C % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N <= 65535) {
+        const int ck = in_chunk(N, HW);
+        hipLaunchKernelGGL(in_stats4_kernel, dim3(cdiv(HW, ck), N), dim3(256), 0, s, x, ld, HW, C, ck, stats);
+        return fgt_check_launch("instnorm_stats");
+    }
+    const int chunk = 512;
+    dim3 grid(cdiv(HW, chunk), N);
+    hipLaunchKernelGGL(in_stats_kernel, grid, dim3(256), 0, s, x, ld, HW, C, chunk, stats);
+    return fgt_check_launch("instnorm_stats");
+}
+
+extern "C" int fgt_instnorm_apply_split(const float* x, int ld, int N, int HW, int C, const double* stats, float eps, int act,
+                                        const float* res, int ldres, int act2, float* out, int ldo, void* out_s, int ldo_s, long long ps_s, void* stream) {
+    FGT_REQUIRE(x && stats && (out || out_s) && N > 0 && HW > 0 && C > 0 && C <= 1024, "fgt_instnorm_apply: bad arguments");
+    const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec = C % 4 == 0 && ld % 4 == 0 && al16(x) && (!res || (ldres % 4 == 0 && al16(res))) && (!out || (ldo % 4 == 0 && al16(out))) && N <= 65535;
+    if (out_s) {
+        FGT_REQUIRE(vec, "fgt_instnorm_apply: a split output needs C, strides multiples of 4 and 16-byte aligned pointers");
+        FGT_REQUIRE(ldo_s % 4 == 0 && (ps_s == -1 || (ps_s > 0 && ps_s % 4 == 0)) && (reinterpret_cast<uintptr_t>(out_s) & 7) == 0 && (ps_s != 32 || (C % 32 == 0 && ldo_s >= 2 * C)),
+                    "fgt_instnorm_apply: split output: ldo_s %d, ps %lld (32 = interleaved: C %% 32 == 0, ldo_s >= 2 C)", ldo_s, ps_s);
+    }
+    if (vec) {
+        const int ck = in_chunk(N, HW);
+        hipLaunchKernelGGL(in_apply4_kernel, dim3(cdiv(HW, ck), N), dim3(256), 0, (hipStream_t)stream, x, ld, HW, C, stats, eps, act, res, ldres, act2,
+                           out, ldo, static_cast<float*>(out_s), ldo_s, (long)ps_s, ck);
+        return fgt_check_launch("instnorm_apply");
+    }
+    hipLaunchKernelGGL(in_apply_kernel, dim3(grid_for((long)N * HW * C)), dim3(256), 0, (hipStream_t)stream, x, ld, N, HW, C, stats,
+                       eps, act, res, ldres, act2, out, ldo);
+    return fgt_check_launch("instnorm_apply");
+}
+
+extern "C" int fgt_instnorm_apply(const float* x, int ld, int N, int HW, int C, const double* stats, float eps, int act,
+                                  const float* res, int ldres, int act2, float* out, int ldo, void* stream) {
+    return fgt_instnorm_apply_split(x, ld, N, HW, C, stats, eps, act, res, ldres, act2, out, ldo, nullptr, 0, 0, stream);
 }

@@ -804,18 +804,23 @@ def convex_upsample(flow, mask):
     return out
 
 
-def instnorm(x, act=None, res=None, act2=None, eps=1e-5, out=None):
-    """InstanceNorm2d(affine=False) over a channels-last map, fused act / residual / act2."""
+def instnorm(x, act=None, res=None, act2=None, eps=1e-5, out=None, out_split=None, out_s=None):
+    """InstanceNorm2d(affine=False) over a channels-last map, fused act / residual / act2.  out_split: None -> fp32; "only" -> a Split (what the next conv's
+    LDS-DMA loader reads); "both" -> (fp32, Split)."""
     _require_dev(x, res, out)
     x4, N, H, W, Cc, ld = _as_map(x)
     stats = torch.empty(N * Cc * 2, dtype=torch.float64, device=x.device)
     check(_lib.lib().fgt_instnorm_stats(_ptr(x4), ld, N, H * W, Cc, _ptr(stats), _stream()), "fgt_instnorm_stats")
-    if out is None:
+    if out is None and out_split != "only":
         out = torch.empty(N, H, W, Cc, dtype=torch.float32, device=x.device)
+    if out_split and out_s is None:
+        out_s = Split.empty((N, H, W, Cc), x.device, interleaved=split_il(Cc), h=False)
     ldres = 0 if res is None else _as_map(res)[5]
-    check(_lib.lib().fgt_instnorm_apply(_ptr(x4), ld, N, H * W, Cc, _ptr(stats), eps, ACT[act], _ptr(res), ldres, ACT[act2],
-                                        _ptr(out), _as_map(out)[5], _stream()), "fgt_instnorm_apply")
-    return out
+    lds_, ps_ = (0, 0) if out_s is None else (_as_map(out_s.hi)[5], out_s.ps)
+    check(_lib.lib().fgt_instnorm_apply_split(_ptr(x4), ld, N, H * W, Cc, _ptr(stats), eps, ACT[act], _ptr(res), ldres, ACT[act2],
+                                              _ptr(out), 0 if out is None else _as_map(out)[5], _ptr(None if out_s is None else out_s.data), lds_, ps_, _stream()),
+          "fgt_instnorm_apply")
+    return {None: out, False: out, "only": out_s, "both": (out, out_s)}[out_split]
 
 
 def axpby(a, sa=1.0, b=None, sb=1.0, act=None, out=None, slope=0.2):

@@ -187,21 +187,38 @@ class RAFT(nn.Module):
 
     # ------------------------------------------------------------------ encoders
     def _encode(self, x, P, instance):
-        """BasicEncoder.forward (extractor.py:173-192) on a channels-last batch."""
+        """BasicEncoder.forward (extractor.py:173-192) on a channels-last batch.
+        bf16x3 (round 6): the encoders run as SPLIT CHAINS like the update block — an activation that feeds a convolution is handed over as a bf16 hi / lo
+        pair written by its producer (the conv epilogue, or fgt_instnorm_apply_split for fnet), so the 3 x 3 layers run the LDS-DMA tap kernels instead of
+        the register-staged one (64 -> 64 at 240x432: 190 -> ~300 TFLOP/s); a block's output is ALSO kept in fp32 where it is the next block's residual.
+        The same products as feeding fp32 tensors to the bf16x3 kernel (tap-routed layers sum them in another order: equal to fp32 rounding)."""
+        sc = ops.DEFAULT_CONV_PRECISION != "fp32"
+        K = (lambda pc, form: dict(out_split=form, out_h=False, out_il=ops.split_il(pc.Cout))) if sc else (lambda pc, form: {})      # (interleaved hand-over where C % 32 == 0)
+        # y / y32: the running activation for conv consumers (Split in the chain) and its fp32 form (the residual operand)
         if instance:
-            y = ops.instnorm(ops.conv2d(x, P["conv1"], stride=2, pad=3), act="relu")
+            y = ops.instnorm(ops.conv2d(x, P["conv1"], stride=2, pad=3), act="relu", out_split="both" if sc else None)
         else:
-            y = ops.conv2d(x, P["conv1"], stride=2, pad=3, act="relu")
-        for b in P["blocks"]:
+            y = ops.conv2d(x, P["conv1"], stride=2, pad=3, act="relu", **K(P["conv1"], "both"))
+        y32, y = y if sc else (y, y)
+        nb = len(P["blocks"])
+        for i, b in enumerate(P["blocks"]):
             s = b["stride"]
+            last = i + 1 == nb                         # the last block's output only feeds the 1 x 1 output conv
+            both = ("only" if last else "both") if sc else None
             if instance:
-                h = ops.instnorm(ops.conv2d(y, b["c1"], stride=s, pad=1), act="relu")
-                sk = y if b["down"] is None else ops.instnorm(ops.conv2d(y, b["down"], stride=s, pad=0))
-                y = ops.instnorm(ops.conv2d(h, b["c2"], stride=1, pad=1), act="relu", res=sk, act2="relu")
+                h = ops.instnorm(ops.conv2d(y, b["c1"], stride=s, pad=1), act="relu", out_split="only" if sc else None)
+                sk = y32 if b["down"] is None else ops.instnorm(ops.conv2d(y, b["down"], stride=s, pad=0))
+                o = ops.instnorm(ops.conv2d(h, b["c2"], stride=1, pad=1), act="relu", res=sk, act2="relu", out_split=both)
             else:
-                h = ops.conv2d(y, b["c1"], stride=s, pad=1, act="relu")
-                sk = y if b["down"] is None else ops.conv2d(y, b["down"], stride=s, pad=0)
-                y = ops.conv2d(h, b["c2"], stride=1, pad=1, act="relu", epi="add", aux1=sk, act2="relu")
+                h = ops.conv2d(y, b["c1"], stride=s, pad=1, act="relu", **K(b["c1"], "only"))
+                sk = y32 if b["down"] is None else ops.conv2d(y, b["down"], stride=s, pad=0)
+                o = ops.conv2d(h, b["c2"], stride=1, pad=1, act="relu", epi="add", aux1=sk, act2="relu", **K(b["c2"], both))
+            if not sc:
+                y32 = y = o
+            elif last:
+                y32, y = None, o
+            else:
+                y32, y = o
         return ops.conv2d(y, P["conv2"])
 
     # ------------------------------------------------------------------ forward

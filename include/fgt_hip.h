@@ -363,6 +363,11 @@ int fgt_convex_upsample(const float* flow, int ldf, const float* mask, int ldm, 
 int fgt_instnorm_stats(const float* x, int ld, int N, int HW, int C, double* stats, void* stream);
 int fgt_instnorm_apply(const float* x, int ld, int N, int HW, int C, const double* stats, float eps, int act,
                        const float* res, int ldres, int act2, float* out, int ldo, void* stream);
+/* ABI 8: the same with an optional split output for the LDS-DMA conv kernels behind it (out_s: bf16 hi at the pointer, lo `ps_s` elements further; ps_s = 32:
+ * interleaved per 32 channels, C % 32 == 0, ldo_s >= 2 C; ps_s = -1: one fp16 plane); out may be NULL when out_s is given.  C % 4 == 0 runs the vectorised
+ * kernels (per-channel mean / rstd once per workgroup); RAFT's fnet hands its activations to the next convolution pre-split this way. */
+int fgt_instnorm_apply_split(const float* x, int ld, int N, int HW, int C, const double* stats, float eps, int act,
+                             const float* res, int ldres, int act2, float* out, int ldo, void* out_s, int ldo_s, long long ps_s, void* stream);
 
 /* Generic pointwise helper: out = act(a * sa + b * sb) over rows x C slices (b = NULL: single operand);
  * slope is the LeakyReLU slope when act = FGT_ACT_LRELU. */

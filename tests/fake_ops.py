@@ -362,16 +362,22 @@ def axpby(a, sa=1.0, b=None, sb=1.0, act=None, out=None, slope=0.2):
 
 
 # ------------------------------------------------------------------ flow-side kernels (spec)
-def instnorm(x, act=None, res=None, act2=None, eps=1e-5, out=None):
+def instnorm(x, act=None, res=None, act2=None, eps=1e-5, out=None, out_split=None, out_s=None):
     x4 = _as_map(x)[0]
     y = F.instance_norm(x4.permute(0, 3, 1, 2), eps=eps).permute(0, 2, 3, 1)
     y = _ACT[act](y, 0.2)
     if res is not None:
         y = _ACT[act2](y + res.reshape(y.shape), 0.2)
+    y = y.contiguous()
     if out is not None:
         out.copy_(y)
-        return out
-    return y.contiguous()
+        y = out
+    if out_split:
+        sp = Split(y, False) if out_s is None else out_s
+        if out_s is not None:
+            out_s.put(y.reshape(out_s.x.shape))
+        return sp if out_split == "only" else (y, sp)
+    return y
 
 
 def avgpool2(src, rows, H, W):
