@@ -3,8 +3,16 @@
 // float4 accesses along the channel dimension of channels-last tensors, one pass over the data.
 #include <stdlib.h>
 #include "common.h"
+#include "conv_params.h"      // FgtFastDiv
 
 namespace {
+
+// Round 6: index arithmetic.  These kernels decoded a 64-bit linear work-item index with `%` and `/` by kernel arguments — four to six 64-bit integer
+// divisions per item, ~100 instructions each on a GPU without a divide unit: the "bandwidth" kernels were bound by their index arithmetic
+// (the RAFT lookup lost half of its time this way, NOTEBOOK §13.8).  Now the outer dimension is a grid dimension (or a 32-bit index where the item
+// count allows), and the inner decode is a multiply-shift by a host-made constant (FgtFastDiv, exact for n < 2^31).
+__device__ __forceinline__ int fdiv(int n, const FgtFastDiv f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.sh); }
+
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -146,14 +154,13 @@ __global__ void __launch_bounds__(256) dw_pool_kernel(const float* x0, int C0, i
 
 // ------------------------------------------------------------------ depthwise 3x3 + identity (AddPosEmb)
 __global__ void __launch_bounds__(256) dw3x3_res_kernel(const float* x, int bt, int h, int w, int C, const float* wgt,
-                                                        const float* bias, float* out) {
-    const int c4n = C >> 2;
-    const long total = (long)bt * h * w * c4n;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % c4n) * 4;
-        long pix = idx / c4n;
-        const int px = (int)(pix % w); long r = pix / w;
-        const int py = (int)(r % h); const int f = (int)(r / h);
+                                                        const float* bias, float* out, FgtFastDiv dc4, FgtFastDiv dw_) {
+    const int c4n = C >> 2, per_f = h * w * c4n;
+    const int f = blockIdx.y;                                     // grid: (items of one frame / 256, frames)
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < per_f; e += gridDim.x * 256) {
+        const int pl = fdiv(e, dc4), c = (e - pl * c4n) * 4;
+        const int py = fdiv(pl, dw_), px = pl - py * w;
+        const long pix = (long)f * h * w + pl;
         // the 9 taps unrolled: clamped (always in-range) loads issued back to back, out-of-image taps get a zero WEIGHT
         // (acc + 0 * v == acc exactly), the 36 weights of the 4 channels are one contiguous run read as 9 float4
         float4 v[9];
@@ -192,15 +199,14 @@ __global__ void __launch_bounds__(256) dw3x3_res_kernel(const float* x, int bt, 
 // above walks the taps with 4 scalar weight loads each and ran at ~1 TB/s).  Same accumulation order: bit-identical results.
 __global__ void __launch_bounds__(256) dw_pool4_kernel(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1,
                                                        int bt, int nh, int nw, int vh, int vw, const float* w, const float* bias,
-                                                       float* out, int ldo) {
+                                                       float* out, int ldo, FgtFastDiv dc4, FgtFastDiv dgw) {
     const int C = C0 + C1, c4n = C >> 2;
-    const int gh = nh / 4, gw = nw / 4;
-    const long total = (long)bt * gh * gw * c4n;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % c4n) * 4;
-        long tok = idx / c4n;
-        const int gx = (int)(tok % gw); long r = tok / gw;
-        const int gy = (int)(r % gh); const int f = (int)(r / gh);
+    const int gh = nh / 4, gw = nw / 4, per_f = gh * gw * c4n;
+    const int f = blockIdx.y;                                     // grid: (items of one frame / 256, frames)
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < per_f; e += gridDim.x * 256) {
+        const int tl = fdiv(e, dc4), c = (e - tl * c4n) * 4;
+        const int gy = fdiv(tl, dgw), gx = tl - gy * gw;
+        const long tok = (long)f * gh * gw + tl;
         const bool s0 = c < C0;
         const float* src = s0 ? x0 + c : x1 + (c - C0);               // select on the address, loads stay straight-line
         const long ld = s0 ? ld0 : ld1;
@@ -331,17 +337,15 @@ __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* src, int
 }
 
 __global__ void __launch_bounds__(256) pad_tokens_kernel(const float* src, int lds, int bt, int h, int w, int C, int nh,
-                                                         int nw, float* dst, int ldd) {
-    const int c4n = C >> 2;
-    const long total = (long)bt * nh * nw * c4n;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % c4n) * 4;
-        long pix = idx / c4n;
-        const int x = (int)(pix % nw); long r = pix / nw;
-        const int y = (int)(r % nh); const int f = (int)(r / nh);
+                                                         int nw, float* dst, int ldd, FgtFastDiv dc4, FgtFastDiv dnw) {
+    const int c4n = C >> 2, per_f = nh * nw * c4n;
+    const int f = blockIdx.y;                                     // grid: (items of one frame / 256, frames)
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < per_f; e += gridDim.x * 256) {
+        const int pl = fdiv(e, dc4), c = (e - pl * c4n) * 4;
+        const int y = fdiv(pl, dnw), x = pl - y * nw;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (y < h && x < w) v = *reinterpret_cast<const float4*>(src + (((long)f * h + y) * w + x) * lds + c);
-        *reinterpret_cast<float4*>(dst + pix * ldd + c) = v;
+        *reinterpret_cast<float4*>(dst + ((long)f * nh * nw + pl) * ldd + c) = v;
     }
 }
 
@@ -422,11 +426,11 @@ __global__ void __launch_bounds__(256) norm_flows_kernel(const float* src, int n
 // dst[i, :] = src[ids[i], :] for rows of row_len floats (row_len % 4 == 0): the window's frames out of the per-frame feature cache
 __global__ void __launch_bounds__(256) gather_rows_kernel(const float* src, long ld_src, const int* ids, int n, long row4, float* dst,
                                                           long ld_dst) {
-    const long total = (long)n * row4;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const long i = idx / row4, c = (idx - i * row4) * 4;
-        *reinterpret_cast<float4*>(dst + i * ld_dst + c) = *reinterpret_cast<const float4*>(src + (long)ids[i] * ld_src + c);
-    }
+    const int i = blockIdx.y;                                     // grid: (float4 of one row / 256, rows)
+    const float* s = src + (long)ids[i] * ld_src;
+    float* d = dst + (long)i * ld_dst;
+    for (long c4 = (long)blockIdx.x * 256 + threadIdx.x; c4 < row4; c4 += (long)gridDim.x * 256)
+        *reinterpret_cast<float4*>(d + c4 * 4) = *reinterpret_cast<const float4*>(s + c4 * 4);
 }
 
 inline int grid_for(long total, int block = 256) {
@@ -436,11 +440,11 @@ inline int grid_for(long total, int block = 256) {
 
 
 // fp32 -> split tensor (hi = bf16_rne(x), lo = bf16_rne(x - hi)); one float4 per thread
-__global__ void split_kernel(const float* __restrict__ x, long rows, int C4, int ldx, __bf16* __restrict__ out, int ld_s, long ps, int relu) {
-    const long total = rows * C4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / C4;
-        const int c = (int)(i - r * C4) * 4;
+__global__ void split_kernel(const float* __restrict__ x, long rows, int C4, int ldx, __bf16* __restrict__ out, int ld_s, long ps, int relu, FgtFastDiv dC) {
+    const int total = (int)(rows * C4);                           // (host: < 2^31 items per launch)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const long r = fdiv(i, dC);
+        const int c = (i - (int)r * C4) * 4;
         float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
         if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
         if (ps < 0) {                                                                  // ps == -1: one fp16 plane
@@ -456,11 +460,11 @@ __global__ void split_kernel(const float* __restrict__ x, long rows, int C4, int
 }
 
 // C % 4 != 0 but even (RAFT's 2-channel flow into the GRU input buffer): one channel pair per thread, planes layout only
-__global__ void split2_kernel(const float* __restrict__ x, long rows, int C2, int ldx, __bf16* __restrict__ out, int ld_s, long ps, int relu) {
-    const long total = rows * C2;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / C2;
-        const int c = (int)(i - r * C2) * 2;
+__global__ void split2_kernel(const float* __restrict__ x, long rows, int C2, int ldx, __bf16* __restrict__ out, int ld_s, long ps, int relu, FgtFastDiv dC) {
+    const int total = (int)(rows * C2);                           // (host: < 2^31 items per launch)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const long r = fdiv(i, dC);
+        const int c = (i - (int)r * C2) * 2;
         float2 v = *reinterpret_cast<const float2*>(x + r * ldx + c);
         if (relu) v = make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f));
         uint2 hi, lo;
@@ -621,9 +625,9 @@ extern "C" int fgt_dw_pool(const float* x0, int C0, int ld0, const float* x1, in
     FGT_REQUIRE(k > 0 && nh % k == 0 && nw % k == 0, "fgt_dw_pool: grid %dx%d not divisible by %d", nh, nw, k);
     const long total = (long)bt * (nh / k) * (nw / k) * ((C0 + C1) / 4);
     FgtProfScope prof(FGT_PROF_DW_POOL, 0.0, 4.0 * (C0 + C1) * ((double)bt * vh * vw + (double)k * k + 1.0 + (double)bt * (nh / k) * (nw / k)), stream);
-    if (k == 4 && (((uintptr_t)w | (uintptr_t)bias) & 15) == 0)
-        hipLaunchKernelGGL(dw_pool4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, bt, nh,
-                           nw, vh, vw, w, bias, out, ldo);
+    if (k == 4 && (((uintptr_t)w | (uintptr_t)bias) & 15) == 0 && bt <= 65535)
+        hipLaunchKernelGGL(dw_pool4_kernel, dim3(grid_for((long)(nh / 4) * (nw / 4) * ((C0 + C1) / 4)), bt), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, bt, nh,
+                           nw, vh, vw, w, bias, out, ldo, fgt_fastdiv_make((unsigned)((C0 + C1) / 4)), fgt_fastdiv_make((unsigned)(nw / 4)));
     else
         hipLaunchKernelGGL(dw_pool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x0, C0, ld0, x1, C1, ld1, bt, nh,
                            nw, vh, vw, k, w, bias, out, ldo);
@@ -632,11 +636,11 @@ extern "C" int fgt_dw_pool(const float* x0, int C0, int ld0, const float* x1, in
 
 extern "C" int fgt_dw3x3_residual(const float* x, int bt, int h, int w, int C, const float* wgt, const float* bias, float* out,
                                   void* stream) {
-    FGT_REQUIRE(x && wgt && bias && out && C % 4 == 0, "fgt_dw3x3_residual: bad arguments");
+    FGT_REQUIRE(x && wgt && bias && out && C % 4 == 0 && bt > 0 && bt <= 65535 && (long)h * w * (C / 4) < (1l << 31), "fgt_dw3x3_residual: bad arguments");
     FGT_REQUIRE(((uintptr_t)wgt & 15) == 0, "fgt_dw3x3_residual: weights must be 16-byte aligned");
-    const long total = (long)bt * h * w * (C / 4);
     FgtProfScope prof(FGT_PROF_POINTWISE, 0.0, 8.0 * (double)bt * h * w * C, stream);
-    hipLaunchKernelGGL(dw3x3_res_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, bt, h, w, C, wgt, bias, out);
+    hipLaunchKernelGGL(dw3x3_res_kernel, dim3(grid_for((long)h * w * (C / 4)), bt), dim3(256), 0, (hipStream_t)stream, x, bt, h, w, C, wgt, bias, out,
+                       fgt_fastdiv_make((unsigned)(C / 4)), fgt_fastdiv_make((unsigned)w));
     return fgt_check_launch("dw3x3_residual");
 }
 
@@ -679,10 +683,10 @@ extern "C" int fgt_nhwc_to_nchw(const float* src, int lds, int coff, int N, int 
 extern "C" int fgt_pad_tokens(const float* src, int lds, int bt, int h, int w, int C, int nh, int nw, float* dst, int ldd,
                               void* stream) {
     FGT_REQUIRE(src && dst && C % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0, "fgt_pad_tokens: bad arguments");
-    const long total = (long)bt * nh * nw * (C / 4);
+    FGT_REQUIRE(bt > 0 && bt <= 65535 && (long)nh * nw * (C / 4) < (1l << 31), "fgt_pad_tokens: frame count / frame size out of range");
     FgtProfScope prof(FGT_PROF_POINTWISE, 0.0, 4.0 * C * ((double)bt * (h < nh ? h : nh) * (w < nw ? w : nw) + (double)bt * nh * nw), stream);
-    hipLaunchKernelGGL(pad_tokens_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, lds, bt, h, w, C, nh, nw,
-                       dst, ldd);
+    hipLaunchKernelGGL(pad_tokens_kernel, dim3(grid_for((long)nh * nw * (C / 4)), bt), dim3(256), 0, (hipStream_t)stream, src, lds, bt, h, w, C, nh, nw,
+                       dst, ldd, fgt_fastdiv_make((unsigned)(C / 4)), fgt_fastdiv_make((unsigned)nw));
     return fgt_check_launch("pad_tokens");
 }
 
@@ -740,7 +744,8 @@ extern "C" int fgt_gather_rows(const float* src, long ld_src, const int* ids, in
     FGT_REQUIRE(row_len % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0,
                 "fgt_gather_rows: rows must be float4 aligned");
     FgtProfScope prof(FGT_PROF_POINTWISE, 0.0, 8.0 * (double)n * row_len, stream);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)n * (row_len / 4))), dim3(256), 0, (hipStream_t)stream, src, ld_src, ids, n,
+    FGT_REQUIRE(n <= 65535, "fgt_gather_rows: at most 65535 rows per call");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(row_len / 4), n), dim3(256), 0, (hipStream_t)stream, src, ld_src, ids, n,
                        row_len / 4, dst, ld_dst);
     return fgt_check_launch("gather_rows");
 }
@@ -751,15 +756,21 @@ extern "C" int fgt_split(const float* x, long rows, int C, int ldx, void* out_s,
         FGT_REQUIRE(C % 2 == 0 && ldx % 2 == 0 && ld_s % 2 == 0 && ps > 0 && ps % 2 == 0 && ps != 32 && ((uintptr_t)x & 7) == 0 && ((uintptr_t)out_s & 3) == 0,
                     "fgt_split: C %% 4 != 0 needs even C, strides and plane stride (planes layout) and 8- / 4-byte aligned pointers");
         FgtProfScope prof2(FGT_PROF_POINTWISE, 0.0, (double)rows * C * 8.0, stream);
+        FGT_REQUIRE(rows * (C / 2) < (1l << 31), "fgt_split: too many items for one call");
         hipLaunchKernelGGL(split2_kernel, dim3(grid_for(rows * (C / 2))), dim3(256), 0, (hipStream_t)stream, x, rows, C / 2, ldx,
-                           static_cast<__bf16*>(out_s), ld_s, (long)ps, relu);
+                           static_cast<__bf16*>(out_s), ld_s, (long)ps, relu, fgt_fastdiv_make((unsigned)(C / 2)));
         return fgt_check_launch("split2");
     }
     FGT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ld_s % 4 == 0 && (ps == -1 || (ps > 0 && ps % 4 == 0)) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out_s & 7) == 0,
                 "fgt_split: C, strides must be multiples of 4 and pointers aligned");
     FgtProfScope prof(FGT_PROF_POINTWISE, 0.0, (double)rows * C * (4.0 + (ps < 0 ? 2.0 : 4.0)), stream);
-    hipLaunchKernelGGL(split_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, rows, C / 4, ldx,
-                       static_cast<__bf16*>(out_s), ld_s, (long)ps, relu);
+    // (32-bit item index in the kernel: rows are taken in chunks of < 2^31 items)
+    const long per = ((1l << 31) - 1) / (C / 4);
+    for (long r0 = 0; r0 < rows; r0 += per) {
+        const long nr = rows - r0 < per ? rows - r0 : per;
+        hipLaunchKernelGGL(split_kernel, dim3(grid_for(nr * (C / 4))), dim3(256), 0, (hipStream_t)stream, x + r0 * ldx, nr, C / 4, ldx,
+                           static_cast<__bf16*>(out_s) + r0 * ld_s, ld_s, (long)ps, relu, fgt_fastdiv_make((unsigned)(C / 4)));
+    }
     return fgt_check_launch("split");
 }
 
