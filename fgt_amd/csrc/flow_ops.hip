@@ -2,6 +2,7 @@
 // consistency, RAFT correlation pyramid pooling + lookup, convex upsampling and instance norm.
 // All gather/HBM-bound; channels-last so that a warp's 4 corner reads are contiguous channel runs.
 #include "common.h"
+#include "conv_params.h"      // FgtFastDiv
 
 namespace {
 
@@ -45,6 +46,28 @@ __device__ __forceinline__ void sample_coord(float fx, float fy, int x, int y, i
     }
 }
 
+// The launch-invariant parts of the relative-flow branch above, evaluated ONCE on the host in the same IEEE arithmetic (two fp64 divisions and two fp64 -> fp32
+// conversions that every work item repeated), and the pixel decode as a multiply-shift: the warp kernels spent more instructions here than on their taps.
+struct WarpK { double sx, sy; float hx, hy; FgtFastDiv dW; };
+inline WarpK warp_consts(int W, int H) {
+    WarpK k;
+    k.sx = 2.0 / (double)(W - 1); k.sy = 2.0 / (double)(H - 1);
+    k.hx = (float)((W - 1.0) / 2.0); k.hy = (float)((H - 1.0) / 2.0);
+    k.dW = fgt_fastdiv_make((unsigned)W);
+    return k;
+}
+__device__ __forceinline__ void sample_coord_k(float fx, float fy, int x, int y, int W, int H, int align_corners, int absolute, const WarpK& k,
+                                               float& ix, float& iy) {
+    if (absolute) { sample_coord(fx, fy, x, y, W, H, align_corners, 1, ix, iy); return; }
+    const float bx = (float)(-1.0 + (double)x * k.sx);
+    const float by = (float)(-1.0 + (double)y * k.sy);
+    const float gx = bx + fx / k.hx;
+    const float gy = by + fy / k.hy;
+    if (align_corners) { ix = ((gx + 1.f) / 2.f) * (float)(W - 1); iy = ((gy + 1.f) / 2.f) * (float)(H - 1); }
+    else { ix = ((gx + 1.f) * (float)W - 1.f) / 2.f; iy = ((gy + 1.f) * (float)H - 1.f) / 2.f; }
+}
+__device__ __forceinline__ int fdivw(int n, const FgtFastDiv f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.sh); }
+
 struct Bilin { int x0, y0; float wnw, wne, wsw, wse; };
 __device__ __forceinline__ Bilin bilin(float ix, float iy) {
     Bilin b;
@@ -64,20 +87,21 @@ __device__ __forceinline__ Bilin bilin(float ix, float iy) {
 // (0.12 of the HBM roof on 3-channel frames).  Same arithmetic, same order: v = ((0 + nw*wnw) + ne*wne) + sw*wsw) + se*wse.
 template <int V, bool FLOW8 = true>
 __global__ void __launch_bounds__(256) warp_kernel(const float* __restrict__ img, int ldi, const float* __restrict__ flow, int B, int H, int W, int C,
-                                                   int align_corners, int absolute, float* __restrict__ out, int ldo) {
+                                                   int align_corners, int absolute, float* __restrict__ out, int ldo, WarpK wk, FgtFastDiv dcpv) {
     typedef float vec __attribute__((ext_vector_type(V)));
     const int cpv = C / V;
-    const long total = (long)B * H * W * cpv;
-    for (long item = xcd_first_item(); item < total; item += (long)gridDim.x * blockDim.x) {
-        const long pix = item / cpv;
-        const int c = (int)(item - pix * cpv) * V;
-        const int x = (int)(pix % W); const long r = pix / W;
-        const int y = (int)(r % H); const long b = r / H;
+    const int per_img = H * W * cpv;                     // grid: (items of one image / 256 — XCD-contiguous, blockIdx.y = image)
+    const long b = blockIdx.y;
+    for (int item = (int)xcd_first_item(); item < per_img; item += gridDim.x * blockDim.x) {
+        const int pl = fdivw(item, dcpv);
+        const int c = (item - pl * cpv) * V;
+        const int y = fdivw(pl, wk.dW), x = pl - y * W;
+        const long pix = b * H * W + pl;
         float2 fl;                                       // (FLOW8 = false: a flow pointer at an odd float offset — two 4-byte loads)
         if constexpr (FLOW8) fl = *reinterpret_cast<const float2*>(flow + pix * 2);
         else fl = make_float2(flow[pix * 2], flow[pix * 2 + 1]);
         float ix, iy;
-        sample_coord(fl.x, fl.y, x, y, W, H, align_corners, absolute, ix, iy);
+        sample_coord_k(fl.x, fl.y, x, y, W, H, align_corners, absolute, wk, ix, iy);
         const Bilin bl = bilin(ix, iy);
         const bool vx0 = bl.x0 >= 0 && bl.x0 < W, vx1 = bl.x0 + 1 >= 0 && bl.x0 + 1 < W;
         const bool vy0 = bl.y0 >= 0 && bl.y0 < H, vy1 = bl.y0 + 1 >= 0 && bl.y0 + 1 < H;
@@ -105,13 +129,14 @@ __global__ void __launch_bounds__(256) warp_kernel(const float* __restrict__ img
 // C = 2 (flow fields, the forward-backward check's operands): TWO adjacent pixels per work item — one 16-byte flow load, eight 8-byte tap
 // loads in flight together, one 16-byte store.  Same arithmetic per pixel as warp_kernel<2>.
 __global__ void __launch_bounds__(256) warp_c2x2_kernel(const float* __restrict__ img, const float* __restrict__ flow, int B, int H, int W,
-                                                        int align_corners, int absolute, float* __restrict__ out) {
+                                                        int align_corners, int absolute, float* __restrict__ out, WarpK wk) {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const long total = (long)B * H * W / 2;
-    for (long item = xcd_first_item(); item < total; item += (long)gridDim.x * blockDim.x) {
-        const long pix = item * 2;
-        const int x = (int)(pix % W); const long r = pix / W;
-        const int y = (int)(r % H); const long b = r / H;
+    const int per_img = H * W / 2;                       // (W even: a pixel pair never straddles two rows)
+    const long b = blockIdx.y;
+    for (int item = (int)xcd_first_item(); item < per_img; item += gridDim.x * blockDim.x) {
+        const int pl = item * 2;
+        const int y = fdivw(pl, wk.dW), x = pl - y * W;
+        const long pix = b * H * W + pl;
         const f4 fl = __builtin_nontemporal_load(reinterpret_cast<const f4*>(flow + pix * 2));
         const float* base = img + b * H * W * 2;
         float2 tap[2][4];
@@ -120,7 +145,7 @@ __global__ void __launch_bounds__(256) warp_c2x2_kernel(const float* __restrict_
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             float ix, iy;
-            sample_coord(q ? fl.z : fl.x, q ? fl.w : fl.y, x + q, y, W, H, align_corners, absolute, ix, iy);
+            sample_coord_k(q ? fl.z : fl.x, q ? fl.w : fl.y, x + q, y, W, H, align_corners, absolute, wk, ix, iy);
             const Bilin bl = bilin(ix, iy);
             const bool vx0 = bl.x0 >= 0 && bl.x0 < W, vx1 = bl.x0 + 1 >= 0 && bl.x0 + 1 < W;
             const bool vy0 = bl.y0 >= 0 && bl.y0 < H, vy1 = bl.y0 + 1 >= 0 && bl.y0 + 1 < H;
@@ -147,10 +172,10 @@ __global__ void __launch_bounds__(256) warp_c2x2_kernel(const float* __restrict_
     }
 }
 
-__device__ __forceinline__ void warp2(const float* src, const float* flw, long b, int x, int y, int H, int W, float& ox, float& oy) {
+__device__ __forceinline__ void warp2(const float* src, const float* flw, long b, int x, int y, int H, int W, const WarpK& wk, float& ox, float& oy) {
     const long pix = (b * H + y) * W + x;
     float ix, iy;
-    sample_coord(flw[pix * 2], flw[pix * 2 + 1], x, y, W, H, 0, 0, ix, iy);
+    sample_coord_k(flw[pix * 2], flw[pix * 2 + 1], x, y, W, H, 0, 0, wk, ix, iy);
     const Bilin bl = bilin(ix, iy);
     ox = oy = 0.f;
     const float* base = src + b * H * W * 2;
@@ -166,14 +191,15 @@ __device__ __forceinline__ void warp2(const float* src, const float* flw, long b
 
 // fbConsistencyCheck.py:33-47
 __global__ void __launch_bounds__(256) fb_kernel(const float* ffw, const float* fbw, int B, int H, int W, float a1, float a2,
-                                                 float* occ_fw, float* occ_bw) {
-    const long total = (long)B * H * W;
-    for (long pix = xcd_first_item(); pix < total; pix += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(pix % W); const long r = pix / W;
-        const int y = (int)(r % H); const long b = r / H;
+                                                 float* occ_fw, float* occ_bw, WarpK wk) {
+    const int per_img = H * W;
+    const long b = blockIdx.y;
+    for (int pl = (int)xcd_first_item(); pl < per_img; pl += gridDim.x * blockDim.x) {
+        const int y = fdivw(pl, wk.dW), x = pl - y * W;
+        const long pix = b * per_img + pl;
         float bwx, bwy, fwx, fwy;
-        warp2(fbw, ffw, b, x, y, H, W, bwx, bwy);  // flow_bw warped by flow_fw
-        warp2(ffw, fbw, b, x, y, H, W, fwx, fwy);  // flow_fw warped by flow_bw
+        warp2(fbw, ffw, b, x, y, H, W, wk, bwx, bwy);  // flow_bw warped by flow_fw
+        warp2(ffw, fbw, b, x, y, H, W, wk, fwx, fwy);  // flow_fw warped by flow_bw
         const float fx = ffw[pix * 2], fy = ffw[pix * 2 + 1], gx = fbw[pix * 2], gy = fbw[pix * 2 + 1];
         const float dfx = fx + bwx, dfy = fy + bwy, dbx = gx + fwx, dby = gy + fwy;
         const float mag_fw = (fx * fx + fy * fy) + (bwx * bwx + bwy * bwy);
@@ -395,21 +421,23 @@ __global__ void __launch_bounds__(256) convex_up_kernel(const float* flow, int l
 
 extern "C" int fgt_warp(const float* img, int ldi, const float* flow, int B, int H, int W, int C, int align_corners,
                         int absolute_coords, float* out, int ldo, void* stream) {
-    FGT_REQUIRE(img && flow && out && B > 0 && H > 1 && W > 1 && C > 0, "fgt_warp: bad arguments");
+    FGT_REQUIRE(img && flow && out && B > 0 && B <= 65535 && H > 1 && W > 1 && C > 0 && (long)H * W * C < (1l << 31), "fgt_warp: bad arguments");
+    const WarpK wk = warp_consts(W, H);
     FgtProfScope prof(FGT_PROF_WARP, 0.0, 4.0 * (double)B * H * W * (2.0 * C + 2.0), stream);
     const auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
     FGT_REQUIRE(al(flow, 4) && al(img, 4) && al(out, 4), "fgt_warp: pointers must be 4-byte aligned");
     const bool flow8 = al(flow, 8);                    // (a contiguous view at an odd float offset is legal: scalar flow loads then)
     if (C == 2 && ldi == 2 && ldo == 2 && W % 2 == 0 && al(img, 8) && al(flow, 16) && al(out, 16)) {
-        hipLaunchKernelGGL(warp_c2x2_kernel, dim3(grid_for8((long)B * H * W / 2)), dim3(256), 0, (hipStream_t)stream, img, flow, B, H, W, align_corners,
-                           absolute_coords, out);
+        hipLaunchKernelGGL(warp_c2x2_kernel, dim3(grid_for8((long)H * W / 2), B), dim3(256), 0, (hipStream_t)stream, img, flow, B, H, W, align_corners,
+                           absolute_coords, out, wk);
         return fgt_check_launch("warp");
     }
     const int V = (C % 4 == 0 && ldi % 4 == 0 && ldo % 4 == 0 && al(img, 16) && al(out, 16)) ? 4
                 : (C % 2 == 0 && ldi % 2 == 0 && ldo % 2 == 0 && al(img, 8) && al(out, 8)) ? 2 : 1;
-    const long items = (long)B * H * W * (C / V);
+    const long items = (long)H * W * (C / V);            // per image (blockIdx.y)
     auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(grid_for8(items)), dim3(256), 0, (hipStream_t)stream, img, ldi, flow, B, H, W, C, align_corners, absolute_coords, out, ldo);
+        hipLaunchKernelGGL(kern, dim3(grid_for8(items), B), dim3(256), 0, (hipStream_t)stream, img, ldi, flow, B, H, W, C, align_corners, absolute_coords, out, ldo,
+                           wk, fgt_fastdiv_make((unsigned)(C / V)));
     };
     if (!flow8) { if (V == 4) go(warp_kernel<4, false>); else if (V == 2) go(warp_kernel<2, false>); else go(warp_kernel<1, false>); }
     else if (V == 4) go(warp_kernel<4>); else if (V == 2) go(warp_kernel<2>); else go(warp_kernel<1>);
@@ -418,9 +446,9 @@ extern "C" int fgt_warp(const float* img, int ldi, const float* flow, int B, int
 
 extern "C" int fgt_fb_consistency(const float* flow_fw, const float* flow_bw, int B, int H, int W, float alpha1, float alpha2,
                                   float* occ_fw, float* occ_bw, void* stream) {
-    FGT_REQUIRE(flow_fw && flow_bw && occ_fw && occ_bw && H > 1 && W > 1, "fgt_fb_consistency: bad arguments");
-    hipLaunchKernelGGL(fb_kernel, dim3(grid_for8((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, flow_fw, flow_bw, B, H, W,
-                       alpha1, alpha2, occ_fw, occ_bw);
+    FGT_REQUIRE(flow_fw && flow_bw && occ_fw && occ_bw && H > 1 && W > 1 && B > 0 && B <= 65535, "fgt_fb_consistency: bad arguments");
+    hipLaunchKernelGGL(fb_kernel, dim3(grid_for8((long)H * W), B), dim3(256), 0, (hipStream_t)stream, flow_fw, flow_bw, B, H, W,
+                       alpha1, alpha2, occ_fw, occ_bw, warp_consts(W, H));
     return fgt_check_launch("fb_consistency");
 }
 
