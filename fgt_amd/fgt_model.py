@@ -538,7 +538,10 @@ class FGT(nn.Module):
         # Small calls (<= SPATIAL_STREAM_ROWS rows) keep their three operand buffers per shape with the padded token's rows written ONCE — the padded
         # token is a zero vector in front of the LayerNorms, so its rows are constants of the weights (LayerNorm(0) = beta): two of the module's 15
         # launches per call go, which is what a 7 200-row call is bound by.  Large calls allocate per call and write the rows with the two 1-row launches.
-        pad_cached = x.is_cuda and 0 < R <= SPATIAL_STREAM_ROWS
+        # NEVER under a stream capture: a captured graph must own every buffer it touches.  (The first version cached under capture too, keyed by the stream:
+        # torch hands out capture / side streams from a pool of 32, so a later capture could HIT an entry that an eager call had allocated on a recycled
+        # stream id — the graph then replayed into memory the cache had long freed: a memory fault in the 400th test of the GPU suite, nowhere else.)
+        pad_cached = x.is_cuda and 0 < R <= SPATIAL_STREAM_ROWS and not torch.cuda.is_current_stream_capturing()
         z = self._zero_row(dev, c + cf)
         pad_done = False
         if pad_cached:
