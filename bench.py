@@ -72,17 +72,18 @@ def kernel_traffic(prec):
     out = dict(json.load(open(p)).get(prec, {}))
     out["_source"] = {"file": "profiles/kernel_traffic.json", "git_head": out.get("git_head", ""), "command": out.get("command", ""),
                       "note": "PMC counters cannot be read in-process: last profiled value of this configuration (tools/gpu_check.sh pmc stage)"}
-    # the profile's commit against the tree that runs (tools/gpu.sh writes .git_head into the snapshot; in a checkout: git): a kernel change after the
-    # PMC visit makes the traffic figure stale, and the line says so instead of quoting it silently
+    # the profile's kernel sources against the tree that runs (a hash over csrc/ + the ABI header, fgt_amd.build.csrc_hash): a kernel change after the PMC
+    # visit makes the traffic figure stale, and the line says so instead of quoting it silently; commits that touch no kernel do not
     here = ""
     try:
-        hp = os.path.join(ROOT, ".git_head")
-        here = open(hp).read().strip() if os.path.exists(hp) else subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        from fgt_amd.build import csrc_hash
+        here = csrc_hash()
     except Exception:  # noqa: BLE001
         pass
     out["_source"]["tree"] = here
-    if here and out["_source"]["git_head"] and here.split("-")[0] != out["_source"]["git_head"].split("-")[0]:
-        out["_source"]["warning"] = f"traffic profiled on {out['_source']['git_head']}, this tree is {here}: re-run tools/gpu_check.sh pmc if a kernel changed in between"
+    prof = out.get("csrc_hash", "")
+    if here and here != prof:
+        out["_source"]["warning"] = f"traffic profiled on kernel sources {prof or '(unrecorded: ' + out['_source']['git_head'] + ')'}, this tree's are {here}: re-run tools/gpu_check.sh pmc"
     return out
 
 

@@ -82,5 +82,21 @@ def usage_report(src):
     return open(obj + ".usage").read()
 
 
+
+
+
+def csrc_hash():
+    """sha1 over the kernel sources and the ABI header (what a PMC traffic profile depends on): profiles/kernel_traffic.json stores it, bench.py compares it
+    with the running tree's — a profile stays valid across commits that do not touch a kernel."""
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) 
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "fgt_hip.h"), "rb").read())
+    return h.hexdigest()[:12]
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))

@@ -91,7 +91,9 @@ def main():
     if not head:        # the GPU box gets a snapshot without .git: tools/gpu.sh writes the head of the snapshot into .git_head
         hf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".git_head")
         head = open(hf).read().strip() if os.path.exists(hf) else ""
-    entry = {"command": note, "git_head": head, "templates": templates,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from fgt_amd.build import csrc_hash
+    entry = {"command": note, "git_head": head, "csrc_hash": csrc_hash(), "templates": templates,
              "note": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KiB -> bytes, per launch"}
     for k, v in kinds.items():
         n = max(v["launches"], 1)
@@ -105,7 +107,7 @@ def main():
         cur = res.get(prec, {})
         for k in kinds:
             if k in merge:
-                cur[k] = dict(entry[k], command=note, git_head=head)
+                cur[k] = dict(entry[k], command=note, git_head=head, csrc_hash=csrc_hash())
         cur.setdefault("templates", {}).update({n_: t for n_, t in templates.items() if kind_of(n_) in merge})
         res[prec] = cur
         json.dump(res, open(out, "w"), indent=1)
