@@ -298,7 +298,7 @@ int fgt_attention(const fgt_attn_desc* d, const void* Q, const void* K, const vo
 int fgt_dw_pool(const float* x0, int C0, int ld0, const float* x1, int C1, int ld1, int bt, int nh, int nw, int vh, int vw,
                 int k, const float* w, const float* bias, float* out, int ldo, void* stream);
 
-/* Depthwise 3x3, stride 1, pad 1, plus identity: out = dwconv(x) + x  (FGT/models/model.py:76-88). */
+/* Depthwise 3x3, stride 1, pad 1, plus identity: out = dwconv(x) + x  (FGT/models/model.py:76-88).  bt <= 65535 (a grid dimension). */
 int fgt_dw3x3_residual(const float* x, int bt, int h, int w, int C, const float* wgt, const float* bias,
                        float* out, void* stream);
 
@@ -323,19 +323,19 @@ int fgt_nchw_to_nhwc(const float* src, int N, int C, int H, int W, float* dst, i
 int fgt_nhwc_to_nchw(const float* src, int lds, int coff, int N, int C, int H, int W, float* dst, void* stream);
 
 /* copy a token map [bt,h,w,C] (row stride lds) into [bt,nh,nw,C]: zero pad where the destination grid is larger
- * (attention_flow.py:66-68, attention_base.py:55-57), crop where it is smaller (attention_base.py:71-72). */
+ * (attention_flow.py:66-68, attention_base.py:55-57), crop where it is smaller (attention_base.py:71-72).  bt <= 65535 (a grid dimension). */
 int fgt_pad_tokens(const float* src, int lds, int bt, int h, int w, int C, int nh, int nw, float* dst, int ldd,
                    void* stream);
 
 /* Backward bilinear warp, zeros padding (LAFC/models/utils/fbConsistencyCheck.py:8-26 image_warp:
  * grid_sample default align_corners=False on a linspace(-1,1) base grid + flow/((W-1)/2)).
  * img [B,H,W,C] channels-last (ld), flow [B,H,W,2] channels-last; align_corners = 1 gives
- * RAFT/utils/utils.py:57-71 bilinear_sampler semantics with absolute pixel coords in `flow`. */
+ * RAFT/utils/utils.py:57-71 bilinear_sampler semantics with absolute pixel coords in `flow`.  B <= 65535 (a grid dimension), H*W*C < 2^31. */
 int fgt_warp(const float* img, int ldi, const float* flow, int B, int H, int W, int C, int align_corners,
              int absolute_coords, float* out, int ldo, void* stream);
 
 /* Forward/backward consistency occlusion masks (fbConsistencyCheck.py:29-47).
- * flow_fw/flow_bw [B,H,W,2]; occ_fw/occ_bw [B,H,W] (1.0 = occluded). */
+ * flow_fw/flow_bw [B,H,W,2]; occ_fw/occ_bw [B,H,W] (1.0 = occluded).  B <= 65535. */
 int fgt_fb_consistency(const float* flow_fw, const float* flow_bw, int B, int H, int W, float alpha1, float alpha2,
                        float* occ_fw, float* occ_bw, void* stream);
 
@@ -403,7 +403,7 @@ int fgt_pack_frames(const float* frames01, const float* masks, const int* ids, i
 int fgt_norm_flows(const float* flows, int n_src, int n_out, int C, long HW, float* out, void* stream);
 
 /* Row gather dst[i, 0:row_len] = src[ids[i], 0:row_len] (ids: device int32): a window's frames out of the per-frame feature
- * buffers — `tensor[:, neighbor_ids + ref_ids]` of tool/video_inpainting.py:718-722 applied to cached features.  row_len % 4 == 0. */
+ * buffers — `tensor[:, neighbor_ids + ref_ids]` of tool/video_inpainting.py:718-722 applied to cached features.  row_len % 4 == 0, n <= 65535 rows per call (a grid dimension). */
 int fgt_gather_rows(const float* src, long ld_src, const int* ids, int n, long row_len, float* dst, long ld_dst, void* stream);
 
 /* Laplace ("diffusion") fill of the masked pixels of B scalar H x W maps (flow channels), all maps at once, by conjugate
