@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256, C4_TM == 1 ? (KS == 7 ? 2 : 3) : 2) conv_
         __builtin_amdgcn_sched_barrier(0);               // (the next chunk's gathers are not hoisted above this chunk's MFMAs: registers)
     });
     __syncthreads();                                     // every wavefront has read its last weight fragment: the LDS becomes the epilogue's scratch
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, false, false>(p, acc, smem, bm0, bn0, 0);      // (the 4-channel input layers: no bias maps, no two heads)
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, false, false>(conv_epilogue_args(p), acc, smem, bm0, bn0, 0);      // (the 4-channel input layers: no bias maps, no two heads)
 }
 
 template <int KS>

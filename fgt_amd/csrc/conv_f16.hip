@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_f16_kernel(const ConvP
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, false, false>(p, acc, smem, bm0, bn0, g);      // (no bias maps in the f16 mode: fgt_conv2d rejects them)
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, false, false>(conv_epilogue_args(p), acc, smem, bm0, bn0, g);      // (no bias maps in the f16 mode: fgt_conv2d rejects them)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_f16w_kernel(const Conv
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, false, false>(p, acc, smem, bm0, bn0, g);      // (no bias maps in the f16 mode: fgt_conv2d rejects them)
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, false, false>(conv_epilogue_args(p), acc, smem, bm0, bn0, g);      // (no bias maps in the f16 mode: fgt_conv2d rejects them)
 }
 
 template <int BM, int BN, int WM, int WN, int MINW = 2, int EA = 0>

@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_igemm_kernel(const Con
 
     // (fp32 inputs: no two-headed layers, fgt_conv2d rejects them; bias maps reach this kernel in the exact-fp32 mode only — RAFT's GRU convs on
     //  fp32 maps — so the bf16x3-on-fp32-inputs instances are built without those bodies and launch() declines)
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, PREC == 0, false>(p, acc, smem, bm0, bn0, g);
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, PREC == 0, false>(conv_epilogue_args(p), acc, smem, bm0, bn0, g);
 }
 
 template <int BM, int BN, int WM, int WN, int PREC, int MINW = 2>

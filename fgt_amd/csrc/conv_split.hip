@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     // (epilogue diet, round 6: bias-map / two-headed bodies only in the two tiles the static fallback routes to when the tap kernels are switched
     //  off — 128x128 on 4 wavefronts and 64x64, plain schedule; the launcher declines such layers on the other tiles)
     constexpr bool OPS = EA == 0 && WM * WN == 4 && ((BM == 128 && BN == 128) || (BM == 64 && BN == 64));
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, OPS, OPS>(p, acc, smem, bm0, bn0, g);
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, OPS, OPS>(conv_epilogue_args(p), acc, smem, bm0, bn0, g);
 }
 
 template <int BM, int BN, int WM, int WN, int MINW = 2, int EA = 0>

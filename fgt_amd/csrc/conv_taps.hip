@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_taps_kernel(const Conv
     // Epilogue diet (round 6): the bias-map bodies (fgt_conv_desc.ld_bias) and the two-headed epilogue (dual_n0) are instantiated for the 5-tap
     // instances only — their one caller is RAFT's SepConvGRU (1 x 5 and 5 x 1 convolutions, RAFT/update.py:36-58); launch_kw declines other layers.
     // The bias-map bodies were half of every instance's code (the library went from 22 to 45 MB when round 5 added them to every kernel).
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, KW == 5, KW == 5>(p, acc, smem, bm0, bn0, g);
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, KW == 5, KW == 5>(conv_epilogue_args<MINW != 6>(p), acc, smem, bm0, bn0, g);
 }
 
 template <int BM, int BN, int WM, int WN, int MINW, int KW>

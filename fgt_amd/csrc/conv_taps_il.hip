@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(BM * 2, 2) conv_taps_il_kernel(const ConvP p) 
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, KW == 5, KW == 5>(p, acc, smem, bm0, bn0, g);      // (bias maps / two heads: the 5-tap instances only, see conv_taps.hip)
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, KW == 5, KW == 5>(conv_epilogue_args(p), acc, smem, bm0, bn0, g);      // (bias maps / two heads: the 5-tap instances only, see conv_taps.hip)
 }
 
 template <int BM, int BN, int KW, bool WIDE>

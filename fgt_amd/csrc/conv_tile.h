@@ -97,6 +97,26 @@ __device__ __forceinline__ void conv_row_of(const ConvP& p, int mt, int ry, int 
     mo = ((long)f * d.ps_H + y) * d.ps_W + x;
 }
 
+// The epilogue's view of the kernel arguments (round 6).  A conv kernel takes ONE by-value ConvP (112 dwords); what the epilogue needs of it — two dozen descriptor
+// fields, six pointers — stayed live through the K loop, i.e. was spilled to VGPR lanes and read back with v_readlane (312 spilled SGPRs in the hottest tap instance, 830+
+// in the ones with bias-map bodies).  Behind an opaque copy of the kernarg segment pointer the epilogue re-reads them with scalar loads when it starts instead: 312 -> 72
+// and 832 -> 201 spilled SGPRs.  Every conv kernel's ONLY kernel argument is its ConvP (offset 0 of the segment); -DFGT_EPI_KERNARG=0 keeps the old form for A/B builds.
+#ifndef FGT_EPI_KERNARG
+#define FGT_EPI_KERNARG 1
+#endif
+template <bool REREAD = true>
+__device__ __forceinline__ const ConvP& conv_epilogue_args(const ConvP& p) {
+#if FGT_EPI_KERNARG
+    if constexpr (!REREAD) return p;               // (the 80-register tap tile: the segment pointer and the reloads cost it two spilled VGPRs)
+    typedef const __attribute__((address_space(4))) ConvP* kconvp_t;
+    kconvp_t pe = (kconvp_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(pe));
+    return *(const ConvP*)pe;
+#else
+    return p;
+#endif
+}
+
 // ---- epilogue.  The accumulators go through LDS (the tile buffers are free now) so that the global side is a compact,
 // coalesced float4 loop shared by every epilogue flavour: bias / per-channel scale, activation, mul / add / GRU combine,
 // then the fp32 store (NHWC slice or NCHW) and / or the pre-split bf16 store (desc.out_split) the next conv's LDS-DMA

@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_wide_kernel(const Conv
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     // (no bias-map / two-headed instances: interleaved-input layers with those operands are tap-routed or run conv_split.hip; the launcher declines)
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, false, false>(p, acc, smem, bm0, bn0, gb ? 0 : g, gb ? (long)g * d.gb_o : 0l);
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, false, false>(conv_epilogue_args(p), acc, smem, bm0, bn0, gb ? 0 : g, gb ? (long)g * d.gb_o : 0l);
 }
 
 template <int BM, int BN, int WM, int WN, int MINW = 2, int SCHED = 0>

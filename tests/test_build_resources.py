@@ -78,15 +78,15 @@ def test_hazard_audit_finds_a_planted_copy():
     assert run([".LBB0_1:", "v_mov_b32_e32 v20, v4", "s_waitcnt lgkmcnt(0)", "ds_read_b128 v[4:7], v1", "s_cbranch_scc1 .LBB0_1"]) == 1
 
 
-# ---- round 6: size guards.  Ceilings of the tree as built — the bias-map / two-headed epilogue bodies are instantiated only where
-# their callers route, which took the library from 45 to 29 MB and the kernels without them from ~830 spilled SGPRs / 150 K instructions to < 260 / 60 K.
-# The instances that keep those bodies (RAFT's GRU convs: 5-tap instances, conv_split 128x128 / 64x64, conv_igemm fp32) are still at ~150 K: the ceilings
-# below stop regressions, they are not the target the review set (20 K per instance).
-SGPR_SPILL_CEILING = {"conv_wide.hip": 64, "attention.hip": 16, "attention_split.hip": 16, "pointwise.hip": 16, "flow_ops.hip": 16}
-SGPR_SPILL_DEFAULT = 900
+# ---- round 6: size guards.  Ceilings of the tree as built.  Two changes took the numbers down: the bias-map / two-headed epilogue bodies are
+# instantiated only where their callers route (library 45 -> 29 MB, kernels without them 150 K -> 57 K instructions), and the epilogue re-reads its kernel arguments
+# from the kernarg segment instead of keeping them live through the K loop (conv_tile.h: conv_epilogue_args; spilled SGPRs 830 -> 201 at most in the MFMA conv kernels,
+# 24 MB).  The instances that keep the bias-map bodies (RAFT's GRU convs) are still ~150 K instructions: the ceilings stop regressions, they are not the review's target.
+SGPR_SPILL_CEILING = {"conv_direct.hip": 480, "solve_onchip.hip": 520, "conv_wide.hip": 96, "conv_f16.hip": 96, "conv_igemm.hip": 96, "attention.hip": 16, "attention_split.hip": 16, "pointwise.hip": 16, "flow_ops.hip": 16}
+SGPR_SPILL_DEFAULT = 220
 INSTRUCTION_CEILING = {"conv_wide.o": 62000, "conv_f16.o": 62000}
 INSTRUCTION_DEFAULT = 160000
-LIBRARY_BYTES_CEILING = 32 << 20
+LIBRARY_BYTES_CEILING = 27 << 20
 
 
 def test_sgpr_spills_and_library_size_stay_below_their_ceilings():
