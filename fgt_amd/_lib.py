@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # no fallback — a missing file raises.
 LIB_PATH = os.environ.get("FGT_HIP_LIB") or os.path.join(_HERE, "lib", "libfgt_hip.so")
 
-ABI_VERSION = 8        # include/fgt_hip.h: what fgt_abi_version() of a matching build returns
+ABI_VERSION = 9        # include/fgt_hip.h: what fgt_abi_version() of a matching build returns
 
 ACT = {"none": 0, None: 0, "lrelu": 1, "relu": 2, "sigmoid": 3, "tanh": 4}
 EPI = {"none": 0, None: 0, "mul": 1, "add": 2, "gru": 3, "affine": 4, "ps_add2": 5}
@@ -38,7 +38,7 @@ class ConvDesc(C.Structure):
                [("out_scale", C.c_float)] + \
                [(n, C.c_int) for n in ("Kpad", "Npad", "tile", "precision", "in_split", "out_split", "ldo_s", "ooff_s", "w_il", "k_alg")] + \
                [(n, C.c_longlong) for n in ("ps0", "ps1", "pso")] + \
-               [(n, C.c_int) for n in ("ps_r", "ps_c", "ps_g0", "ps_H", "ps_W", "ky_skip_n0", "aux_per_image", "n_alg", "ld_bias", "tile_order", "dual_n0", "reserved8")] + \
+               [(n, C.c_int) for n in ("ps_r", "ps_c", "ps_g0", "ps_H", "ps_W", "ky_skip_n0", "aux_per_image", "n_alg", "ld_bias", "tile_order", "dual_n0", "ps_phase_pad")] + \
                [(n, C.c_longlong) for n in ("gb_x0", "gb_w", "gb_o")]      # ABI 8
 
 

@@ -387,8 +387,9 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
                 "fgt_conv2d: pointers must be 16-byte aligned");
     FGT_REQUIRE(d.kh > 0 && d.kw > 0 && d.sh > 0 && d.sw > 0 && d.dh > 0 && d.dw > 0 && d.ph >= 0 && d.pw >= 0, "fgt_conv2d: bad kernel geometry");
     p.Hin = d.H * (d.upsample ? 2 : 1); p.Win = d.W * (d.upsample ? 2 : 1);
-    const int Ho = (p.Hin + 2 * d.ph - d.dh * (d.kh - 1) - 1) / d.sh + 1;
-    const int Wo = (p.Win + 2 * d.pw - d.dw * (d.kw - 1) - 1) / d.sw + 1;
+    // (ABI 9, ps_phase_pad: the 2x2 sub-pixel form of "nearest x2 + 3x3": padding (1 - a, 1 - b) per sub-pixel, one output row per input pixel)
+    const int Ho = d.ps_phase_pad ? p.Hin : (p.Hin + 2 * d.ph - d.dh * (d.kh - 1) - 1) / d.sh + 1;
+    const int Wo = d.ps_phase_pad ? p.Win : (p.Win + 2 * d.pw - d.dw * (d.kw - 1) - 1) / d.sw + 1;
     FGT_REQUIRE(Ho == d.Ho && Wo == d.Wo, "fgt_conv2d: output size (%d,%d) != expected (%d,%d)", d.Ho, d.Wo, Ho, Wo);
     p.K = d.kh * d.kw * p.Cg;
     FGT_REQUIRE(d.Kpad % BK == 0 && d.Kpad >= p.K, "fgt_conv2d: Kpad %d invalid for K %d", d.Kpad, p.K);
@@ -414,7 +415,16 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
                 "fgt_conv2d: a bias map (ld_bias > 0) needs cbias, Cout/groups > 4, ld_bias %% 4 == 0, ld_bias >= Cout, no sub-pixel output, no fp16 inputs");
     FGT_REQUIRE(d.ky_skip_n0 == 0 || (d.groups == 1 && d.kh >= 2 && d.upsample == 0), "fgt_conv2d: ky_skip_n0 needs groups = 1, kh >= 2, no upsampling");
     // ---- ABI 8: two heads in one convolution; batched GEMM on the wide kernel
-    FGT_REQUIRE(d.dual_n0 >= 0 && d.reserved8 == 0, "fgt_conv2d: bad dual_n0 / reserved field");
+    FGT_REQUIRE(d.dual_n0 >= 0 && d.ps_phase_pad >= 0, "fgt_conv2d: bad dual_n0 / ps_phase_pad");
+    // ---- ABI 9: nearest x2 + 3x3 as a 2x2 convolution with a sub-pixel output and per-sub-pixel padding
+    if (d.ps_phase_pad)
+        FGT_REQUIRE(d.ps_phase_pad <= d.ps_c && d.ps_phase_pad % 4 == 0 && (!d.out_split || d.pso != 32 || d.ps_phase_pad % 32 == 0) &&
+                    d.ps_r == 2 && d.ps_g0 == 2 * d.ps_c && d.ps_c % 64 == 0 && d.Cout == 4 * d.ps_c && d.kh == 2 && d.kw == 2 && d.ph == 1 && d.pw == 1 &&
+                    d.sh == 1 && d.sw == 1 && d.dh == 1 && d.dw == 1 && !d.upsample && d.pad_mode == 0 && d.groups == 1 && (d.in_split == 1 || d.in_split == 2) &&
+                    d.ps_H == 2 * d.H && d.ps_W == 2 * d.W && !d.aux_per_image && !d.dual_n0 && d.ld_bias == 0 && !d.ky_skip_n0 && d.tile_order == 0 &&
+                    (d.epi == FGT_EPI_NONE || d.epi == FGT_EPI_MUL || d.epi == FGT_EPI_ADD) && d.tile < FGT_TILE_TAPS,
+                    "fgt_conv2d: ps_phase_pad = cv needs cv <= ps_c, cv %% 4 == 0 (%% 32 with an interleaved out_s), ps_r = 2, ps_g0 = 2 * ps_c, ps_c %% 64 == 0, Cout = 4 * ps_c, a 2x2 / stride 1 / pad 1 geometry with zero padding, "
+                    "groups = 1, split inputs (in_split = 1 or 2), ps_H x ps_W = 2H x 2W, no epilogue beyond mul / add, and a conv_split / conv_wide tile");
     if (d.dual_n0 > 0)
         FGT_REQUIRE(d.epi == FGT_EPI_MUL && d.out_split == 2 && d.groups == 1 && d.Cout == 2 * d.dual_n0 && d.dual_n0 % 64 == 0 &&
                     !d.ps_r && !d.aux_per_image && !d.out_nchw && (d.in_split == 1 || d.in_split == 2),
@@ -445,13 +455,14 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     int tile = d.tile;
     // tile = 0 or a +200 code on a layer conv_taps.hip serves: that kernel (geometry decides, see taps_enabled); an explicit tile of another
     // family on such a layer selects that family (A/B measurements, tests)
-    const bool taps = d.tile >= FGT_TILE_TAPS ? fgt_conv_taps_eligible(p) : (d.tile == 0 && taps_enabled() && fgt_conv_taps_preferred(p));
+    const bool taps = d.ps_phase_pad ? false : d.tile >= FGT_TILE_TAPS ? fgt_conv_taps_eligible(p) : (d.tile == 0 && taps_enabled() && fgt_conv_taps_preferred(p));
     FGT_REQUIRE(d.tile < FGT_TILE_TAPS || taps, "fgt_conv2d: tile %d (tap-reusing kernel) on a layer it does not serve", d.tile);
     if (taps && tile == 0) tile = FGT_TILE_TAPS + (p.Cout_g <= 192 ? FGT_TILE_128x64 : FGT_TILE_128x128x8);
     FGT_REQUIRE(!taps || d.w_il == (tile >= FGT_TILE_TAPS_BREG ? 2 : 1), "fgt_conv2d: tile %d takes weights with w_il = %d", tile, tile >= FGT_TILE_TAPS_BREG ? 2 : 1);
 #ifndef FGT_DIAG
     FGT_REQUIRE(tile < FGT_TILE_TAPS_BREG, "fgt_conv2d: tile %d (register-fed weights) exists in diagnostic builds only", tile);
 #endif
+    if (tile == 0 && d.ps_phase_pad) tile = d.ps_c % 128 == 0 ? FGT_TILE_128x128 : FGT_TILE_128x64;       // (the tile's N width must divide ps_c)
     if (tile == 0) {
         // static fallback (profiles/r01_run2_tune_conv_*.txt); fgt_amd.ops autotunes per shape on first use
         if (p.Cout_g <= 32) tile = FGT_TILE_128x32;
@@ -472,8 +483,8 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
     // (fp16 tensors — in_split = 3, out_s with pso = -1 — are 2 B per value)
     const double in_b = d.in_split == 3 ? 2.0 : 4.0, os_b = (d.out_split && d.pso < 0) ? 2.0 : 4.0;
     // (per-image aux tables are Ho*Wo rows; a sub-pixel map holds ps_H*ps_W*ps_c values per image, and its PS_ADD2 residual as many)
-    const double out_vals = d.ps_r ? (double)d.N * d.ps_H * d.ps_W * d.ps_c : (double)M * d.Cout;
-    const double aux1_vals = d.epi == FGT_EPI_NONE ? 0.0 : (d.aux_per_image ? (double)Ho * Wo * d.Cout : (double)M * d.Cout);
+    const double out_vals = d.ps_r ? (double)d.N * d.ps_H * d.ps_W * (d.ps_phase_pad ? d.ps_phase_pad : d.ps_c) : (double)M * d.Cout;
+    const double aux1_vals = d.epi == FGT_EPI_NONE ? 0.0 : d.ps_phase_pad ? out_vals : (d.aux_per_image ? (double)Ho * Wo * d.Cout : (double)M * d.Cout);
     const double aux2_vals = d.epi < FGT_EPI_GRU ? 0.0 : d.epi == FGT_EPI_PS_ADD2 ? out_vals : (d.epi == FGT_EPI_AFFINE && d.aux_per_image ? (double)Ho * Wo * d.Cout : (double)M * d.Cout);
     const double bmap_bytes = d.ld_bias > 0 ? 4.0 * (double)M * d.Cout : 0.0;
     // (two heads: each output form and aux1 cover half of the columns)
@@ -490,7 +501,7 @@ extern "C" int fgt_conv2d(const fgt_conv_desc* dd, const void* x0v, const void* 
 #endif
     else if (taps) rc = fgt_conv_taps_launch(tile - FGT_TILE_TAPS, p, s);
     else if (tile == FGT_TILE_C4) {
-        if (!fgt_conv_c4_eligible(p)) { fgt_set_error("fgt_conv2d: tile %d (4-channel-input kernel) on a layer it does not serve", tile); rc = FGT_EINVAL; }
+        if (d.ps_phase_pad || !fgt_conv_c4_eligible(p)) { fgt_set_error("fgt_conv2d: tile %d (4-channel-input kernel) on a layer it does not serve", tile); rc = FGT_EINVAL; }
         else rc = fgt_conv_c4_launch(p, s);
     }
     else if (d.in_split == 2 && tile >= FGT_TILE_WIDE) {

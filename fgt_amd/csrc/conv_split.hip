@@ -76,14 +76,21 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     const int kc = (lane & 3) ^ ((lane >> 4) & 3);      // swizzle on the source side (all groups start at multiples of 16 rows)
     const int il_sh = il ? 1 : 0, il_sub = il ? kc * 8 : 0;
     int a_iy0[A_IT], a_ix0[A_IT], a_nb[A_IT];
+    // ABI 9 (desc.ps_phase_pad): the workgroup's columns lie in ONE sub-pixel (a, b) of the x2 output (the launcher checks BN | ps_c): its padding is (1 - a, 1 - b)
+    int ph_e = d.ph, pw_e = d.pw;
+    if (d.ps_phase_pad) {
+        const int q = bn0 / d.ps_c;
+        ph_e -= q >> 1;
+        pw_e -= q & 1;
+    }
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         const int m = bm0 + (wave + it * NW) * 16 + lrow;
         if (m < p.M) {
             const int n_img = m / p.HoWo, rem = m - n_img * p.HoWo;
             const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
-            a_iy0[it] = oy * d.sh - d.ph;
-            a_ix0[it] = ox * d.sw - d.pw;
+            a_iy0[it] = oy * d.sh - ph_e;
+            a_ix0[it] = ox * d.sw - pw_e;
             a_nb[it] = n_img * d.H * d.W;
         } else {
             a_iy0[it] = 0; a_ix0[it] = 0; a_nb[it] = -1;
@@ -280,7 +287,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_split_kernel(const Con
     // (epilogue diet, round 6: bias-map / two-headed bodies only in the two tiles the static fallback routes to when the tap kernels are switched
     //  off — 128x128 on 4 wavefronts and 64x64, plain schedule; the launcher declines such layers on the other tiles)
     constexpr bool OPS = EA == 0 && WM * WN == 4 && ((BM == 128 && BN == 128) || (BM == 64 && BN == 64));
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, OPS, OPS>(conv_epilogue_args(p), acc, smem, bm0, bn0, g);
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, OPS, OPS, true>(conv_epilogue_args(p), acc, smem, bm0, bn0, g);
 }
 
 template <int BM, int BN, int WM, int WN, int MINW = 2, int EA = 0>
@@ -290,6 +297,7 @@ int launch(const ConvP& p, hipStream_t s) {
     static_assert(smem <= 160 * 1024, "LDS stages do not fit");
     constexpr bool OPS = EA == 0 && WM * WN == 4 && ((BM == 128 && BN == 128) || (BM == 64 && BN == 64));
     if (!OPS && (p.d.ld_bias > 0 || p.d.dual_n0 > 0)) { fgt_set_error("fgt_conv2d: this conv_split tile is built without bias-map / two-headed epilogues (use 128x128 or 64x64)"); return FGT_EINVAL; }
+    if (p.d.ps_phase_pad && p.d.ps_c % BN != 0) { fgt_set_error("fgt_conv2d: ps_phase_pad needs a tile whose N width (%d) divides ps_c (%d)", BN, p.d.ps_c); return FGT_EINVAL; }
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WM, WN, MINW, EA>), (int)smem, lds_set, "conv_split")) return rc;
     ConvP q = p;

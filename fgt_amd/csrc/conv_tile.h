@@ -69,6 +69,7 @@ __device__ __forceinline__ int conv_out_row(const ConvP& p, int m) {
 __device__ __forceinline__ int fgt_fastdiv(int n, const FgtFastDiv f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.sh); }
 
 // ABI 7 (fold as a convolution): output column n -> sub-pixel (ry, rx) and channel; false for the padding columns between the ry = 0 block and ps_g0.
+template <bool PHASE = false>
 __device__ __forceinline__ bool conv_ps_column(const fgt_conv_desc& d, int n, int& ry, int& rx, int& ch) {
     const int rc = d.ps_r * d.ps_c;
     bool ok = true;
@@ -78,6 +79,7 @@ __device__ __forceinline__ bool conv_ps_column(const fgt_conv_desc& d, int n, in
     const int r2 = q - ry * rc;
     rx = r2 / d.ps_c;
     ch = r2 - rx * d.ps_c;
+    if constexpr (PHASE) { if (d.ps_phase_pad) ok = ch < d.ps_phase_pad; }       // ABI 9: cv real channels per sub-pixel, the rest of ps_c is padding to the tile width
     return ok;
 }
 
@@ -125,7 +127,8 @@ __device__ __forceinline__ const ConvP& conv_epilogue_args(const ConvP& p) {
 // BIAS_MAP = false: a kernel family that never sees desc.ld_bias > 0 (the fp16 kernels: the host rejects the combination) skips those instances.
 // out_goff: element offset added to `out` (ABI 8, the batched GEMM mode of conv_wide.hip: group g's output block; the caller passes g = 0 then).
 // DUAL = false: a kernel family that never sees desc.dual_n0 > 0 (fp32 / fp16 inputs: the host requires split inputs for two heads).
-template <int BM, int BN, int WM, int WN, int STAGE, int TM, int TN, bool BIAS_MAP = true, bool DUAL = true>
+// PHASE = true: the two kernel families that serve desc.ps_phase_pad (ABI 9: conv_split.hip, conv_wide.hip; the host rejects it elsewhere).
+template <int BM, int BN, int WM, int WN, int STAGE, int TM, int TN, bool BIAS_MAP = true, bool DUAL = true, bool PHASE = false>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], float* smem, int bm0, int bn0, int g, long out_goff = 0) {
     constexpr int NT = WM * WN * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -166,7 +169,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         // straddles two sub-pixels); a row's (image, I, J) costs two multiply-shift divisions.
         int ps_ry = 0, ps_rx = 0, och = co;
         bool ps_col = true;
-        if (d.ps_r) ps_col = conv_ps_column(d, n, ps_ry, ps_rx, och);
+        if (d.ps_r) ps_col = conv_ps_column<PHASE>(d, n, ps_ry, ps_rx, och);
         // ABI 8, two heads (desc.dual_n0 > 0, FGT_EPI_MUL, groups = 1).  Head 0 = columns [0, n0): fp32 output, no combine;
         // head 1 = [n0, 2 n0): times aux1[m, n - n0], split output at channel n - n0.
         // (the host requires n0 % 64 == 0 and every wavefront's columns are 32 or 64 wide: which head a WAVEFRONT serves is a scalar)
@@ -174,6 +177,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         const bool head1 = dual && __builtin_amdgcn_readfirstlane(bn0 + wn * WTN) >= d.dual_n0;
         if (head1) och = co - d.dual_n0;
         const bool st_f32 = want_f32 && !head1, st_split = want_split && (!dual || head1);
+        const bool a1_och = dual || (PHASE && d.ps_phase_pad != 0);      // (ABI 9: with ps_phase_pad aux1 is shaped like the sub-pixel output: column = channel of the pixel)
         // The body is instantiated per number of aux operands (AUX = 0: no epilogue operand, 1: mul / add, 2: GRU) and dispatched on desc.epi.
         // With desc.epi tested at run time inside ONE body, hipcc put `s_waitcnt vmcnt(0)` in front of every row group (the join of the
         // paths with and without aux loads) — and on gfx9 that counter also holds the STORES until they are acknowledged: every group of
@@ -205,7 +209,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 conv_row_of(p, mt, ps_ry, ps_rx, ps_col, m, rem, okr);
                 const long m1 = d.aux_per_image ? (long)rem : m;
                 // (out-of-range lanes read the zero page: the select is on the address, the loads stay back to back)
-                if constexpr (AUX >= 1) a1[u0] = *reinterpret_cast<const float4*>(okk && (!dual || head1) ? p.aux1 + m1 * d.ld_aux1 + (dual ? och : co) : p.zero_page);
+                if constexpr (AUX >= 1) a1[u0] = *reinterpret_cast<const float4*>(okk && (!dual || head1) ? p.aux1 + m1 * d.ld_aux1 + (a1_och ? och : co) : p.zero_page);
                 if constexpr (AUX >= 2) {
                     const float* q2 = d.epi == FGT_EPI_PS_ADD2 ? p.aux2 + m * d.ld_aux2 + och : p.aux2 + (d.epi == FGT_EPI_AFFINE ? m1 : m) * d.ld_aux2 + co;
                     a2[u0] = *reinterpret_cast<const float4*>(okk && okr ? q2 : p.zero_page);
@@ -334,7 +338,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
             int ps_ry = 0, ps_rx = 0, och = co, rem;
             bool okr;
             long m;
-            const bool ps_col = d.ps_r ? conv_ps_column(d, n, ps_ry, ps_rx, och) : true;     // (host: sub-pixel output implies vec_ok)
+            const bool ps_col = d.ps_r ? conv_ps_column<PHASE>(d, n, ps_ry, ps_rx, och) : true;     // (host: sub-pixel output implies vec_ok)
             const bool dual = DUAL && d.dual_n0 > 0, head1 = dual && n >= d.dual_n0;                 // (host: two heads imply vec_ok)
             if (head1) och = co - d.dual_n0;
             conv_row_of(p, mbase + row, ps_ry, ps_rx, ps_col, m, rem, okr);
@@ -353,9 +357,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                     else if (d.epi == FGT_EPI_PS_ADD2) pre = pre + p.aux1[m1 * d.ld_aux1 + co + u] + p.aux2[m * d.ld_aux2 + och + u];
                     float x = fgt_act(pre, d.act, d.slope) * d.out_scale;
                     if (d.epi == FGT_EPI_MUL) {
-                        if (!dual || head1) x *= p.aux1[m1 * d.ld_aux1 + (dual ? och : co) + u];
+                        if (!dual || head1) x *= p.aux1[m1 * d.ld_aux1 + ((dual || (PHASE && d.ps_phase_pad)) ? och : co) + u];
                     } else if (d.epi == FGT_EPI_ADD) {
-                        x = fgt_act(x + p.aux1[m1 * d.ld_aux1 + co + u], d.act2, d.slope);
+                        x = fgt_act(x + p.aux1[m1 * d.ld_aux1 + ((PHASE && d.ps_phase_pad) ? och : co) + u], d.act2, d.slope);
                     } else if (d.epi == FGT_EPI_GRU) {
                         const float z = p.aux1[m * d.ld_aux1 + co + u];
                         const float hh = p.aux2[m * d.ld_aux2 + co + u];

@@ -75,14 +75,21 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_wide_kernel(const Conv
     const int lrow = lane >> 3;
     const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
     int a_iy0[PA], a_ix0[PA], a_nb[PA];
+    // ABI 9 (desc.ps_phase_pad): this workgroup's columns lie in one sub-pixel (a, b) of the x2 output: padding (1 - a, 1 - b) (see conv_split.hip)
+    int ph_e = d.ph, pw_e = d.pw;
+    if (d.ps_phase_pad) {
+        const int q = bn0 / d.ps_c;
+        ph_e -= q >> 1;
+        pw_e -= q & 1;
+    }
 #pragma unroll
     for (int it = 0; it < PA; ++it) {
         const int m = bm0 + (wave + it * NW) * 8 + lrow;
         if (m < p.M) {
             const int n_img = m / p.HoWo, rem = m - n_img * p.HoWo;
             const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
-            a_iy0[it] = oy * d.sh - d.ph;
-            a_ix0[it] = ox * d.sw - d.pw;
+            a_iy0[it] = oy * d.sh - ph_e;
+            a_ix0[it] = ox * d.sw - pw_e;
             a_nb[it] = n_img * d.H * d.W;
         } else {
             a_iy0[it] = 0; a_ix0[it] = 0; a_nb[it] = -1;
@@ -378,7 +385,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) conv_wide_kernel(const Conv
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     // (no bias-map / two-headed instances: interleaved-input layers with those operands are tap-routed or run conv_split.hip; the launcher declines)
-    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, false, false>(conv_epilogue_args(p), acc, smem, bm0, bn0, gb ? 0 : g, gb ? (long)g * d.gb_o : 0l);
+    conv_epilogue<BM, BN, WM, WN, STAGE, TM, TN, false, false, true>(conv_epilogue_args(p), acc, smem, bm0, bn0, gb ? 0 : g, gb ? (long)g * d.gb_o : 0l);
 }
 
 template <int BM, int BN, int WM, int WN, int MINW = 2, int SCHED = 0>
@@ -386,6 +393,7 @@ int launch(const ConvP& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr size_t smem = (size_t)2 * (BM + BN) * LDB * sizeof(float);
     static_assert(smem <= 160 * 1024, "LDS stages do not fit");
+    if (p.d.ps_phase_pad && p.d.ps_c % BN != 0) { fgt_set_error("fgt_conv2d: ps_phase_pad needs a tile whose N width (%d) divides ps_c (%d)", BN, p.d.ps_c); return FGT_EINVAL; }
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = fgt_set_max_lds(reinterpret_cast<const void*>(&conv_wide_kernel<BM, BN, WM, WN, MINW, SCHED>), (int)smem, lds_set, "conv_wide")) return rc;
     ConvP q = p;

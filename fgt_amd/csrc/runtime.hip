@@ -15,7 +15,7 @@ void fgt_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* fgt_last_error(void) { return g_err; }
-extern "C" int fgt_abi_version(void) { return 8; }
+extern "C" int fgt_abi_version(void) { return 9; }
 
 // One 256-byte zero-filled allocation PER DEVICE (the target of out-of-image im2col gathers: a kernel on device d must not be
 // handed memory of device 0), created under a mutex.  fgt_init(device) creates it eagerly so that the lazy path below never runs

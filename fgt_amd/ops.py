@@ -306,10 +306,55 @@ def prepack_weights(pc, mode=None):
         _f16_weights(pc)
 
 
+# "nearest x2 + 3x3" as a 2x2 convolution with a sub-pixel output (fgt_conv_desc.ps_phase_pad, ABI 9): 4 multiply-adds per output value and input
+# channel instead of 9.  FGT_UP4=0: the upsampled 3x3 form on the tap kernels (A/B measurements; results differ by the rounding of the weight sums).
+UP4 = os.environ.get("FGT_UP4", "1") != "0"
+
+
+def up4_weights(w, cpad=None):
+    """[Cout, Cin, 3, 3] -> [4*cpad, Cin, 2, 2] (cpad >= Cout, default Cout: zero rows pad a sub-pixel's channels), rows ordered (a, b, co): sub-pixel (a, b) of the x2 output is a 2x2 convolution over the
+    low-resolution map whose taps are sums of the 3x3 taps that read the same input pixel — rows: a = 0 -> [w(-1)], [w(0) + w(+1)] over input
+    rows {i-1, i}; a = 1 -> [w(-1) + w(0)], [w(+1)] over {i, i+1}; columns likewise (network_blocks_2d.py:46-60: F.interpolate(scale_factor=2)
+    + 3x3 conv, padding 1).  Sums in fp64, rounded once."""
+    w = w.detach().double()
+    Cout, Cin = w.shape[:2]
+    rows = (lambda t: (t[:, :, 0], t[:, :, 1] + t[:, :, 2]), lambda t: (t[:, :, 0] + t[:, :, 1], t[:, :, 2]))      # over dim 2 (ky)
+    cpad = Cout if cpad is None else cpad
+    out = torch.zeros(2, 2, cpad, Cin, 2, 2, dtype=torch.float64, device=w.device)
+    for a in range(2):
+        for ky, wr in enumerate(rows[a](w)):                        # wr [Cout, Cin, 3 (kx)]
+            for b in range(2):
+                cols = (wr[:, :, 0], wr[:, :, 1] + wr[:, :, 2]) if b == 0 else (wr[:, :, 0] + wr[:, :, 1], wr[:, :, 2])
+                for kx, wc in enumerate(cols):
+                    out[a, b, :Cout, :, ky, kx] = wc
+    return out.reshape(4 * cpad, Cin, 2, 2).float()
+
+
+def _up4_pack(pc):
+    """The PackedConv of the 2x2 sub-pixel form of a packed 3x3 layer (cached on it)."""
+    cache = pc.__dict__.setdefault("_w_split_cache", {})
+    if "up4" not in cache:
+        w = pc.w[0, :pc.Cout, :pc.K].reshape(pc.Cout, 3, 3, pc.Cg).permute(0, 3, 1, 2)      # packed k = (ky*3 + kx)*Cg + ci -> [Cout, Cg, 3, 3]
+        cp = ceil_to(pc.Cout, 64)                                   # a sub-pixel's columns padded to the tile width (LAFC: 48 -> 64, 96 -> 128)
+        rep = lambda v, fill: None if v is None else torch.cat([v, v.new_full((cp - pc.Cout,), fill)]).repeat(4)
+        q = PackedConv(up4_weights(w, cp), rep(pc.bias, 0.0), scale=rep(pc.scale, 1.0), pad_cin_to4=False)
+        q.k_alg, q.up4_c = 4 * (pc.k_alg // 9), cp
+        cache["up4"] = q
+    return cache["up4"]
+
+
+def _up4_ok(x, pc, stride, pad, dil, pad_mode, in_relu, epi, out_nchw, tile, precision, ps, ky_skip_n0, aux_per_image, bias_map, dual, out_s, out_il, out_split):
+    return (UP4 and isinstance(x, Split) and not x.h and pc.kh == 3 and pc.kw == 3 and pc.groups == 1 and pc.Cout % 4 == 0 and pc.Cout >= 32 and stride == 1 and pad == 1 and dil == 1 and
+            pad_mode == "zeros" and not in_relu and epi in (None, "mul", "add") and not out_nchw and tile is None and ps is None and not ky_skip_n0 and
+            not aux_per_image and bias_map is None and not dual and (precision or DEFAULT_CONV_PRECISION) == "bf16x3" and pc.Cg % 32 == 0 and
+            not (out_split and (out_il or (out_s is not None and out_s.il)) and pc.Cout % 32))
+
+
+
 def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zeros", in_relu=False, act=None, slope=0.2,
            epi=None, aux1=None, aux2=None, act2=None, out_scale=1.0, out=None, out_nchw=False, tile=None, precision=None,
            out_split=None, out_s=None, out_il=False, out_h=None, ps=None, ky_skip_n0=0, aux_per_image=False, n_alg=0, bias_map=None, tile_order=0,
-           dual=False):
+           dual=False, _phase_pad=0):
     """fgt_conv2d.  x (and optional x1) are channels-last maps (fp32 tensors, or `Split`s for the LDS-DMA bf16x3 path);
     returns/outputs a channels-last map (or NCHW).  out_split: None -> fp32 result; "only" -> a Split; "both" -> (fp32, Split).
     ps = (r, c, g0, Hf, Wf): sub-pixel output (fold as a convolution, fgt_conv_desc.ps_r): the result is the [N, Hf, Wf, c] map;
@@ -317,6 +362,12 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     the activation INSTEAD of pc.bias (fgt_conv_desc.ld_bias; the caller folds the bias into it).
     dual=True (fgt_conv_desc.dual_n0 = Cout / 2, with epi="mul", out_split="both"): two heads — columns [0, Cout/2) -> act(v) into the fp32 `out`
     [.., Cout/2]; columns [Cout/2, Cout) -> act(v) * aux1 into the Split `out_s` [.., Cout/2]."""
+    if upsample and _up4_ok(x, pc, stride, pad, dil, pad_mode, in_relu, epi, out_nchw, tile, precision, ps, ky_skip_n0, aux_per_image, bias_map, dual, out_s, out_il, out_split):
+        # nearest x2 + 3x3 -> the 2x2 sub-pixel form over the low-resolution map (4 of the 9 multiply-adds; ABI 9 ps_phase_pad)
+        Hx, Wx = x.shape[-3], x.shape[-2]
+        q = _up4_pack(pc)
+        return conv2d(x, q, x1=x1, stride=1, pad=1, act=act, slope=slope, epi=epi, aux1=aux1, act2=act2, out_scale=out_scale, out=out,
+                      out_split=out_split, out_s=out_s, out_il=out_il, out_h=out_h, ps=(2, q.up4_c, 2 * q.up4_c, 2 * Hx, 2 * Wx), n_alg=4 * pc.Cout, precision="bf16x3", _phase_pad=pc.Cout)
     in_split = isinstance(x, Split)
     if in_split:
         assert x1 is None or (isinstance(x1, Split) and x1.il == x.il and x1.h == x.h), "conv2d: both sources must be split the same way"
@@ -339,8 +390,10 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     Hin, Win = H * (2 if upsample else 1), W * (2 if upsample else 1)
     Ho = (Hin + 2 * ph - dh * (pc.kh - 1) - 1) // sh + 1
     Wo = (Win + 2 * pw - dw * (pc.kw - 1) - 1) // sw + 1
+    if _phase_pad:
+        Ho, Wo = H, W                            # one tile row per INPUT pixel; padding (1 - a, 1 - b) per sub-pixel (fgt_conv_desc.ps_phase_pad)
     osp = {None: 0, False: 0, "only": 1, "both": 2}[out_split]
-    oshape = (N, Ho, Wo, pc.Cout) if ps is None else (N, ps[3], ps[4], ps[1])       # (sub-pixel output: the folded map)
+    oshape = (N, Ho, Wo, pc.Cout) if ps is None else (N, ps[3], ps[4], _phase_pad or ps[1])       # (sub-pixel output: the folded map; ps_phase_pad: its real channels)
     if dual:
         assert epi == "mul" and out_split == "both" and ps is None and pc.groups == 1 and pc.Cout % 8 == 0, "conv2d: dual needs epi='mul', out_split='both', groups = 1"
         oshape = (N, Ho, Wo, pc.Cout // 2)
@@ -369,6 +422,7 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     if ps is not None:
         d.ps_r, d.ps_c, d.ps_g0, d.ps_H, d.ps_W = (int(v) for v in ps)
     d.ky_skip_n0, d.aux_per_image, d.n_alg = int(ky_skip_n0), int(bool(aux_per_image)), int(n_alg)
+    d.ps_phase_pad = int(_phase_pad)
     # the epilogue indexes its operands by tile row with no bounds of their own: a table of another grid (a stale cache key, another th / tw) would
     # read out of bounds on the device
     rows_out = N * Ho * Wo
@@ -378,6 +432,8 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
         a4, aN, aH, aW, aC, _ = _as_map(a)
         if nm == "aux2" and epi == "ps_add2":
             assert ps is not None and (aN * aH * aW, aC) == (N * ps[3] * ps[4], ps[1]), f"conv2d: ps_add2 aux2 shape {tuple(a.shape)} is not the [N, {ps[3]}, {ps[4]}, {ps[1]}] map"
+        elif _phase_pad:
+            assert (aN * aH * aW, aC) == (N * ps[3] * ps[4], _phase_pad), f"conv2d: {nm} shape {tuple(a.shape)} is not the [N, {ps[3]}, {ps[4]}, {_phase_pad}] output map"
         elif aux_per_image and (nm == "aux1" or epi == "affine"):
             assert (aN * aH * aW, aC) == (Ho * Wo, pc.Cout), f"conv2d: per-image {nm} table shape {tuple(a.shape)} != ({Ho * Wo}, {pc.Cout})"
         else:
@@ -426,7 +482,7 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
     if d.tile == 0 and AUTOTUNE and pc.Cout // pc.groups > 4:
         key = (N, H, W, C0, C1, pc.Cout, pc.groups, pc.kh, pc.kw, sh, sw, ph, pw, dh, dw, d.upsample, d.epi, d.out_nchw, d.precision,
                d.in_split, d.out_split, d.w_il, int(bool(osp) and out_s.il) + 2 * int(bool(osp) and out_s.h), d.pad_mode, d.in_relu,
-               d.ps_r, d.ps_c, d.ps_H, d.ps_W, d.ky_skip_n0, int(d.ld_bias > 0), d.tile_order, d.aux_per_image, d.dual_n0)
+               d.ps_r, d.ps_c, d.ps_H, d.ps_W, d.ky_skip_n0, int(d.ld_bias > 0), d.tile_order, d.aux_per_image, d.dual_n0 + 100000 * d.ps_phase_pad)
         best = _tile_cache.get(key)
         if best is not None and key not in _tile_validated:
             # A cached / loaded tile must belong to the kernel family the GEOMETRY routes this layer to (taps-routed layers: codes 200-299,

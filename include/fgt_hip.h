@@ -151,7 +151,18 @@ typedef struct fgt_conv_desc {
                              * act(v) * aux1[m, n - n0] -> split `out_s` channel ooff_s + n - n0.  RAFT's SepConvGRU: z = sigmoid(convz(hx)) and
                              * r * h = sigmoid(convr(hx)) * h read the same hx (RAFT/update.py:46-49, 53-56): one Cout = 256 launch per GRU half
                              * instead of two of 128, the im2col rows fetched once. */
-    int reserved8;          /* 0 (keeps the 8-byte fields below aligned without implicit padding)                                                    */
+    int ps_phase_pad;       /* ABI 9 (the field was `reserved8` = 0 in ABI 8).  0: off | cv > 0: "nearest x2 upsampling + 3x3 'same' convolution" (zero padding) as ONE
+                             * 2x2 convolution over the LOW-RESOLUTION map with a sub-pixel output (FGT/models/utils/network_blocks_2d.py:46-60: the decoder's
+                             * deconv blocks; LAFC/models/utils/network_blocks.py likewise).  Output pixel (2i + a, 2j + b) of the upsampled convolution sees only
+                             * input rows {i-1, i} (a = 0) or {i, i+1} (a = 1) — likewise the columns —, so sub-pixel (a, b) is a 2x2 convolution whose taps carry
+                             * SUMS of the 3x3 weights (a = 0: [w(-1)], [w(0) + w(+1)]; a = 1: [w(-1) + w(0)], [w(+1)]) and whose padding is (1 - a, 1 - b): 4
+                             * multiply-adds per output value and input channel instead of 9.  Needs ps_r = 2, ps_g0 = 2*ps_c, Cout = 4*ps_c (columns ordered
+                             * (a, b, c)), kh = kw = 2, ph = pw = 1, stride 1, no dilation, no `upsample`, zero padding, groups = 1, split inputs (in_split 1 | 2),
+                             * Ho = H, Wo = W, ps_H = 2*H, ps_W = 2*W, and a tile whose N width divides ps_c (ps_c % 64 == 0): a workgroup's columns then lie in
+                             * one sub-pixel and it subtracts (a, b) from (ph, pw).  The VALUE is cv, the number of real channels per sub-pixel (cv <= ps_c,
+                             * cv % 4 == 0): the output map has cv channels per pixel and columns (a, b, c >= cv) — zero weight rows that pad a layer's channel
+                             * count to the tile width — are dropped.  Served by csrc/conv_split.hip and csrc/conv_wide.hip.  With this mode
+                             * FGT_EPI_MUL / FGT_EPI_ADD read aux1 as a map shaped like the OUTPUT ([N, ps_H, ps_W, cv]: row = output pixel, column = c). */
     long long gb_x0, gb_w, gb_o;
                             /* all 0: off | BATCHED GEMM (needs in_split = 2, w_il = 1, a "wide" tile code, 1 x 1, stride 1, one source, N = 1, fp32 output,
                              * no epilogue / bias / scale, Cout/groups % 8 == 0): group g multiplies ITS OWN rows and ITS OWN weights,

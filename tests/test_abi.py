@@ -25,13 +25,13 @@ def test_library_exports_every_symbol():
     h = ctypes.CDLL(_lib.LIB_PATH)
     for s in declared_symbols():
         assert hasattr(h, s), f"{s} not exported"
-    assert _lib.lib().fgt_abi_version() == _lib.ABI_VERSION == 8
+    assert _lib.lib().fgt_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_struct_sizes_match_header():
     # 44 ints/floats + 3 long long + the 10 ints of ABI 7 in fgt_conv_desc (44 * 4 = 176: no padding before the 8-byte fields; 240 bytes: none behind
     # them), 21 ints in fgt_attn_desc
-    # ABI 8: + dual_n0, reserved8 (ints) and gb_x0, gb_w, gb_o (long long): 272 bytes, no implicit padding
+    # ABI 8: + dual_n0, reserved8 (ints; ABI 9: reserved8 became ps_phase_pad) and gb_x0, gb_w, gb_o (long long): 272 bytes, no implicit padding
     assert ctypes.sizeof(_lib.ConvDesc) == 44 * 4 + 3 * 8 + 10 * 4 + 2 * 4 + 3 * 8
     assert _lib.ConvDesc.gb_x0.offset == 248 and _lib.ConvDesc.dual_n0.offset == 240
     assert ctypes.sizeof(_lib.AttnDesc) == 22 * 4 + 8 + 2 * 4 + 5 * 8 + 2 * 4          # ... in_split, tq | ps* | compact, pad_row

@@ -158,7 +158,11 @@ def test_taps_nearest_upsampling(il, dev):
             assert e <= max(2.0 * e_other, 2e-6 * scale) and e <= 2e-5 * scale, f"{t}: {e:.3e} vs other kernels {e_other:.3e} (scale {scale:.2e})"
             first = got if first is None else first
             assert torch.equal(got, first), t
-        assert torch.equal(ops.conv2d(xs, pc, x1=x1s, pad=1, upsample=True, act="lrelu", precision="bf16x3"), first)      # tile = auto: routed
+        auto = ops.conv2d(xs, pc, x1=x1s, pad=1, upsample=True, act="lrelu", precision="bf16x3")
+        if ops.UP4 and Cout % 4 == 0 and Cout >= 32 and (C0 + C1) % 32 == 0:      # tile = auto: the 2x2 sub-pixel form (tests/test_up4.py), another summation
+            assert (auto.double() - ref).abs().max().item() <= 4e-6 * scale
+        else:                                                        # tile = auto: routed to the tap kernel
+            assert torch.equal(auto, first)
         print(f"[parity] conv_taps upsample x2 {N}x{H}x{W} {C0}+{C1}->{Cout} ({'interleaved' if il else 'planes'}): max |taps - fp64| {e:.2e}, |conv_split - fp64| {e_other:.2e}")
 
 
