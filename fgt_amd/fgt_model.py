@@ -323,6 +323,11 @@ class FGT(nn.Module):
                 for v in o:
                     walk(v)
         walk(P)
+        if mode == "bf16x3":                             # the decoder's two "nearest x2 + 3x3" layers run in their 2x2 sub-pixel form (ops.conv2d: _up4_ok)
+            for blk in (P["dec"][0], P["dec"][2]):
+                for o in blk:
+                    if isinstance(o, PackedConv):
+                        ops.prepack_up4(o)
         dev = dev if dev is not None else next(self.parameters()).device
         self._zero_row(dev, self.cfg["c"] + self.cfg["cf"])
         return self

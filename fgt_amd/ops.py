@@ -343,6 +343,13 @@ def _up4_pack(pc):
     return cache["up4"]
 
 
+def prepack_up4(pc):
+    """Build the 2x2 sub-pixel weight image of a 3x3 layer that is used with upsample=True (and its bf16 hi / lo image) on the CURRENT stream:
+    for callers that fork work onto side streams or capture graphs (fgt_model.Model.prepack)."""
+    if UP4 and pc.kh == 3 and pc.kw == 3 and pc.groups == 1 and pc.Cout % 4 == 0 and pc.Cout >= 32 and pc.Cg % 32 == 0:
+        _split_weights(_up4_pack(pc))
+
+
 def _up4_ok(x, pc, stride, pad, dil, pad_mode, in_relu, epi, out_nchw, tile, precision, ps, ky_skip_n0, aux_per_image, bias_map, dual, out_s, out_il, out_split):
     return (UP4 and isinstance(x, Split) and not x.h and pc.kh == 3 and pc.kw == 3 and pc.groups == 1 and pc.Cout % 4 == 0 and pc.Cout >= 32 and stride == 1 and pad == 1 and dil == 1 and
             pad_mode == "zeros" and not in_relu and epi in (None, "mul", "add") and not out_nchw and tile is None and ps is None and not ky_skip_n0 and
