@@ -218,7 +218,8 @@ def _contract_line(full):
     line = {k: full[k] for k in keep if k in full}
     line["dtype"] = _short(str(full.get("dtype", "")), 120)
     cfg = full.get("config") or {}
-    line["config"] = {k: (_short(v, 200) if isinstance(v, str) else v) for k, v in cfg.items()} if isinstance(cfg, dict) else {"workload": _short(str(cfg), 200)}
+    # (graph_probe — the host-enqueue probe behind --graphs auto — stays in the detail file: host_enqueue_ms_per_step is in the line)
+    line["config"] = {k: (_short(v, 200) if isinstance(v, str) else v) for k, v in cfg.items() if k != "graph_probe"} if isinstance(cfg, dict) else {"workload": _short(str(cfg), 200)}
     return line
 
 
@@ -253,7 +254,7 @@ def _optional_blocks(full, line):
                              for x in full["rooflines"]]      # traffic_x: rocprofv3 counter bytes / algorithmic bytes per launch (HBM kinds)
     cb = full.get("cpu_baseline")
     if cb:
-        line["cpu_baseline"] = {k: (_short(v, 260) if k == "sample" else v) for k, v in cb.items() if k in ("value", "unit", "cores", "host_cores", "kind", "sample", "port_equals_reference")}
+        line["cpu_baseline"] = {k: (_short(v, 200) if k == "sample" else v) for k, v in cb.items() if k in ("value", "unit", "cores", "host_cores", "kind", "sample", "port_equals_reference")}
         if cb.get("reference_record"):
             line["cpu_baseline"]["reference_record"] = {k: cb["reference_record"].get(k) for k in ("value", "cores", "kind", "port_on_the_same_host", "file")}
     pv = full.get("parity_vs_cpu_oracle")
