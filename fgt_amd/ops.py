@@ -8,6 +8,7 @@ buffers are ordinary torch views (stride(-1) == 1, pixel stride = stride(-2)), s
 import ctypes as C
 import math
 import os
+import warnings
 
 import torch
 
@@ -351,7 +352,7 @@ def prepack_up4(pc):
 
 
 def _up4_ok(x, pc, stride, pad, dil, pad_mode, in_relu, epi, out_nchw, tile, precision, ps, ky_skip_n0, aux_per_image, bias_map, dual, out_s, out_il, out_split):
-    return (UP4 and isinstance(x, Split) and not x.h and pc.kh == 3 and pc.kw == 3 and pc.groups == 1 and pc.Cout % 4 == 0 and pc.Cout >= 32 and stride == 1 and pad == 1 and dil == 1 and
+    return (UP4 and "_up4_declined" not in pc.__dict__ and isinstance(x, Split) and not x.h and pc.kh == 3 and pc.kw == 3 and pc.groups == 1 and pc.Cout % 4 == 0 and pc.Cout >= 32 and stride == 1 and pad == 1 and dil == 1 and
             pad_mode == "zeros" and not in_relu and epi in (None, "mul", "add") and not out_nchw and tile is None and ps is None and not ky_skip_n0 and
             not aux_per_image and bias_map is None and not dual and (precision or DEFAULT_CONV_PRECISION) == "bf16x3" and pc.Cg % 32 == 0 and
             not (out_split and (out_il or (out_s is not None and out_s.il)) and pc.Cout % 32))
@@ -373,8 +374,13 @@ def conv2d(x, pc, x1=None, stride=1, pad=0, dil=1, upsample=False, pad_mode="zer
         # nearest x2 + 3x3 -> the 2x2 sub-pixel form over the low-resolution map (4 of the 9 multiply-adds; ABI 9 ps_phase_pad)
         Hx, Wx = x.shape[-3], x.shape[-2]
         q = _up4_pack(pc)
-        return conv2d(x, q, x1=x1, stride=1, pad=1, act=act, slope=slope, epi=epi, aux1=aux1, act2=act2, out_scale=out_scale, out=out,
-                      out_split=out_split, out_s=out_s, out_il=out_il, out_h=out_h, ps=(2, q.up4_c, 2 * q.up4_c, 2 * Hx, 2 * Wx), n_alg=4 * pc.Cout, precision="bf16x3", _phase_pad=pc.Cout)
+        try:
+            return conv2d(x, q, x1=x1, stride=1, pad=1, act=act, slope=slope, epi=epi, aux1=aux1, act2=act2, out_scale=out_scale, out=out,
+                          out_split=out_split, out_s=out_s, out_il=out_il, out_h=out_h, ps=(2, q.up4_c, 2 * q.up4_c, 2 * Hx, 2 * Wx), n_alg=4 * pc.Cout, precision="bf16x3", _phase_pad=pc.Cout)
+        except RuntimeError as e:
+            # a geometry the 2x2 form's kernels decline (argument validation: nothing was launched): the upsampled 3x3 form serves every layer it served before
+            pc.__dict__["_up4_declined"] = str(e)
+            warnings.warn(f"conv2d: the 2x2 sub-pixel form declined this upsampled layer ({e}); using the upsampled 3x3 form")
     in_split = isinstance(x, Split)
     if in_split:
         assert x1 is None or (isinstance(x1, Split) and x1.il == x.il and x1.h == x.h), "conv2d: both sources must be split the same way"
