@@ -119,3 +119,23 @@ def test_up4_rejects_what_it_does_not_serve(dev):
     a = ops.conv2d(xs, pc2, pad=1, upsample=True, precision="bf16x3")
     assert torch.equal(a, ops.conv2d(xs, pc2, pad=1, upsample=True, tile="128x64t", precision="bf16x3"))
     assert torch.equal(ops.conv2d(xs, pc, pad=1, upsample=True, pad_mode="replicate", precision="bf16x3"), ops.conv2d(xs, pc, pad=1, upsample=True, pad_mode="replicate", tile="128x128", precision="bf16x3"))
+
+
+@pytest.mark.gpu
+def test_up4_declined_layer_falls_back_to_the_upsampled_form(dev, monkeypatch):
+    """A layer the 2x2 form's argument validation declines (here: a weight image whose sub-pixel blocks are not padded to the tile width) runs in
+    the upsampled 3x3 form, with a warning, and is remembered."""
+    from fgt_amd import ops
+    xs = ops.split(_rand(1, 8, 8, 64, seed=1).to(dev))
+    pc = ops.PackedConv(_rand(48, 64, 3, 3, seed=2, scale=0.05).to(dev), None)
+    want = ops.conv2d(xs, pc, pad=1, upsample=True, precision="bf16x3", tile="128x64t")
+
+    def bad_pack(p):
+        q = ops.PackedConv(ops.up4_weights(p.w[0, :p.Cout, :p.K].reshape(p.Cout, 3, 3, p.Cg).permute(0, 3, 1, 2)), None, pad_cin_to4=False)
+        q.up4_c = p.Cout                       # 48: not a multiple of 64
+        return q
+    monkeypatch.setattr(ops, "_up4_pack", bad_pack)
+    with pytest.warns(UserWarning, match="2x2 sub-pixel form declined"):
+        got = ops.conv2d(xs, pc, pad=1, upsample=True, precision="bf16x3")
+    assert torch.equal(got, want) and "_up4_declined" in pc.__dict__
+    assert torch.equal(ops.conv2d(xs, pc, pad=1, upsample=True, precision="bf16x3"), want)      # remembered: no second attempt
