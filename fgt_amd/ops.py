@@ -70,6 +70,9 @@ def load_tuning(path):
 
 if os.environ.get("FGT_TUNING_FILE") and os.path.exists(os.environ["FGT_TUNING_FILE"]):
     load_tuning(os.environ["FGT_TUNING_FILE"])
+if os.environ.get("FGT_TUNING_FILE") and os.environ.get("FGT_TUNING_SAVE") == "1":      # tools: write the table this process tuned when it exits
+    import atexit
+    atexit.register(lambda: save_tuning(os.environ["FGT_TUNING_FILE"]))
 
 
 def _stream():

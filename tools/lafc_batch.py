@@ -2,7 +2,7 @@
 """LAFC completion of an 80-frame direction with 8 / 16 / 32 pivots per call (flow_pipeline.complete_flows): ms per flow, bit-equality.
     python tools/lafc_batch.py"""
 import sys, os, time, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fgt_amd import lafc_model, ops, flow_pipeline
 from fgt_amd.synth import synth_state_dict
 ops.DEFAULT_CONV_PRECISION = ops.DEFAULT_ATTN_PRECISION = "bf16x3"
